@@ -1,0 +1,115 @@
+"""CPU tests: the oracle restatement against (a) the committed golden vectors made by the
+reference's own models.py, (b) the reference executed in place (build container only), and
+(c) the substitute pins of SURVEY.md section 8c (param counts, key sets, zero-init identity)."""
+import os
+
+import pytest
+import torch
+from safetensors.torch import load_file
+
+from oracle import cases, unet_ref
+from oracle import controllora_ref as cr
+
+HAVE_REF = os.path.isdir("/root/reference")
+ALL_CASES = list(cases.CASES) + ["lora"]
+
+
+@pytest.mark.parametrize("case", ALL_CASES)
+def test_oracle_matches_golden(case, golden_dir):
+    gold = load_file(os.path.join(golden_dir, f"case_{case}.safetensors"))
+    unet, params, fwd = cases.build_oracle_case(case)
+    assert torch.allclose(cases.weight_checksum(unet), gold["unet_checksum"], rtol=1e-12), "seeded UNet weights drifted"
+    assert torch.allclose(cases.weight_checksum(params), gold["clora_checksum"], rtol=1e-12), "seeded adapter weights drifted"
+    out = cases.oracle_train_step(unet, params, fwd, cases.seeded_inputs())
+    for k, v in out.items():
+        ref = gold[k]
+        err = float((v - ref).norm() / (ref.norm() + 1e-30))
+        assert err < 2e-5, f"{case}:{k} rel-L2 {err:.3e}"
+
+
+@pytest.mark.skipif(not HAVE_REF, reason="/root/reference only exists in the build container")
+@pytest.mark.parametrize("case", ["v1", "v2"])
+def test_oracle_matches_reference_with_adapter_chain(case):
+    """pre_loras / post_loras chaining (reference models.py:232-243, 249-265, 276-282;
+    mix_lora_and_control_lora.py:111-123) -- reference in place vs restatement."""
+    from oracle.diffusers_shim import import_reference_models
+    ref = import_reference_models()
+    torch.manual_seed(0)
+    attn = unet_ref.CrossAttention(64, None, heads=4, dim_head=16)
+    for self_attn in (True, False):
+        attn = unet_ref.CrossAttention(64, None if self_attn else 48, heads=4, dim_head=16)
+        cad = None if self_attn else 48
+        if case == "v1":
+            a = ref.ControlLoRACrossAttnProcessor(64, cad, rank=4)
+            b = cr.ControlLoRAProcRef(64, cad, rank=4)
+        else:
+            a = ref.ControlLoRACrossAttnProcessorV2(64, cad, rank=4, control_channels=32)
+            b = cr.ControlLoRAProcV2Ref(64, cad, rank=4, control_channels=32)
+        pre_a, pre_b = ref.LoRACrossAttnProcessor(64, cad, rank=4), cr.LoRAProcRef(64, cad, rank=4)
+        post_a, post_b = ref.LoRACrossAttnProcessor(64, cad, rank=2, post_add=True), cr.LoRAProcRef(64, cad, rank=2, post_add=True)
+        for m, s in ((a, 1), (pre_a, 2), (post_a, 3)):
+            cases.seeded_weights_(m, seed=s)
+        b.load_state_dict(a.state_dict()); pre_b.load_state_dict(pre_a.state_dict()); post_b.load_state_dict(post_a.state_dict())
+        a.inject_pre_lora(pre_a); a.inject_post_lora(post_a)
+        b.inject_pre_lora(pre_b); b.inject_post_lora(post_b)
+        h = torch.randn(2, 16, 64)
+        e = None if self_attn else torch.randn(2, 5, 48)
+        ctrl = torch.randn(1, 64 if case == "v1" else 32, 4, 4)       # control batch 1 broadcasts (C6)
+        a.inject_control_states(ctrl); b.inject_control_states(ctrl.clone())
+        ya = a(attn, h, e, None, 0.7)
+        yb = b(attn, h, e, None, 0.7)
+        assert torch.allclose(ya, yb, atol=1e-6), float((ya - yb).abs().max())
+
+
+@pytest.mark.skipif(not HAVE_REF, reason="/root/reference only exists in the build container")
+@pytest.mark.parametrize("name,n_params,n_keys", [
+    ("fill50k", 6047040, 400), ("diffusiondb-canny", 6047040, 400), ("mpii-pose", 6047040, 400),
+    ("post-add", 6048576, 400), ("danbooru-sketch", 19810304, 376),
+    ("mpii-pose-v2", 5000704, 312), ("diffusiondb-canny-v2", 5000704, 312)])
+def test_param_counts_and_keys_vs_reference_configs(name, n_params, n_keys):
+    from oracle.diffusers_shim import import_reference_models
+    ref = import_reference_models()
+    path = f"/root/reference/configs/{name}.json"
+    a, b = ref.ControlLoRA.from_config(path), cr.ControlLoRARef.from_config(path)
+    assert sum(p.numel() for p in b.parameters()) == n_params == sum(p.numel() for p in a.parameters())
+    assert set(a.state_dict()) == set(b.state_dict()) and len(b.state_dict()) == n_keys
+
+
+def test_sd15_unet_parameter_count():
+    with torch.device("meta"):
+        u = unet_ref.UNet2DConditionModel()
+    assert sum(p.numel() for p in u.parameters()) == 859_520_964
+    assert len(u.attn_processors) == 32
+
+
+@pytest.mark.parametrize("case", ["v1", "v2"])
+def test_zero_init_identity(case):
+    """a freshly initialised ControlLoRA leaves the UNet output bit-identical."""
+    torch.manual_seed(0)
+    unet = unet_ref.UNet2DConditionModel(**cases.SMALL_UNET)
+    cases.seeded_weights_(unet, seed=11)
+    inp = cases.seeded_inputs()
+    with torch.no_grad():
+        plain = unet(inp["latents"], inp["timesteps"], inp["ehs"]).sample
+        clora = cr.ControlLoRARef(**cases.CASES[case])       # default init: every `up` is zero
+        unet.set_attn_processor(cr.map_processors_to_unet(unet, clora))
+        clora(inp["guide"])
+        with_adapters = unet(inp["latents"], inp["timesteps"], inp["ehs"]).sample
+    assert torch.equal(plain, with_adapters)
+
+
+def test_mapping_order():
+    """M1: lora_layers[i][0..3] -> down_blocks.i, [4..9] -> up_blocks.(3-i), lora_layers[3] -> mid."""
+    unet = unet_ref.UNet2DConditionModel(**cases.SMALL_UNET)
+    clora = cr.ControlLoRARef(**cases.SMALL_CLORA_V1)
+    m = cr.map_processors_to_unet(unet, clora)
+    assert m["down_blocks.1.attentions.0.transformer_blocks.0.attn2.processor"] is clora.lora_layers[1][1]
+    assert m["up_blocks.3.attentions.2.transformer_blocks.0.attn1.processor"] is clora.lora_layers[0][8]
+    assert m["mid_block.attentions.0.transformer_blocks.0.attn2.processor"] is clora.lora_layers[3][1]
+    assert m["up_blocks.1.attentions.0.transformer_blocks.0.attn1.processor"] is clora.lora_layers[2][4]
+
+
+def test_ddim_timesteps():
+    s = unet_ref.DDPMSchedule()
+    ts = s.ddim_timesteps(50)
+    assert ts[0] == 981 and ts[-1] == 1 and len(ts) == 50
