@@ -1,0 +1,119 @@
+"""ctypes binding of the C ABI in ``include/clora.h`` (libclora.so, gfx950).
+
+This is the ONLY way the Python host code reaches the GPU kernels.  There is no CPU or PyTorch
+fallback: if the library was not built (``python -m controllora_amd.build``) importing the ops raises,
+and every wrapper refuses tensors that are not on a HIP device.  PyTorch is used for device memory
+and streams only -- wrappers pass ``tensor.data_ptr()`` and ``torch.cuda.current_stream().cuda_stream``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_build", "libclora.so")
+
+OK, ERR_ARG, ERR_LAUNCH, ERR_WORKSPACE = 0, -1, -2, -3
+_ERR = {ERR_ARG: "bad argument", ERR_LAUNCH: "kernel launch failed", ERR_WORKSPACE: "workspace too small"}
+
+
+class CloraError(RuntimeError):
+    pass
+
+
+class ConvDesc(C.Structure):
+    """mirror of clora_conv_t"""
+    _fields_ = [(n, C.c_int) for n in (
+        "enabled", "Hin", "Win", "Cin", "Hout", "Wout", "ksize", "mul", "kmul", "off", "lim_h", "lim_w", "shift",
+        "need_even")]
+
+
+class Epilogue(C.Structure):
+    """mirror of clora_epilogue_t"""
+    _fields_ = [("bias", C.c_void_p), ("rowadd", C.c_void_p), ("rows_per_batch", C.c_int), ("ld_rowadd", C.c_int),
+                ("residual", C.c_void_p), ("ldr", C.c_int), ("lora_t", C.c_void_p), ("ldt", C.c_int),
+                ("lora_u", C.c_void_p), ("lora_r", C.c_int), ("lora_seg", C.c_int), ("lora_scale", C.c_float)]
+
+
+_P, _I, _Z, _F = C.c_void_p, C.c_int, C.c_size_t, C.c_float
+_PROTOS = {
+    "clora_gemm_f16": [_P, _I, _P, _P, _I, _I, _I, _I, C.POINTER(ConvDesc), C.POINTER(Epilogue), _I, _P, _Z, _P],
+    "clora_conv_wgrad_f16": [_P, _I, _P, _I, _P, _I, _I, _I, C.POINTER(ConvDesc), _P],
+    "clora_attn_fwd_f16": [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _F, _P],
+    "clora_attn_bwd_f16": [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _F, _P],
+    "clora_groupnorm_fwd_f16": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P, _Z, _P],
+    "clora_groupnorm_bwd_f16": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _Z, _P],
+    "clora_layernorm_fwd_f16": [_P, _P, _P, _P, _I, _I, _F, _P],
+    "clora_layernorm_bwd_f16": [_P, _P, _P, _P, _I, _I, _F, _P],
+    "clora_geglu_fwd_f16": [_P, _P, _I, _I, _P],
+    "clora_geglu_bwd_f16": [_P, _P, _P, _I, _I, _P],
+    "clora_lora_down_f16": [_P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "clora_lora_up_f16": [_P, _I, _P, _I, _I, _P, _I, _P, _I, _I, _I, _I, _F, _P],
+    "clora_lora_wgrad_f16": [_P, _I, _P, _I, _I, _P, _I, _I, _I, _I, _I, _F, _I, _P],
+    "clora_add_f16": [_P, _P, _P, _Z, _P],
+    "clora_silu_f16": [_P, _P, _Z, _P],
+    "clora_silu_bwd_f16": [_P, _P, _P, _Z, _P],
+    "clora_copy2d_f16": [_P, _I, _P, _I, _Z, _I, _P],
+    "clora_pool2x2_sum_f16": [_P, _P, _I, _I, _I, _I, _P],
+    "clora_colsum_f16": [_P, _I, _P, _I, _I, _P],
+    "clora_mse_f16": [_P, _P, _P, _P, _Z, _F, _P, _P],
+    "clora_cast_f32_to_f16": [_P, _P, _Z, _P],
+    "clora_cast_f16_to_f32": [_P, _P, _Z, _P],
+    "clora_grad_sumsq_f32": [_P, _Z, _P, _P],
+    "clora_optim_prep_f32": [_P, _F, _F, _F, _I, _F, _F, _I, _P],
+    "clora_adamw_flat_f32": [_P, _P, _P, _P, _Z, _P, _F, _F, _F, _F, _F, _P],
+    "clora_abi_version": [],
+}
+
+
+class Lib:
+    """A loaded libclora with typed prototypes."""
+
+    def __init__(self, path: str = LIB_PATH, require_device: bool = True):
+        if not os.path.exists(path):
+            raise CloraError(
+                f"{path} not found: the gfx950 kernel library is not built.  Run `python -m controllora_amd.build` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU / PyTorch fallback for this path.")
+        self.path = path
+        self.require_device = require_device
+        self.cdll = C.CDLL(path)
+        for name, argtypes in _PROTOS.items():
+            fn = getattr(self.cdll, name)          # AttributeError (loud) if a symbol is missing
+            fn.argtypes = argtypes
+            fn.restype = C.c_int
+        self.cdll.clora_build_info.restype = C.c_char_p
+
+    def call(self, name: str, *args) -> None:
+        rc = getattr(self.cdll, name)(*args)
+        if rc != OK:
+            raise CloraError(f"{name} failed: {_ERR.get(rc, rc)}")
+
+
+_LIB: Optional[Lib] = None
+
+
+def lib() -> Lib:
+    global _LIB
+    if _LIB is None:
+        _LIB = Lib()
+    return _LIB
+
+
+def ptr(t: Optional[torch.Tensor], dtype=None) -> Optional[int]:
+    if t is None:
+        return None
+    L = lib()
+    if L.require_device and not t.is_cuda:
+        raise CloraError("libclora kernels need tensors on a HIP device (no CPU fallback)")
+    if dtype is not None and t.dtype != dtype:
+        raise CloraError(f"expected {dtype}, got {t.dtype}")
+    return t.data_ptr()
+
+
+def stream() -> Optional[int]:
+    if lib().require_device:
+        return torch.cuda.current_stream().cuda_stream
+    return None

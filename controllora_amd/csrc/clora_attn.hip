@@ -1,0 +1,487 @@
+// clora_attn.hip -- fused (flash-style) attention core for gfx950: forward, dQ, dK/dV.
+//
+// Replaces the materialised  baddbmm -> softmax -> bmm  of the reference processors
+// (models.py:140-141, 270-271, 407-408; upstream CrossAttention.get_attention_scores):
+// at 512^2, B=4 that score tensor is 1 GiB per self-attention site and is what autograd keeps for
+// backward; here it never leaves registers.
+//
+// Layout: q/k/v/o are read and written IN PLACE in the [B, N, H*D] token-major activations (row
+// strides ldq/ldk/...), so head_to_batch_dim / batch_to_head_dim permutes disappear.
+//
+// Register-level design (wave = 64 lanes, v_mfma_f32_16x16x32_f16):
+//   * scores are computed TRANSPOSED, S^T = K . Q^T, so every lane owns one query column (lane&15):
+//     softmax statistics (m, l), the LSE and the delta of the backward are lane-local scalars and the
+//     row reductions need only two shuffles (across the 4 lane groups);
+//   * a C-layout tile (lane: col = lane&15, rows 4*(lane>>4)+r) is fed back as the B operand of the
+//     next MFMA WITHOUT any shuffle or LDS round trip: two 16-row tiles give the 8 k-slots of a lane,
+//     and the A operand (V^T, K^T, Q^T, dO^T staged transposed in LDS) is read with the same slot
+//     assignment -- the hardware only pairs slot e of lane-group g of A with slot e of group g of B;
+//   * head dims 40 / 80 / 160 are zero-padded to 64 / 96 / 160 along the contraction dim only.
+#include "clora_common.h"
+#include "../../include/clora.h"
+
+namespace {
+
+struct AttnArgs {
+    const half_t *q, *k, *v, *o, *dO;
+    half_t *out, *dq, *dk, *dv;
+    const float* lse_in;
+    float *lse, *delta;
+    int ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv;
+    int B, H, Nq, Nk, D;
+    float scale;
+};
+
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kLn2 = 0.6931471805599453f;
+constexpr float kNegBig = -1.0e30f;
+
+// [ROWS x DP] row-major tile, zero padded, 16-byte coalesced along d
+template <int ROWS, int DP, int LD>
+__device__ __forceinline__ void stage_rows(half_t* dst, const half_t* src, int ld, int rows_valid, int D, int t) {
+    constexpr int CPR = DP / 8;
+    for (int c = t; c < ROWS * CPR; c += 256) {
+        const int row = c / CPR, col = (c - row * CPR) * 8;
+        half8 v = zero8();
+        if (row < rows_valid && col < D) v = ld8(src + (size_t)row * ld + col);
+        st8(dst + row * LD + col, v);
+    }
+}
+// transposed tile dst[d][row] for d < DROWS (lanes walk the rows so the 2-byte LDS writes do not conflict)
+template <int ROWS, int DROWS, int LDT>
+__device__ __forceinline__ void stage_cols(half_t* dst, const half_t* src, int ld, int rows_valid, int D, int t) {
+    constexpr int CPC = DROWS / 8;
+    for (int c = t; c < ROWS * CPC; c += 256) {
+        const int row = c % ROWS, col = (c / ROWS) * 8;
+        half8 v = zero8();
+        if (row < rows_valid && col < D) v = ld8(src + (size_t)row * ld + col);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dst[(col + e) * LDT + row] = v[e];
+    }
+}
+// A operand from a transposed tile: 8 k-slots = rows {pair*32 + 4g .. +3} and {pair*32 + 16 + 4g .. +3}
+template <int LDT>
+__device__ __forceinline__ half8 frag_cols(const half_t* tile, int drow, int pair, int g) {
+    const half4v a = ld4(tile + drow * LDT + pair * 32 + 4 * g);
+    const half4v b = ld4(tile + drow * LDT + pair * 32 + 16 + 4 * g);
+    half8 r;
+    r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; r[3] = a[3];
+    r[4] = b[0]; r[5] = b[1]; r[6] = b[2]; r[7] = b[3];
+    return r;
+}
+// B operand from two C-layout tiles (same slot assignment as frag_cols)
+__device__ __forceinline__ half8 frag_from_acc(floatx4 lo, floatx4 hi) {
+    half8 r;
+    r[0] = (half_t)lo[0]; r[1] = (half_t)lo[1]; r[2] = (half_t)lo[2]; r[3] = (half_t)lo[3];
+    r[4] = (half_t)hi[0]; r[5] = (half_t)hi[1]; r[6] = (half_t)hi[2]; r[7] = (half_t)hi[3];
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------ forward
+template <int DP, int DT>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
+    constexpr int BKV = 64, LDK = DP + 8, LDV = BKV + 8, KS = DP / 32;
+    __shared__ __attribute__((aligned(16))) half_t smem[BKV * LDK + DT * 16 * LDV];
+    half_t* Ks = smem;
+    half_t* Vt = smem + BKV * LDK;
+    const int t = threadIdx.x, w = t >> 6, l = t & 63, g = l >> 4, li = l & 15;
+    const int b = blockIdx.y / p.H, h = blockIdx.y % p.H;
+    const int q0 = blockIdx.x * 128 + w * 32;
+    const int D = p.D;
+
+    half8 qf[2][KS];
+#pragma unroll
+    for (int qg = 0; qg < 2; ++qg)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int q = q0 + qg * 16 + li, d = ks * 32 + g * 8;
+            qf[qg][ks] = (q < p.Nq && d < D) ? ld8(p.q + ((size_t)b * p.Nq + q) * p.ldq + h * D + d) : zero8();
+        }
+    floatx4 oacc[DT][2];
+#pragma unroll
+    for (int i = 0; i < DT; ++i) { oacc[i][0] = zero4f(); oacc[i][1] = zero4f(); }
+    float mrun[2] = {kNegBig, kNegBig}, lrun[2] = {0.f, 0.f};
+    const float c = p.scale * kLog2e;
+
+    for (int kv0 = 0; kv0 < p.Nk; kv0 += BKV) {
+        const int rows = (p.Nk - kv0 < BKV) ? p.Nk - kv0 : BKV;
+        __syncthreads();
+        stage_rows<BKV, DP, LDK>(Ks, p.k + ((size_t)b * p.Nk + kv0) * p.ldk + h * D, p.ldk, rows, D, t);
+        stage_cols<BKV, DT * 16, LDV>(Vt, p.v + ((size_t)b * p.Nk + kv0) * p.ldv + h * D, p.ldv, rows, D, t);
+        __syncthreads();
+
+        floatx4 s[4][2];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) { s[kt][0] = zero4f(); s[kt][1] = zero4f(); }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                const half8 a = ld8(Ks + (kt * 16 + li) * LDK + ks * 32 + g * 8);
+                s[kt][0] = mfma16(a, qf[0][ks], s[kt][0]);
+                s[kt][1] = mfma16(a, qf[1][ks], s[kt][1]);
+            }
+#pragma unroll
+        for (int qg = 0; qg < 2; ++qg) {
+            float mx = kNegBig;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool ok = (kt * 16 + 4 * g + r) < rows;
+                    const float v = ok ? s[kt][qg][r] * c : kNegBig;
+                    s[kt][qg][r] = v;
+                    mx = fmaxf(mx, v);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float mnew = fmaxf(mrun[qg], mx);
+            const float alpha = exp2f(mrun[qg] - mnew);
+            mrun[qg] = mnew;
+            float ps = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pv = exp2f(s[kt][qg][r] - mnew);
+                    s[kt][qg][r] = pv;
+                    ps += pv;
+                }
+            lrun[qg] = lrun[qg] * alpha + ps;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) oacc[dt][qg] *= alpha;
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const half8 pb0 = frag_from_acc(s[2 * j][0], s[2 * j + 1][0]);
+            const half8 pb1 = frag_from_acc(s[2 * j][1], s[2 * j + 1][1]);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const half8 a = frag_cols<LDV>(Vt, dt * 16 + li, j, g);
+                oacc[dt][0] = mfma16(a, pb0, oacc[dt][0]);
+                oacc[dt][1] = mfma16(a, pb1, oacc[dt][1]);
+            }
+        }
+    }
+#pragma unroll
+    for (int qg = 0; qg < 2; ++qg) {
+        float lt = lrun[qg];
+        lt += __shfl_xor(lt, 16);
+        lt += __shfl_xor(lt, 32);
+        const float inv = 1.0f / lt;
+        const int q = q0 + qg * 16 + li;
+        if (q < p.Nq) {
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const int d = dt * 16 + 4 * g;
+                if (d < D) {
+                    half4v o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = (half_t)(oacc[dt][qg][r] * inv);
+                    st4(p.out + ((size_t)b * p.Nq + q) * p.ldo + h * D + d, o);
+                }
+            }
+            if (g == 0 && p.lse) p.lse[((size_t)b * p.H + h) * p.Nq + q] = (mrun[qg] + log2f(lt)) * kLn2;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ delta
+// delta[b,h,q] = sum_d dO[q,d] * O[q,d]
+__global__ __launch_bounds__(256) void attn_delta_kernel(AttnArgs p) {
+    const size_t total = (size_t)p.B * p.Nq * p.H;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int h = (int)(i % p.H);
+        const size_t row = i / p.H;  // b*Nq + q
+        const half_t* po = p.o + row * p.ldo + h * p.D;
+        const half_t* pd = p.dO + row * p.lddo + h * p.D;
+        float acc = 0.f;
+        for (int d = 0; d < p.D; d += 8) {
+            const half8 a = ld8(po + d), bb = ld8(pd + d);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc += (float)a[e] * (float)bb[e];
+        }
+        const int b = (int)(row / p.Nq), q = (int)(row % p.Nq);
+        p.delta[((size_t)b * p.H + h) * p.Nq + q] = acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ dQ
+template <int DP, int DT, int BKV>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
+    constexpr int LDK = DP + 8, LDT = BKV + 8, KS = DP / 32, KT = BKV / 16, NP = BKV / 32;
+    __shared__ __attribute__((aligned(16))) half_t smem[2 * BKV * LDK + DT * 16 * LDT];
+    half_t* Ks = smem;
+    half_t* Vs = smem + BKV * LDK;
+    half_t* Kt = smem + 2 * BKV * LDK;
+    const int t = threadIdx.x, w = t >> 6, l = t & 63, g = l >> 4, li = l & 15;
+    const int b = blockIdx.y / p.H, h = blockIdx.y % p.H;
+    const int q0 = blockIdx.x * 128 + w * 32;
+    const int D = p.D;
+
+    half8 qf[2][KS], dof[2][KS];
+    float Lq[2], Dq[2];
+#pragma unroll
+    for (int qg = 0; qg < 2; ++qg) {
+        const int q = q0 + qg * 16 + li;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int d = ks * 32 + g * 8;
+            const bool ok = q < p.Nq && d < D;
+            qf[qg][ks] = ok ? ld8(p.q + ((size_t)b * p.Nq + q) * p.ldq + h * D + d) : zero8();
+            dof[qg][ks] = ok ? ld8(p.dO + ((size_t)b * p.Nq + q) * p.lddo + h * D + d) : zero8();
+        }
+        const size_t si = ((size_t)b * p.H + h) * p.Nq + q;
+        Lq[qg] = (q < p.Nq) ? p.lse_in[si] * kLog2e : 1.0e30f;
+        Dq[qg] = (q < p.Nq) ? p.delta[si] : 0.f;
+    }
+    floatx4 acc[DT][2];
+#pragma unroll
+    for (int i = 0; i < DT; ++i) { acc[i][0] = zero4f(); acc[i][1] = zero4f(); }
+    const float c = p.scale * kLog2e;
+
+    for (int kv0 = 0; kv0 < p.Nk; kv0 += BKV) {
+        const int rows = (p.Nk - kv0 < BKV) ? p.Nk - kv0 : BKV;
+        const half_t* kg = p.k + ((size_t)b * p.Nk + kv0) * p.ldk + h * D;
+        __syncthreads();
+        stage_rows<BKV, DP, LDK>(Ks, kg, p.ldk, rows, D, t);
+        stage_rows<BKV, DP, LDK>(Vs, p.v + ((size_t)b * p.Nk + kv0) * p.ldv + h * D, p.ldv, rows, D, t);
+        stage_cols<BKV, DT * 16, LDT>(Kt, kg, p.ldk, rows, D, t);
+        __syncthreads();
+
+        floatx4 s[KT][2], dp[KT][2];
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) { s[kt][0] = zero4f(); s[kt][1] = zero4f(); dp[kt][0] = zero4f(); dp[kt][1] = zero4f(); }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) {
+                const half8 a = ld8(Ks + (kt * 16 + li) * LDK + ks * 32 + g * 8);
+                const half8 av = ld8(Vs + (kt * 16 + li) * LDK + ks * 32 + g * 8);
+                s[kt][0] = mfma16(a, qf[0][ks], s[kt][0]);
+                s[kt][1] = mfma16(a, qf[1][ks], s[kt][1]);
+                dp[kt][0] = mfma16(av, dof[0][ks], dp[kt][0]);
+                dp[kt][1] = mfma16(av, dof[1][ks], dp[kt][1]);
+            }
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int qg = 0; qg < 2; ++qg)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool ok = (kt * 16 + 4 * g + r) < rows;
+                    const float pv = ok ? exp2f(s[kt][qg][r] * c - Lq[qg]) : 0.f;
+                    s[kt][qg][r] = pv * (dp[kt][qg][r] - Dq[qg]);  // dS^T
+                }
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const half8 b0 = frag_from_acc(s[2 * j][0], s[2 * j + 1][0]);
+            const half8 b1 = frag_from_acc(s[2 * j][1], s[2 * j + 1][1]);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const half8 a = frag_cols<LDT>(Kt, dt * 16 + li, j, g);
+                acc[dt][0] = mfma16(a, b0, acc[dt][0]);
+                acc[dt][1] = mfma16(a, b1, acc[dt][1]);
+            }
+        }
+    }
+#pragma unroll
+    for (int qg = 0; qg < 2; ++qg) {
+        const int q = q0 + qg * 16 + li;
+        if (q < p.Nq) {
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const int d = dt * 16 + 4 * g;
+                if (d < D) {
+                    half4v o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = (half_t)(acc[dt][qg][r] * p.scale);
+                    st4(p.dq + ((size_t)b * p.Nq + q) * p.lddq + h * D + d, o);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ dK, dV
+template <int DP, int DT, int BQT>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs p) {
+    constexpr int LDK = DP + 8, LDT = BQT + 8, KS = DP / 32, QT = BQT / 16, NP = BQT / 32;
+    constexpr int HALVES = 2 * BQT * LDK + 2 * DT * 16 * LDT;
+    __shared__ __attribute__((aligned(16))) half_t smem[HALVES + 4 * BQT];
+    half_t* Qs = smem;
+    half_t* dOs = smem + BQT * LDK;
+    half_t* Qt = smem + 2 * BQT * LDK;
+    half_t* dOt = Qt + DT * 16 * LDT;
+    float* Ls = reinterpret_cast<float*>(smem + HALVES);
+    float* Ds = Ls + BQT;
+    const int t = threadIdx.x, w = t >> 6, l = t & 63, g = l >> 4, li = l & 15;
+    const int b = blockIdx.y / p.H, h = blockIdx.y % p.H;
+    const int k0 = blockIdx.x * 128 + w * 32;
+    const int D = p.D;
+
+    half8 kf[2][KS], vf[2][KS];
+#pragma unroll
+    for (int kg = 0; kg < 2; ++kg)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int key = k0 + kg * 16 + li, d = ks * 32 + g * 8;
+            const bool ok = key < p.Nk && d < D;
+            kf[kg][ks] = ok ? ld8(p.k + ((size_t)b * p.Nk + key) * p.ldk + h * D + d) : zero8();
+            vf[kg][ks] = ok ? ld8(p.v + ((size_t)b * p.Nk + key) * p.ldv + h * D + d) : zero8();
+        }
+    floatx4 dkacc[DT][2], dvacc[DT][2];
+#pragma unroll
+    for (int i = 0; i < DT; ++i) { dkacc[i][0] = zero4f(); dkacc[i][1] = zero4f(); dvacc[i][0] = zero4f(); dvacc[i][1] = zero4f(); }
+    const float c = p.scale * kLog2e;
+
+    for (int qq = 0; qq < p.Nq; qq += BQT) {
+        const int rows = (p.Nq - qq < BQT) ? p.Nq - qq : BQT;
+        const half_t* qg_ = p.q + ((size_t)b * p.Nq + qq) * p.ldq + h * D;
+        const half_t* dog = p.dO + ((size_t)b * p.Nq + qq) * p.lddo + h * D;
+        __syncthreads();
+        stage_rows<BQT, DP, LDK>(Qs, qg_, p.ldq, rows, D, t);
+        stage_rows<BQT, DP, LDK>(dOs, dog, p.lddo, rows, D, t);
+        stage_cols<BQT, DT * 16, LDT>(Qt, qg_, p.ldq, rows, D, t);
+        stage_cols<BQT, DT * 16, LDT>(dOt, dog, p.lddo, rows, D, t);
+        if (t < BQT) {
+            const size_t si = ((size_t)b * p.H + h) * p.Nq + qq + t;
+            Ls[t] = (t < rows) ? p.lse_in[si] * kLog2e : 1.0e30f;
+            Ds[t] = (t < rows) ? p.delta[si] : 0.f;
+        }
+        __syncthreads();
+
+        floatx4 s[QT][2], dp[QT][2];
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) { s[qt][0] = zero4f(); s[qt][1] = zero4f(); dp[qt][0] = zero4f(); dp[qt][1] = zero4f(); }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) {
+                const half8 a = ld8(Qs + (qt * 16 + li) * LDK + ks * 32 + g * 8);
+                const half8 ad = ld8(dOs + (qt * 16 + li) * LDK + ks * 32 + g * 8);
+                s[qt][0] = mfma16(a, kf[0][ks], s[qt][0]);
+                s[qt][1] = mfma16(a, kf[1][ks], s[qt][1]);
+                dp[qt][0] = mfma16(ad, vf[0][ks], dp[qt][0]);
+                dp[qt][1] = mfma16(ad, vf[1][ks], dp[qt][1]);
+            }
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ql = qt * 16 + 4 * g + r;
+                const float Lv = Ls[ql], Dv = Ds[ql];
+#pragma unroll
+                for (int kg = 0; kg < 2; ++kg) {
+                    const float pv = exp2f(s[qt][kg][r] * c - Lv);
+                    s[qt][kg][r] = pv;                       // P
+                    dp[qt][kg][r] = pv * (dp[qt][kg][r] - Dv);  // dS
+                }
+            }
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const half8 p0 = frag_from_acc(s[2 * j][0], s[2 * j + 1][0]);
+            const half8 p1 = frag_from_acc(s[2 * j][1], s[2 * j + 1][1]);
+            const half8 d0 = frag_from_acc(dp[2 * j][0], dp[2 * j + 1][0]);
+            const half8 d1 = frag_from_acc(dp[2 * j][1], dp[2 * j + 1][1]);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const half8 ao = frag_cols<LDT>(dOt, dt * 16 + li, j, g);
+                const half8 aq = frag_cols<LDT>(Qt, dt * 16 + li, j, g);
+                dvacc[dt][0] = mfma16(ao, p0, dvacc[dt][0]);
+                dvacc[dt][1] = mfma16(ao, p1, dvacc[dt][1]);
+                dkacc[dt][0] = mfma16(aq, d0, dkacc[dt][0]);
+                dkacc[dt][1] = mfma16(aq, d1, dkacc[dt][1]);
+            }
+        }
+    }
+#pragma unroll
+    for (int kg = 0; kg < 2; ++kg) {
+        const int key = k0 + kg * 16 + li;
+        if (key < p.Nk) {
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const int d = dt * 16 + 4 * g;
+                if (d < D) {
+                    half4v ok_, ov;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { ok_[r] = (half_t)(dkacc[dt][kg][r] * p.scale); ov[r] = (half_t)dvacc[dt][kg][r]; }
+                    st4(p.dk + ((size_t)b * p.Nk + key) * p.lddk + h * D + d, ok_);
+                    st4(p.dv + ((size_t)b * p.Nk + key) * p.lddv + h * D + d, ov);
+                }
+            }
+        }
+    }
+}
+
+template <int DP, int DT>
+int launch_fwd(const AttnArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL((attn_fwd_kernel<DP, DT>), dim3(clora_cdiv(a.Nq, 128), a.B * a.H), dim3(256), 0, s, a);
+    return clora_check_launch();
+}
+template <int DP, int DT, int BT>
+int launch_bwd(const AttnArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<DP, DT, BT>), dim3(clora_cdiv(a.Nq, 128), a.B * a.H), dim3(256), 0, s, a);
+    int rc = clora_check_launch();
+    if (rc != CLORA_OK) return rc;
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<DP, DT, BT>), dim3(clora_cdiv(a.Nk, 128), a.B * a.H), dim3(256), 0, s, a);
+    return clora_check_launch();
+}
+
+bool bad_dims(int B, int H, int Nq, int Nk, int D) {
+    return B <= 0 || H <= 0 || Nq <= 0 || Nk <= 0 || D <= 0 || (D & 7) || D > 160;
+}
+
+}  // namespace
+
+#define CLORA_ATTN_DISPATCH(FN, ...)                                  \
+    do {                                                              \
+        const int dt_ = (a.D + 15) / 16;                              \
+        if (a.D <= 32) return FN<32, 2 __VA_ARGS__>(a, s);            \
+        if (a.D <= 64 && dt_ <= 3) return FN<64, 3 __VA_ARGS__>(a, s);\
+        if (a.D <= 64) return FN<64, 4 __VA_ARGS__>(a, s);            \
+        if (a.D <= 96 && dt_ <= 5) return FN<96, 5 __VA_ARGS__>(a, s);\
+        if (a.D <= 96) return FN<96, 6 __VA_ARGS__>(a, s);            \
+    } while (0)
+
+extern "C" int clora_attn_fwd_f16(const clora_half* q, int ldq, const clora_half* k, int ldk, const clora_half* v,
+                                  int ldv, clora_half* o, int ldo, float* lse, int B, int H, int Nq, int Nk, int D,
+                                  float scale, void* stream) {
+    if (!q || !k || !v || !o || bad_dims(B, H, Nq, Nk, D) || ((ldq | ldk | ldv | ldo) & 7)) return CLORA_ERR_ARG;
+    AttnArgs a = AttnArgs();
+    a.q = (const half_t*)q; a.k = (const half_t*)k; a.v = (const half_t*)v; a.out = (half_t*)o; a.lse = lse;
+    a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
+    a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.D = D; a.scale = scale;
+    hipStream_t s = (hipStream_t)stream;
+    CLORA_ATTN_DISPATCH(launch_fwd);
+    if (D <= 128) return launch_fwd<128, 8>(a, s);
+    return launch_fwd<160, 10>(a, s);
+}
+
+extern "C" int clora_attn_bwd_f16(const clora_half* q, int ldq, const clora_half* k, int ldk, const clora_half* v,
+                                  int ldv, const clora_half* o, int ldo, const clora_half* dO, int lddo,
+                                  const float* lse, float* delta, clora_half* dq, int lddq, clora_half* dk, int lddk,
+                                  clora_half* dv, int lddv, int B, int H, int Nq, int Nk, int D, float scale,
+                                  void* stream) {
+    if (!q || !k || !v || !o || !dO || !lse || !delta || !dq || !dk || !dv || bad_dims(B, H, Nq, Nk, D) ||
+        ((ldq | ldk | ldv | ldo | lddo | lddq | lddk | lddv) & 7))
+        return CLORA_ERR_ARG;
+    AttnArgs a = AttnArgs();
+    a.q = (const half_t*)q; a.k = (const half_t*)k; a.v = (const half_t*)v; a.o = (const half_t*)o;
+    a.dO = (const half_t*)dO; a.lse_in = lse; a.delta = delta;
+    a.dq = (half_t*)dq; a.dk = (half_t*)dk; a.dv = (half_t*)dv;
+    a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.lddo = lddo; a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
+    a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.D = D; a.scale = scale;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t total = (size_t)B * Nq * H;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(attn_delta_kernel, dim3(blocks), dim3(256), 0, s, a);
+    int rc = clora_check_launch();
+    if (rc != CLORA_OK) return rc;
+#define COMMA_64 , 64
+#define COMMA_32 , 32
+    CLORA_ATTN_DISPATCH(launch_bwd, COMMA_64);
+    if (D <= 128) return launch_bwd<128, 8, 32>(a, s);
+    return launch_bwd<160, 10, 32>(a, s);
+}

@@ -1,0 +1,81 @@
+// clora_common.h -- shared device helpers for the gfx950 (CDNA4 / MI355X) kernels.
+//
+// Conventions used by every kernel in this directory
+//   * activations are fp16, "tokens x channels" row-major (NHWC for images): [B, H*W, C]
+//   * accumulation is fp32 on the matrix cores: v_mfma_f32_16x16x32_f16
+//       A fragment: lane l holds A[row = l&15][8 k-slots of group g = l>>4]
+//       B fragment: lane l holds B[8 k-slots of group g = l>>4][col = l&15]
+//       C/D       : lane l holds D[row = 4*(l>>4)+r][col = l&15], r = 0..3
+//     (the hardware pairs k-slot e of group g of A with k-slot e of group g of B, so any
+//      consistent assignment of logical k to (g, e) on both operands is valid -- the
+//      attention kernels use this to feed a C-layout tile straight back in as a B operand)
+//   * wave = 64 lanes, workgroups are 256 threads (4 waves) unless stated
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef _Float16 half_t;
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef _Float16 half4v __attribute__((ext_vector_type(4)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+#define CLORA_WAVE 64
+
+// error codes of the C ABI (include/clora.h)
+#define CLORA_OK 0
+#define CLORA_ERR_ARG (-1)
+#define CLORA_ERR_LAUNCH (-2)
+#define CLORA_ERR_WORKSPACE (-3)
+
+__device__ __forceinline__ floatx4 mfma16(half8 a, half8 b, floatx4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ half8 ld8(const half_t* p) { return *reinterpret_cast<const half8*>(p); }
+__device__ __forceinline__ void st8(half_t* p, half8 v) { *reinterpret_cast<half8*>(p) = v; }
+__device__ __forceinline__ half4v ld4(const half_t* p) { return *reinterpret_cast<const half4v*>(p); }
+__device__ __forceinline__ void st4(half_t* p, half4v v) { *reinterpret_cast<half4v*>(p) = v; }
+__device__ __forceinline__ half8 zero8() {
+    half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+    return z;
+}
+__device__ __forceinline__ floatx4 zero4f() {
+    floatx4 z = {0.f, 0.f, 0.f, 0.f};
+    return z;
+}
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
+// d/dx silu(x) = s + x*s*(1-s), s = sigmoid(x)
+__device__ __forceinline__ float dsilu_f(float x) {
+    float s = 1.0f / (1.0f + expf(-x));
+    return s * (1.0f + x * (1.0f - s));
+}
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float dgelu_f(float x) {
+    float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+    float pdf = 0.39894228040143268f * expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+    v += __shfl_xor(v, 32);
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 8);
+    v += __shfl_xor(v, 4);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 1);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+    v = fmaxf(v, __shfl_xor(v, 32));
+    v = fmaxf(v, __shfl_xor(v, 16));
+    v = fmaxf(v, __shfl_xor(v, 8));
+    v = fmaxf(v, __shfl_xor(v, 4));
+    v = fmaxf(v, __shfl_xor(v, 2));
+    v = fmaxf(v, __shfl_xor(v, 1));
+    return v;
+}
+
+static inline int clora_check_launch() { return hipGetLastError() == hipSuccess ? CLORA_OK : CLORA_ERR_LAUNCH; }
+static inline int clora_cdiv(long a, long b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,423 @@
+// clora_gemm.hip -- fp16 MFMA GEMM / implicit-GEMM convolution for gfx950.
+//
+//   C[M,N] = epilogue( A[M,K] . B[N,K]^T )
+//
+// One kernel family serves every dense contraction of the path: Linear
+// and 1x1 conv (plain A), 3x3 conv forward / strided / nearest-upsampled and the dgrad of each
+// (A rows gathered on the fly from the NHWC activation, include/clora.h clora_conv_t), with the
+// frozen weight always presented K-contiguous as B[N,K] (packed once at load time; the transposed /
+// tap-flipped dgrad copy is a second packed tensor -- HBM is 288 GB, the UNet is 1.7 GB).
+//
+// Tiling: 256 threads = 4 waves, BMxBN output tile, BK = 32 (one v_mfma_f32_16x16x32_f16 k-step),
+// register-staged global->LDS double buffer (one barrier per k-step), 80-byte LDS rows (conflict-free
+// ds_read_b128 fragments), accumulators staged through LDS in the epilogue so C / residual traffic is
+// 16-byte coalesced.  split-K (grid.y) writes fp32 slabs that a second kernel reduces + finishes.
+#include "clora_common.h"
+#include "../../include/clora.h"
+
+namespace {
+
+struct GemmArgs {
+    const half_t* A;
+    const half_t* B;
+    half_t* C;
+    float* partial;
+    int lda, ldc, M, N, K;
+    int k_per_split;
+    int tiles_n;
+    clora_conv_t conv;
+    clora_epilogue_t epi;
+};
+
+// everything of the epilogue that happens BEFORE the fp16 rounding
+__device__ __forceinline__ float epi_pre(float acc, int m, int n, const clora_epilogue_t& e) {
+    if (e.bias) acc += e.bias[n];
+    if (e.rowadd) acc += (float)((const half_t*)e.rowadd)[(size_t)(m / e.rows_per_batch) * e.ld_rowadd + n];
+    if (e.lora_t) {
+        const int r = e.lora_r;
+        const float* t = e.lora_t + (size_t)m * e.ldt + (n / e.lora_seg) * r;
+        const float* u = e.lora_u + (size_t)n * r;
+        float s = 0.f;
+        for (int j = 0; j < r; ++j) s += t[j] * u[j];
+        acc += e.lora_scale * s;
+    }
+    return acc;
+}
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
+    constexpr int BK = 32, LD = BK + 8;
+    constexpr int FM = BM / WM / 16, FN = BN / WN / 16;
+    constexpr int A_CH = BM / 64, B_CH = BN / 64;
+    constexpr int STAGE = (BM + BN) * LD;
+    constexpr int C_LD = BN + 8;
+    constexpr int SMEM = (2 * STAGE > BM * C_LD) ? 2 * STAGE : BM * C_LD;
+    __shared__ __attribute__((aligned(16))) half_t smem[SMEM];
+
+    const int t = threadIdx.x;
+    const int tile_m = blockIdx.x / p.tiles_n, tile_n = blockIdx.x % p.tiles_n;
+    const int split = blockIdx.y;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int kbeg = split * p.k_per_split;
+    const int kend = (kbeg + p.k_per_split < p.K) ? kbeg + p.k_per_split : p.K;
+    const int nk = (kend - kbeg + BK - 1) / BK;
+
+    // ---- loader state: thread owns 16-byte chunk column kc of rows r0 + 64*i
+    const int kc = t & 3, r0 = t >> 2;
+    const bool conv = p.conv.enabled != 0;
+    bool a_ok[A_CH];
+    size_t a_base[A_CH];
+    int a_ty[A_CH], a_tx[A_CH];
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i) {
+        const int m = m0 + r0 + 64 * i;
+        a_ok[i] = m < p.M;
+        a_base[i] = 0; a_ty[i] = 0; a_tx[i] = 0;
+        if (a_ok[i]) {
+            if (!conv) {
+                a_base[i] = (size_t)m * p.lda;
+            } else {
+                const int hw = p.conv.Hout * p.conv.Wout;
+                const int b = m / hw, rem = m - b * hw;
+                const int yo = rem / p.conv.Wout, xo = rem - yo * p.conv.Wout;
+                a_base[i] = (size_t)b * p.conv.Hin * p.conv.Win;
+                a_ty[i] = yo * p.conv.mul + p.conv.off;
+                a_tx[i] = xo * p.conv.mul + p.conv.off;
+            }
+        }
+    }
+    bool b_ok[B_CH];
+    size_t b_base[B_CH];
+#pragma unroll
+    for (int i = 0; i < B_CH; ++i) {
+        const int n = n0 + r0 + 64 * i;
+        b_ok[i] = n < p.N;
+        b_base[i] = (size_t)n * p.K;
+    }
+    int k = kbeg + kc * 8;  // this thread's k for the tile being loaded
+    int tap = 0, ci = k;
+    if (conv) { tap = k / p.conv.Cin; ci = k - tap * p.conv.Cin; }
+
+    half8 ra[A_CH], rb[B_CH];
+    auto load_tile = [&]() {
+        const bool kok = k < kend;
+        int ky = 0, kx = 0;
+        if (conv) { ky = tap / p.conv.ksize; kx = tap - ky * p.conv.ksize; }
+#pragma unroll
+        for (int i = 0; i < A_CH; ++i) {
+            half8 v = zero8();
+            if (a_ok[i] && kok) {
+                if (!conv) {
+                    v = ld8(p.A + a_base[i] + k);
+                } else {
+                    const int ty = a_ty[i] + ky * p.conv.kmul, tx = a_tx[i] + kx * p.conv.kmul;
+                    bool ok = ty >= 0 && ty < p.conv.lim_h && tx >= 0 && tx < p.conv.lim_w;
+                    if (p.conv.need_even) ok = ok && (((ty | tx) & 1) == 0);
+                    if (ok)
+                        v = ld8(p.A + (a_base[i] + (size_t)(ty >> p.conv.shift) * p.conv.Win + (tx >> p.conv.shift)) * p.conv.Cin + ci);
+                }
+            }
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < B_CH; ++i) {
+            half8 v = zero8();
+            if (b_ok[i] && kok) v = ld8(p.B + b_base[i] + k);
+            rb[i] = v;
+        }
+        k += BK;
+        if (conv) {
+            ci += BK;
+            while (ci >= p.conv.Cin) { ci -= p.conv.Cin; ++tap; }
+        }
+    };
+    auto store_tile = [&](int buf) {
+        half_t* As = smem + buf * STAGE;
+        half_t* Bs = As + BM * LD;
+#pragma unroll
+        for (int i = 0; i < A_CH; ++i) st8(As + (r0 + 64 * i) * LD + kc * 8, ra[i]);
+#pragma unroll
+        for (int i = 0; i < B_CH; ++i) st8(Bs + (r0 + 64 * i) * LD + kc * 8, rb[i]);
+    };
+
+    const int w = t >> 6, l = t & 63, g = l >> 4, li = l & 15;
+    const int wm = w / WN, wn = w % WN;
+    floatx4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = zero4f();
+
+    if (nk > 0) {
+        load_tile();
+        store_tile(0);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) load_tile();
+        const half_t* As = smem + buf * STAGE;
+        const half_t* Bs = As + BM * LD;
+        half8 af[FM], bf[FN];
+#pragma unroll
+        for (int i = 0; i < FM; ++i) af[i] = ld8(As + (wm * FM * 16 + i * 16 + li) * LD + g * 8);
+#pragma unroll
+        for (int j = 0; j < FN; ++j) bf[j] = ld8(Bs + (wn * FN * 16 + j * 16 + li) * LD + g * 8);
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) acc[i][j] = mfma16(af[i], bf[j], acc[i][j]);
+        if (kt + 1 < nk) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- split-K: raw fp32 slab, finished by splitk_finish_kernel
+    if (p.partial) {
+        float* slab = p.partial + (size_t)split * p.M * p.N;
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = m0 + wm * FM * 16 + i * 16 + 4 * g + r;
+                    const int n = n0 + wn * FN * 16 + j * 16 + li;
+                    if (m < p.M && n < p.N) slab[(size_t)m * p.N + n] = acc[i][j][r];
+                }
+        return;
+    }
+
+    // ---- fused epilogue: acc -> (+bias, +rowadd, +LoRA) -> fp16 -> LDS -> (+residual) -> 16-B stores
+    half_t* Cs = smem;
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ml = wm * FM * 16 + i * 16 + 4 * g + r;
+                const int nl = wn * FN * 16 + j * 16 + li;
+                const int m = m0 + ml, n = n0 + nl;
+                float v = acc[i][j][r];
+                if (m < p.M && n < p.N) v = epi_pre(v, m, n, p.epi);
+                Cs[ml * C_LD + nl] = (half_t)v;
+            }
+    __syncthreads();
+    constexpr int CPR = BN / 8;  // chunks per row
+    for (int c = t; c < BM * CPR; c += 256) {
+        const int ml = c / CPR, nc = c - ml * CPR;
+        const int m = m0 + ml, n = n0 + nc * 8;
+        if (m < p.M && n < p.N) {
+            half8 v = ld8(Cs + ml * C_LD + nc * 8);
+            if (p.epi.residual) {
+                const half8 rr = ld8((const half_t*)p.epi.residual + (size_t)m * p.epi.ldr + n);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)rr[e]);
+            }
+            st8(p.C + (size_t)m * p.ldc + n, v);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void splitk_finish_kernel(GemmArgs p, int splits) {
+    const size_t chunks = (size_t)p.M * (p.N / 8);
+    for (size_t c = (size_t)blockIdx.x * 256 + threadIdx.x; c < chunks; c += (size_t)gridDim.x * 256) {
+        const int m = (int)(c / (p.N / 8));
+        const int n = (int)(c - (size_t)m * (p.N / 8)) * 8;
+        float s[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s[e] = 0.f;
+        for (int z = 0; z < splits; ++z) {
+            const float* q = p.partial + ((size_t)z * p.M + m) * p.N + n;
+            const floatx4 a = *reinterpret_cast<const floatx4*>(q);
+            const floatx4 b = *reinterpret_cast<const floatx4*>(q + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { s[e] += a[e]; s[4 + e] += b[e]; }
+        }
+        half8 v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (half_t)epi_pre(s[e], m, n + e, p.epi);
+        if (p.epi.residual) {
+            const half8 rr = ld8((const half_t*)p.epi.residual + (size_t)m * p.epi.ldr + n);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)rr[e]);
+        }
+        st8(p.C + (size_t)m * p.ldc + n, v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight gradient of a trainable convolution: dW[N, K] += dY[M,N]^T . gather(X)[M,K]
+// Reduction runs over the GEMM rows m, so both operands are staged TRANSPOSED in LDS
+// (At[n][m], Bt[kcol][m]) and the M axis plays the MFMA k role.  One block = 64(n) x 64(kcol)
+// output tile over one M chunk; fp32 atomics combine the M chunks.
+struct WgradArgs {
+    const half_t* dY;
+    const half_t* X;
+    float* dW;
+    int ldy, ldx, M, N, K;
+    int m_per_block;
+    int tiles_n, tiles_k;
+    clora_conv_t conv;
+};
+
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
+    constexpr int BT = 64, BMR = 32, LD = BMR + 8;
+    __shared__ __attribute__((aligned(16))) half_t smem[2 * BT * LD];
+    half_t* At = smem;             // [n][m]
+    half_t* Bt = smem + BT * LD;   // [kcol][m]
+    const int t = threadIdx.x;
+    const int tile = blockIdx.x;
+    const int tn = tile % p.tiles_n, tk = tile / p.tiles_n;
+    const int n0 = tn * BT, k0 = tk * BT;
+    const int mbeg = blockIdx.y * p.m_per_block;
+    const int mend = (mbeg + p.m_per_block < p.M) ? mbeg + p.m_per_block : p.M;
+    const bool conv = p.conv.enabled != 0;
+
+    // loader: chunk (row mr = t/8, 8 consecutive columns cc = (t%8)*8) of both 32x64 tiles
+    const int mr = t >> 3, cc = (t & 7) * 8;
+    const int kcol = k0 + cc;
+    int tap = 0, ci = kcol, ky = 0, kx = 0;
+    if (conv) { tap = kcol / p.conv.Cin; ci = kcol - tap * p.conv.Cin; ky = tap / p.conv.ksize; kx = tap - ky * p.conv.ksize; }
+    const bool kcol_ok = kcol < p.K;
+    const bool ncol_ok = (n0 + cc) < p.N;
+
+    const int w = t >> 6, l = t & 63, g = l >> 4, li = l & 15;
+    const int wm = w >> 1, wn = w & 1;  // 2x2 waves, each 32(n) x 32(kcol)
+    floatx4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = zero4f();
+
+    for (int mt = mbeg; mt < mend; mt += BMR) {
+        const int m = mt + mr;
+        half8 va = zero8(), vb = zero8();
+        if (m < mend) {
+            if (ncol_ok) va = ld8(p.dY + (size_t)m * p.ldy + n0 + cc);
+            if (kcol_ok) {
+                if (!conv) {
+                    vb = ld8(p.X + (size_t)m * p.ldx + kcol);
+                } else {
+                    const int hw = p.conv.Hout * p.conv.Wout;
+                    const int b = m / hw, rem = m - b * hw;
+                    const int yo = rem / p.conv.Wout, xo = rem - yo * p.conv.Wout;
+                    const int ty = yo * p.conv.mul + p.conv.off + ky * p.conv.kmul;
+                    const int tx = xo * p.conv.mul + p.conv.off + kx * p.conv.kmul;
+                    bool ok = ty >= 0 && ty < p.conv.lim_h && tx >= 0 && tx < p.conv.lim_w;
+                    if (p.conv.need_even) ok = ok && (((ty | tx) & 1) == 0);
+                    if (ok)
+                        vb = ld8(p.X + (((size_t)b * p.conv.Hin + (ty >> p.conv.shift)) * p.conv.Win + (tx >> p.conv.shift)) * p.conv.Cin + ci);
+                }
+            }
+        }
+        __syncthreads();  // previous iteration's fragment reads are done
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            At[(cc + e) * LD + mr] = va[e];
+            Bt[(cc + e) * LD + mr] = vb[e];
+        }
+        __syncthreads();
+        half8 af[2], bf[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) af[i] = ld8(At + (wm * 32 + i * 16 + li) * LD + g * 8);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bf[j] = ld8(Bt + (wn * 32 + j * 16 + li) * LD + g * 8);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = mfma16(af[i], bf[j], acc[i][j]);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + wm * 32 + i * 16 + 4 * g + r;
+                const int kk = k0 + wn * 32 + j * 16 + li;
+                if (n < p.N && kk < p.K) atomicAdd(p.dW + (size_t)n * p.K + kk, acc[i][j][r]);
+            }
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch_gemm(GemmArgs& a, int splits, hipStream_t s) {
+    a.tiles_n = clora_cdiv(a.N, BN);
+    const int tiles_m = clora_cdiv(a.M, BM);
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN>), dim3(tiles_m * a.tiles_n, splits), dim3(256), 0, s, a);
+    return clora_check_launch();
+}
+
+}  // namespace
+
+extern "C" int clora_gemm_f16(const clora_half* A, int lda, const clora_half* B, clora_half* C, int ldc, int M, int N,
+                              int K, const clora_conv_t* conv, const clora_epilogue_t* epi, int split_k,
+                              void* workspace, size_t workspace_bytes, void* stream) {
+    if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || (K & 7) || (N & 7) || (ldc & 7)) return CLORA_ERR_ARG;
+    GemmArgs a;
+    a.A = (const half_t*)A; a.B = (const half_t*)B; a.C = (half_t*)C; a.partial = nullptr;
+    a.lda = lda; a.ldc = ldc; a.M = M; a.N = N; a.K = K;
+    if (conv && conv->enabled) {
+        a.conv = *conv;
+        if ((conv->Cin & 7) || K != conv->ksize * conv->ksize * conv->Cin) return CLORA_ERR_ARG;
+    } else {
+        a.conv = clora_conv_t();
+        a.conv.enabled = 0;
+        if (lda & 7) return CLORA_ERR_ARG;
+    }
+    if (epi) a.epi = *epi; else a.epi = clora_epilogue_t();
+    if (a.epi.lora_t && (a.epi.lora_r <= 0 || a.epi.lora_seg <= 0)) return CLORA_ERR_ARG;
+    if (a.epi.rowadd && a.epi.rows_per_batch <= 0) return CLORA_ERR_ARG;
+    if (a.epi.residual && (a.epi.ldr & 7)) return CLORA_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    int splits = split_k < 1 ? 1 : split_k;
+    const int ksteps = clora_cdiv(K, 32);
+    if (splits > ksteps) splits = ksteps;
+    a.k_per_split = clora_cdiv(ksteps, splits) * 32;
+    splits = clora_cdiv(K, a.k_per_split);
+    if (splits > 1) {
+        if (!workspace || workspace_bytes < (size_t)splits * M * N * sizeof(float)) return CLORA_ERR_WORKSPACE;
+        a.partial = (float*)workspace;
+    }
+    int rc;
+    // tile choice: big tiles when they still fill the 256 CUs, otherwise smaller ones
+    const long t128 = (long)clora_cdiv(M, 128) * clora_cdiv(N, 128) * splits;
+    const long t12864 = (long)clora_cdiv(M, 128) * clora_cdiv(N, 64) * splits;
+    if (N > 64 && t128 >= 512) rc = launch_gemm<128, 128, 2, 2>(a, splits, s);
+    else if (t12864 >= 384 || M >= 4096) rc = launch_gemm<128, 64, 4, 1>(a, splits, s);
+    else rc = launch_gemm<64, 64, 2, 2>(a, splits, s);
+    if (rc != CLORA_OK) return rc;
+    if (splits > 1) {
+        const size_t chunks = (size_t)M * (N / 8);
+        int blocks = (int)((chunks + 255) / 256);
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(splitk_finish_kernel, dim3(blocks), dim3(256), 0, s, a, splits);
+        rc = clora_check_launch();
+    }
+    return rc;
+}
+
+extern "C" int clora_conv_wgrad_f16(const clora_half* dY, int ldy, const clora_half* X, int ldx, float* dW, int M,
+                                    int N, int K, const clora_conv_t* conv, void* stream) {
+    if (!dY || !X || !dW || M <= 0 || N <= 0 || K <= 0 || (K & 7) || (N & 7) || (ldy & 7)) return CLORA_ERR_ARG;
+    WgradArgs a;
+    a.dY = (const half_t*)dY; a.X = (const half_t*)X; a.dW = dW;
+    a.ldy = ldy; a.ldx = ldx; a.M = M; a.N = N; a.K = K;
+    if (conv && conv->enabled) {
+        a.conv = *conv;
+        if ((conv->Cin & 7) || K != conv->ksize * conv->ksize * conv->Cin) return CLORA_ERR_ARG;
+    } else {
+        a.conv = clora_conv_t();
+        a.conv.enabled = 0;
+        if (ldx & 7) return CLORA_ERR_ARG;
+    }
+    a.tiles_n = clora_cdiv(N, 64);
+    a.tiles_k = clora_cdiv(K, 64);
+    const int tiles = a.tiles_n * a.tiles_k;
+    int chunks = clora_cdiv(2048, tiles);              // aim for ~2048 blocks
+    int mpb = clora_cdiv(clora_cdiv(M, chunks), 32) * 32;
+    if (mpb < 256) mpb = 256;
+    a.m_per_block = mpb;
+    hipLaunchKernelGGL(conv_wgrad_kernel, dim3(tiles, clora_cdiv(M, mpb)), dim3(256), 0, (hipStream_t)stream, a);
+    return clora_check_launch();
+}

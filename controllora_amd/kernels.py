@@ -1,0 +1,287 @@
+"""Tensor-level wrappers over the C ABI (one Python function per entry point of include/clora.h).
+
+No math happens here: the wrappers validate shapes/dtypes, allocate outputs / workspaces with torch
+(device memory plumbing) and enqueue the HIP kernel on torch's current stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+
+from . import capi
+from .capi import ConvDesc, Epilogue, ptr
+
+f16, f32 = torch.float16, torch.float32
+
+
+def _call(name, *args):
+    capi.lib().call(name, *args, capi.stream())
+
+
+def _c2(t: torch.Tensor) -> torch.Tensor:
+    """view a [..., C] contiguous tensor as 2-D [M, C]"""
+    assert t.is_contiguous(), "kernel operands must be contiguous"
+    return t.reshape(-1, t.shape[-1])
+
+
+# ------------------------------------------------------------------ conv descriptors (see include/clora.h)
+def conv_fwd_desc(Hin, Win, Cin, ksize=3, stride=1, pad=1, upsample=False, asym_pad=False) -> Tuple[ConvDesc, int, int]:
+    """Forward gather.  asym_pad = diffusers Downsample2D(padding=0): F.pad (0,1,0,1) then stride 2 (A9)."""
+    if upsample:
+        Hout, Wout = 2 * Hin, 2 * Win
+        return ConvDesc(1, Hin, Win, Cin, Hout, Wout, ksize, 1, 1, -pad, 2 * Hin, 2 * Win, 1, 0), Hout, Wout
+    if asym_pad:
+        Hout, Wout = (Hin + 1 - ksize) // stride + 1, (Win + 1 - ksize) // stride + 1
+        return ConvDesc(1, Hin, Win, Cin, Hout, Wout, ksize, stride, 1, 0, Hin, Win, 0, 0), Hout, Wout
+    Hout, Wout = (Hin + 2 * pad - ksize) // stride + 1, (Win + 2 * pad - ksize) // stride + 1
+    return ConvDesc(1, Hin, Win, Cin, Hout, Wout, ksize, stride, 1, -pad, Hin, Win, 0, 0), Hout, Wout
+
+
+def conv_dgrad_desc(Hout, Wout, Cout, Hin, Win, ksize=3, stride=1, pad=1, asym_pad=False) -> ConvDesc:
+    """Gather for dX (rows enumerate the INPUT pixels of the forward conv, A operand is dY).  For an
+    upsampled forward pass (Hin, Win) are the upsampled dims and the result is 2x2 sum-pooled afterwards."""
+    p = 0 if asym_pad else pad
+    if stride == 1:
+        return ConvDesc(1, Hout, Wout, Cout, Hin, Win, ksize, 1, -1, p, Hout, Wout, 0, 0)
+    assert stride == 2
+    return ConvDesc(1, Hout, Wout, Cout, Hin, Win, ksize, 1, -1, p, 2 * Hout, 2 * Wout, 1, 1)
+
+
+_ws_cache = {}
+
+
+def workspace(nbytes: int, device) -> torch.Tensor:
+    """Grow-only per-device scratch (split-K slabs, GroupNorm partials). Reused across calls on one stream."""
+    key = str(device)
+    w = _ws_cache.get(key)
+    if w is None or w.numel() < nbytes:
+        w = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _ws_cache[key] = w
+    return w
+
+
+def pick_split_k(M, N, K) -> int:
+    """split-K when the output tiles alone cannot fill 256 CUs (weight-streaming regime: small M, big K)."""
+    tiles = ((M + 63) // 64) * ((N + 63) // 64)
+    if tiles >= 256 or K < 1024:
+        return 1
+    s = min(16, max(1, 512 // tiles), K // 256)
+    return max(1, s)
+
+
+def gemm(A: torch.Tensor, Bw: torch.Tensor, M: int, N: int, K: int, *, lda: Optional[int] = None,
+         conv: Optional[ConvDesc] = None, bias=None, rowadd=None, rows_per_batch=0, residual=None,
+         lora_t=None, lora_u=None, lora_seg=0, lora_scale=1.0, out: Optional[torch.Tensor] = None,
+         split_k: Optional[int] = None) -> torch.Tensor:
+    """C[M,N] = A . Bw^T with the fused epilogue of clora_epilogue_t."""
+    assert A.dtype == f16 and Bw.dtype == f16 and Bw.shape == (N, K) and Bw.is_contiguous()
+    C_ = out if out is not None else torch.empty((M, N), dtype=f16, device=A.device)
+    assert C_.dtype == f16 and C_.stride(-1) == 1
+    ldc = C_.stride(0) if C_.dim() == 2 else N
+    e = Epilogue()
+    if bias is not None:
+        assert bias.dtype == f32 and bias.numel() == N
+        e.bias = ptr(bias)
+    if rowadd is not None:
+        assert rowadd.dtype == f16 and rowadd.shape[-1] == N and rowadd.is_contiguous()
+        e.rowadd, e.rows_per_batch, e.ld_rowadd = ptr(rowadd), rows_per_batch, N
+    if residual is not None:
+        assert residual.dtype == f16 and residual.stride(-1) == 1
+        e.residual, e.ldr = ptr(residual), (residual.stride(0) if residual.dim() == 2 else N)
+    if lora_t is not None:
+        assert lora_t.dtype == f32 and lora_u.dtype == f32 and lora_t.is_contiguous() and lora_u.is_contiguous()
+        e.lora_t, e.ldt, e.lora_u, e.lora_r = ptr(lora_t), lora_t.shape[-1], ptr(lora_u), lora_u.shape[-1]
+        e.lora_seg, e.lora_scale = (lora_seg or N), float(lora_scale)
+    sk = pick_split_k(M, N, K) if split_k is None else split_k
+    ws = workspace(sk * M * N * 4, A.device) if sk > 1 else None
+    _call("clora_gemm_f16", ptr(A), lda if lda is not None else K, ptr(Bw), ptr(C_), ldc, M, N, K,
+          C.byref(conv) if conv is not None else None, C.byref(e), sk,
+          ptr(ws) if ws is not None else None, ws.numel() if ws is not None else 0)
+    return C_
+
+
+def conv_wgrad(dY: torch.Tensor, X: torch.Tensor, M: int, N: int, K: int, conv: Optional[ConvDesc],
+               ldx: Optional[int] = None) -> torch.Tensor:
+    dW = torch.zeros((N, K), dtype=f32, device=dY.device)
+    _call("clora_conv_wgrad_f16", ptr(dY, f16), N, ptr(X, f16), ldx if ldx is not None else K, ptr(dW), M, N, K,
+          C.byref(conv) if conv is not None else None)
+    return dW
+
+
+# ------------------------------------------------------------------ attention
+def attn_fwd(q, k, v, B, H, Nq, Nk, D, scale, out=None):
+    """q/k/v: 2-D row-strided views [B*N, >=H*D] (stride(0) is the row pitch)."""
+    o = out if out is not None else torch.empty((B * Nq, H * D), dtype=f16, device=q.device)
+    lse = torch.empty((B, H, Nq), dtype=f32, device=q.device)
+    _call("clora_attn_fwd_f16", ptr(q, f16), q.stride(0), ptr(k, f16), k.stride(0), ptr(v, f16), v.stride(0),
+          ptr(o), o.stride(0), ptr(lse), B, H, Nq, Nk, D, float(scale))
+    return o, lse
+
+
+def attn_bwd(q, k, v, o, dO, lse, B, H, Nq, Nk, D, scale, dq, dk, dv):
+    delta = torch.empty((B, H, Nq), dtype=f32, device=q.device)
+    _call("clora_attn_bwd_f16", ptr(q, f16), q.stride(0), ptr(k, f16), k.stride(0), ptr(v, f16), v.stride(0),
+          ptr(o, f16), o.stride(0), ptr(dO, f16), dO.stride(0), ptr(lse, f32), ptr(delta),
+          ptr(dq, f16), dq.stride(0), ptr(dk, f16), dk.stride(0), ptr(dv, f16), dv.stride(0),
+          B, H, Nq, Nk, D, float(scale))
+    return dq, dk, dv
+
+
+# ------------------------------------------------------------------ norms
+def _gn_ws(B, HW, G, device):
+    return workspace((B * 1024 * G * 2 + B * G * 2) * 4 + 4096, device)
+
+
+def groupnorm_fwd(x, gamma, beta, G, eps, silu):
+    B, HW, Cc = x.shape
+    y = torch.empty_like(x)
+    stats = torch.empty((B, G, 2), dtype=f32, device=x.device)
+    ws = _gn_ws(B, HW, G, x.device)
+    _call("clora_groupnorm_fwd_f16", ptr(x, f16), ptr(y), ptr(gamma, f32), ptr(beta, f32), ptr(stats), B, HW, Cc, G,
+          float(eps), int(silu), ptr(ws), ws.numel())
+    return y, stats
+
+
+def groupnorm_bwd(x, dy, gamma, beta, stats, G, silu, want_param_grads=False):
+    B, HW, Cc = x.shape
+    dx = torch.empty_like(x)
+    dg = db = None
+    if want_param_grads:
+        dg = torch.zeros(Cc, dtype=f32, device=x.device)
+        db = torch.zeros(Cc, dtype=f32, device=x.device)
+    ws = _gn_ws(B, HW, G, x.device)
+    _call("clora_groupnorm_bwd_f16", ptr(x, f16), ptr(dy, f16), ptr(dx), ptr(gamma, f32), ptr(beta, f32), ptr(stats, f32),
+          ptr(dg), ptr(db), B, HW, Cc, G, int(silu), ptr(ws), ws.numel())
+    return dx, dg, db
+
+
+def layernorm_fwd(x, gamma, beta, eps):
+    x2 = _c2(x)
+    y = torch.empty_like(x)
+    _call("clora_layernorm_fwd_f16", ptr(x2, f16), ptr(y), ptr(gamma, f32), ptr(beta, f32), x2.shape[0], x2.shape[1], float(eps))
+    return y
+
+
+def layernorm_bwd(x, dy, gamma, eps):
+    x2 = _c2(x)
+    dx = torch.empty_like(x)
+    _call("clora_layernorm_bwd_f16", ptr(x2, f16), ptr(_c2(dy), f16), ptr(dx), ptr(gamma, f32), x2.shape[0], x2.shape[1], float(eps))
+    return dx
+
+
+def geglu_fwd(h):
+    h2 = _c2(h)
+    M, F2 = h2.shape
+    y = torch.empty(h.shape[:-1] + (F2 // 2,), dtype=f16, device=h.device)
+    _call("clora_geglu_fwd_f16", ptr(h2, f16), ptr(y), M, F2 // 2)
+    return y
+
+
+def geglu_bwd(h, dy):
+    h2 = _c2(h)
+    M, F2 = h2.shape
+    dh = torch.empty_like(h)
+    _call("clora_geglu_bwd_f16", ptr(h2, f16), ptr(_c2(dy), f16), ptr(dh), M, F2 // 2)
+    return dh
+
+
+# ------------------------------------------------------------------ adapters
+def lora_down(X, D, T, toff, M, K, accumulate=False, x_rows=0, ldx=None):
+    """T[:, toff:toff+R] (+)= X . D^T ; X [rows, K] fp16 (row pitch ldx), D [R, K] fp32, T [M, ldt] fp32."""
+    assert D.dtype == f32 and D.is_contiguous() and T.dtype == f32 and T.is_contiguous()
+    _call("clora_lora_down_f16", ptr(X, f16), ldx if ldx is not None else X.stride(0), ptr(D), D.shape[1], ptr(T),
+          T.shape[1], toff, M, K, D.shape[0], int(accumulate), x_rows)
+    return T
+
+
+def lora_up(base, T, toff, U, M, N, scale, out=None):
+    assert U.dtype == f32 and U.is_contiguous() and T.dtype == f32
+    y = out if out is not None else torch.empty((M, N), dtype=f16, device=T.device)
+    _call("clora_lora_up_f16", ptr(base, f16) if base is not None else None, base.stride(0) if base is not None else 0,
+          ptr(T), T.shape[1], toff, ptr(U), U.shape[1], ptr(y), y.stride(0), M, N, U.shape[1], float(scale))
+    return y
+
+
+def lora_wgrad(A, T, toff, G, gs_n, gs_j, M, N, R, scale=1.0, a_rows=0, lda=None):
+    """G[n*gs_n + j*gs_j] += scale * sum_m A[m,n] T[m,toff+j]"""
+    assert G.dtype == f32 and T.dtype == f32
+    _call("clora_lora_wgrad_f16", ptr(A, f16), lda if lda is not None else A.stride(0), ptr(T), T.shape[1], toff, ptr(G),
+          gs_n, gs_j, M, N, R, float(scale), a_rows)
+    return G
+
+
+# ------------------------------------------------------------------ elementwise / movement
+def add(a, b):
+    y = torch.empty_like(a)
+    _call("clora_add_f16", ptr(a, f16), ptr(b, f16), ptr(y), a.numel())
+    return y
+
+
+def silu(x):
+    y = torch.empty_like(x)
+    _call("clora_silu_f16", ptr(x, f16), ptr(y), x.numel())
+    return y
+
+
+def silu_bwd(x, dy):
+    dx = torch.empty_like(x)
+    _call("clora_silu_bwd_f16", ptr(x, f16), ptr(dy, f16), ptr(dx), x.numel())
+    return dx
+
+
+def copy2d(src, lds, dst, ldd, M, N):
+    _call("clora_copy2d_f16", ptr(src, f16), lds, ptr(dst, f16), ldd, M, N)
+    return dst
+
+
+def concat_channels(a, b):
+    """[.., Ca] ++ [.., Cb] along the channel (last) dim."""
+    Ca, Cb = a.shape[-1], b.shape[-1]
+    M = a.numel() // Ca
+    y = torch.empty(a.shape[:-1] + (Ca + Cb,), dtype=f16, device=a.device)
+    copy2d(a, Ca, y, Ca + Cb, M, Ca)
+    copy2d(b, Cb, y[..., Ca:], Ca + Cb, M, Cb)
+    return y
+
+
+def split_channels(y, Ca):
+    Ct = y.shape[-1]
+    M = y.numel() // Ct
+    a = torch.empty(y.shape[:-1] + (Ca,), dtype=f16, device=y.device)
+    b = torch.empty(y.shape[:-1] + (Ct - Ca,), dtype=f16, device=y.device)
+    copy2d(y, Ct, a, Ca, M, Ca)
+    copy2d(y[..., Ca:], Ct, b, Ct - Ca, M, Ct - Ca)
+    return a, b
+
+
+def pool2x2_sum(dy, B, H, W, Cc):
+    dx = torch.empty((B, H * W, Cc), dtype=f16, device=dy.device)
+    _call("clora_pool2x2_sum_f16", ptr(dy, f16), ptr(dx), B, H, W, Cc)
+    return dx
+
+
+def colsum(A, M, N, out=None):
+    o = out if out is not None else torch.zeros(N, dtype=f32, device=A.device)
+    _call("clora_colsum_f16", ptr(A, f16), A.stride(0) if A.dim() == 2 else N, ptr(o), M, N)
+    return o
+
+
+def mse(pred, target, loss_sum, dpred, grad_scale, loss_scale=None):
+    _call("clora_mse_f16", ptr(pred, f16), ptr(target, f16), ptr(loss_sum, f32), ptr(dpred, f16) if dpred is not None else None,
+          pred.numel(), float(grad_scale), ptr(loss_scale, f32) if loss_scale is not None else None)
+
+
+def grad_sumsq(g, state):
+    _call("clora_grad_sumsq_f32", ptr(g, f32), g.numel(), ptr(state, f32))
+
+
+def optim_prep(state, max_norm, beta1, beta2, dynamic, growth=2.0, backoff=0.5, interval=2000):
+    _call("clora_optim_prep_f32", ptr(state, f32), float(max_norm), float(beta1), float(beta2), int(dynamic), float(growth),
+          float(backoff), int(interval))
+
+
+def adamw_flat(p, g, m, v, state, lr, beta1, beta2, eps, wd):
+    _call("clora_adamw_flat_f32", ptr(p, f32), ptr(g, f32), ptr(m, f32), ptr(v, f32), p.numel(), ptr(state, f32), float(lr),
+          float(beta1), float(beta2), float(eps), float(wd))

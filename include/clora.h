@@ -1,0 +1,164 @@
+/* clora.h -- C ABI of libclora (gfx950 / MI355X kernels for the ControlLoRA hot path).
+ *
+ * Drop-in boundary.  The reference (HighCWu/ControlLoRA) is pure Python
+ * and delegates every operation below to PyTorch/diffusers ops; each entry point names the
+ * reference call it replaces.  Rules of the ABI:
+ *   - plain pointers and sizes only; every pointer is DEVICE memory owned by the caller;
+ *   - kernels are enqueued on `stream` (a hipStream_t passed as void*) and never synchronise,
+ *     allocate, or keep global state, so they can be captured in a hipGraph;
+ *   - return 0 on success, negative on error (CLORA_ERR_*), never throw;
+ *   - activations are fp16 "tokens x channels" row-major (NHWC); statistics, adapter
+ *     parameters, gradients of trainable parameters and optimizer state are fp32.
+ * Reference-side binding: see INTEGRATION.md (ctypes stub used by controllora_amd/capi.py).
+ */
+#ifndef CLORA_H
+#define CLORA_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CLORA_OK 0
+#define CLORA_ERR_ARG (-1)
+#define CLORA_ERR_LAUNCH (-2)
+#define CLORA_ERR_WORKSPACE (-3)
+
+typedef uint16_t clora_half; /* IEEE fp16 bits */
+
+/* ---- implicit-GEMM convolution gather (NHWC).  Row m of the GEMM is output pixel
+ * (b, yo, xo); column k is (tap = ky*ksize+kx, ci).  Source coordinate along y:
+ *   t = yo*mul + ky*kmul + off ; valid iff 0 <= t < lim_h (and t even when need_even);
+ *   ysrc = t >> shift.   (same for x with lim_w)
+ * forward stride s, pad p      : mul=s, kmul=+1, off=-p, lim=Hin,      shift=0
+ * forward nearest-x2 upsample  : mul=1, kmul=+1, off=-1, lim=2*Hin,    shift=1
+ * dgrad of stride 1, pad p     : mul=1, kmul=-1, off=+p, lim=Hout_fwd, shift=0
+ * dgrad of stride 2, pad p     : mul=1, kmul=-1, off=+p, lim=2*Hout_fwd, shift=1, need_even=1 */
+typedef struct {
+    int enabled;
+    int Hin, Win, Cin;   /* dims of the tensor being gathered (A operand) */
+    int Hout, Wout;      /* spatial dims that enumerate the GEMM rows */
+    int ksize;           /* 1 or 3 */
+    int mul, kmul, off, lim_h, lim_w, shift, need_even;
+} clora_conv_t;
+
+/* ---- fused epilogue of clora_gemm_f16:
+ *   acc[m,n] (+ bias[n]) (+ rowadd[m / rows_per_batch, n]) (+ lora_scale * sum_j T[m, toff+j] * U[n, j])
+ *   -> fp16 -> (+ residual[m,n]) -> C[m,n]
+ * with toff = (n / lora_seg) * lora_r  (several adapters sharing one concatenated GEMM). */
+typedef struct {
+    const float* bias;          /* [N] or NULL */
+    const clora_half* rowadd;   /* [M / rows_per_batch, ld_rowadd] or NULL  (time-embedding add) */
+    int rows_per_batch;
+    int ld_rowadd;
+    const clora_half* residual; /* [M, ldr] or NULL */
+    int ldr;
+    const float* lora_t;        /* [M, ldt] or NULL : X . D^T (fp32, from clora_lora_down) */
+    int ldt;
+    const float* lora_u;        /* [N, lora_r] : adapter up weights */
+    int lora_r;
+    int lora_seg;
+    float lora_scale;
+} clora_epilogue_t;
+
+/* C[M,N] = A[M,K] . B[N,K]^T  (fp16 in, fp32 accumulate on MFMA, fp16 out).
+ * Replaces torch Linear / Conv2d forward AND dgrad of the frozen UNet layers
+ * (reference models.py:124-147,231-282 `attn.to_q/to_k/to_v/to_out`; upstream ResnetBlock2D /
+ * Transformer2DModel / FeedForward, SURVEY.md U1,U4,U5) and of the hint encoder (models.py:470,529,684).
+ * `conv` may be NULL (plain GEMM, A row stride lda).  K must be a multiple of 8, N a multiple of 8.
+ * split_k > 1 needs workspace >= split_k*M*N*4 bytes. */
+int clora_gemm_f16(const clora_half* A, int lda, const clora_half* B, clora_half* C, int ldc,
+                   int M, int N, int K, const clora_conv_t* conv, const clora_epilogue_t* epi,
+                   int split_k, void* workspace, size_t workspace_bytes, void* stream);
+
+/* dW[N, K] += dY[M,N]^T . gather(X)[M,K]   (fp32 atomics; caller zeroes dW).
+ * Weight gradient of the trainable hint-encoder convolutions (reference models.py:470,529,594-597,684:
+ * autograd of F.conv2d).  `conv` as in the forward of that layer (NULL = 1x1 / linear). */
+int clora_conv_wgrad_f16(const clora_half* dY, int ldy, const clora_half* X, int ldx, float* dW,
+                         int M, int N, int K, const clora_conv_t* conv, void* stream);
+
+/* ---- attention core: O = softmax(Q K^T * scale) V per (batch, head), flash-style (never
+ * materialises the [B*H, N, Nk] scores the reference builds at models.py:140-141, 270-271).
+ * q: [B, Nq, H*D] with row stride ldq (elements), k/v: [B, Nk, H*D] strides ldk/ldv, o: ldo.
+ * lse: [B, H, Nq] fp32 (natural-log sum-exp of scaled scores), needed by the backward. */
+int clora_attn_fwd_f16(const clora_half* q, int ldq, const clora_half* k, int ldk, const clora_half* v, int ldv,
+                       clora_half* o, int ldo, float* lse, int B, int H, int Nq, int Nk, int D, float scale,
+                       void* stream);
+/* dq/dk/dv given do (autograd of the same lines). delta: [B,H,Nq] fp32 scratch. */
+int clora_attn_bwd_f16(const clora_half* q, int ldq, const clora_half* k, int ldk, const clora_half* v, int ldv,
+                       const clora_half* o, int ldo, const clora_half* dO, int lddo, const float* lse,
+                       float* delta, clora_half* dq, int lddq, clora_half* dk, int lddk, clora_half* dv, int lddv,
+                       int B, int H, int Nq, int Nk, int D, float scale, void* stream);
+
+/* ---- GroupNorm (+ optional SiLU), NHWC.  Replaces torch GroupNorm + F.silu pairs
+ * (upstream ResnetBlock2D / Transformer2DModel.norm / conv_norm_out; reference models.py:515-516,537-543).
+ * x,y: [B, HW, C]; gamma/beta fp32 [C]; stats: [B, G, 2] fp32 (mean, rstd) written by fwd. */
+int clora_groupnorm_fwd_f16(const clora_half* x, clora_half* y, const float* gamma, const float* beta, float* stats,
+                            int B, int HW, int C, int G, float eps, int fuse_silu, void* workspace,
+                            size_t workspace_bytes, void* stream);
+/* dx (and, when dgamma != NULL, dgamma/dbeta += ... fp32 atomics; caller zeroes them). */
+int clora_groupnorm_bwd_f16(const clora_half* x, const clora_half* dy, clora_half* dx, const float* gamma,
+                            const float* beta, const float* stats, float* dgamma, float* dbeta, int B, int HW, int C,
+                            int G, int fuse_silu, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- LayerNorm over the last dim (upstream BasicTransformerBlock.norm1/2/3, eps 1e-5). */
+int clora_layernorm_fwd_f16(const clora_half* x, clora_half* y, const float* gamma, const float* beta, int M, int C,
+                            float eps, void* stream);
+int clora_layernorm_bwd_f16(const clora_half* x, const clora_half* dy, clora_half* dx, const float* gamma, int M, int C,
+                            float eps, void* stream);
+
+/* ---- GEGLU: y[m, j] = h[m, j] * gelu_erf(h[m, F + j])  (upstream FeedForward). */
+int clora_geglu_fwd_f16(const clora_half* h, clora_half* y, int M, int F, void* stream);
+int clora_geglu_bwd_f16(const clora_half* h, const clora_half* dy, clora_half* dh, int M, int F, void* stream);
+
+/* ---- rank-r adapter pieces (upstream LoRALinearLayer; reference models.py:89-97,185-188,316-323).
+ * T[m, toff+j] (+)= sum_k X[bmap(m), k] * D[j, k]   (fp32 math like the reference's x.float() @ down.T)
+ * x_batch_rows > 0 : X holds one batch element of x_batch_rows rows that is broadcast over M (control batch 1). */
+int clora_lora_down_f16(const clora_half* X, int ldx, const float* D, int ldd, float* T, int ldt, int toff,
+                        int M, int K, int R, int accumulate, int x_rows, void* stream);
+/* Y[m,n] = (base ? base[m,n] : 0) + fp16(scale * fp16(sum_j T[m,toff+j] U[n,j]))  -- the explicit
+ * "hidden + to_control(control)" of models.py:214-218,237-238 and the V2 pre/post adds (:369,:415). */
+int clora_lora_up_f16(const clora_half* base, int ldb, const float* T, int ldt, int toff, const float* U, int ldu,
+                      clora_half* Y, int ldy, int M, int N, int R, float scale, void* stream);
+/* G[n*gs_n + j*gs_j] += scale * sum_m A[m, n] * T[m, toff+j]  (fp32 atomics; adapter weight gradients). */
+int clora_lora_wgrad_f16(const clora_half* A, int lda, const float* T, int ldt, int toff, float* G, int gs_n, int gs_j,
+                         int M, int N, int R, float scale, int a_rows, void* stream);
+
+/* ---- small elementwise / data-movement kernels on the path */
+int clora_add_f16(const clora_half* a, const clora_half* b, clora_half* y, size_t n, void* stream);
+int clora_silu_f16(const clora_half* x, clora_half* y, size_t n, void* stream);
+int clora_silu_bwd_f16(const clora_half* x, const clora_half* dy, clora_half* dx, size_t n, void* stream);
+/* dst[m, 0:N] = src[m, 0:N] with independent row strides (skip-connection concat = two copies,
+ * its backward = two slice copies; upstream torch.cat in the up blocks) */
+int clora_copy2d_f16(const clora_half* src, int lds, clora_half* dst, int ldd, size_t M, int N, void* stream);
+/* dx[b, y, x, c] = sum of the 2x2 block of dy[b, 2y.., 2x.., c]  (backward of nearest x2 upsample) */
+int clora_pool2x2_sum_f16(const clora_half* dy, clora_half* dx, int B, int H, int W, int C, void* stream);
+/* out[n] += sum_m A[m, n]  (bias gradients of trainable convs; fp32 atomics) */
+int clora_colsum_f16(const clora_half* A, int lda, float* out, int M, int N, void* stream);
+/* loss_sum[0] += sum (pred - target)^2 ; dpred = grad_scale * (loss_scale ? loss_scale[0] : 1) * (pred - target)
+ * (F.mse_loss in fp32 + the GradScaler-scaled backward seed, train...:783,790; loss_scale is device resident) */
+int clora_mse_f16(const clora_half* pred, const clora_half* target, float* loss_sum, clora_half* dpred, size_t n,
+                  float grad_scale, const float* loss_scale, void* stream);
+int clora_cast_f32_to_f16(const float* x, clora_half* y, size_t n, void* stream);
+int clora_cast_f16_to_f32(const clora_half* x, float* y, size_t n, void* stream);
+
+/* ---- fused optimizer over ONE flat fp32 buffer (train...:790-796: GradScaler unscale, clip_grad_norm_(1.0),
+ * AdamW step, skipped on inf/nan, loss-scale growth/backoff) -- entirely device resident, no host sync.
+ * state (device fp32[16]): [0] sum of squares of the (still scaled) grads  [1] non-finite count
+ *   [2] optimizer step count  [3] loss scale  [4] growth tracker  [5] grad multiplier = clip/scale (out)
+ *   [6] skip flag (out)  [7] 1-beta1^t  [8] 1-beta2^t  [9] unscaled grad norm (out, -1 when skipped) */
+int clora_grad_sumsq_f32(const float* g, size_t n, float* state, void* stream);
+int clora_optim_prep_f32(float* state, float max_norm, float beta1, float beta2, int dynamic_scale,
+                         float growth_factor, float backoff_factor, int growth_interval, void* stream);
+int clora_adamw_flat_f32(float* p, const float* g, float* m, float* v, size_t n, const float* state, float lr,
+                         float beta1, float beta2, float eps, float weight_decay, void* stream);
+
+/* library info */
+int clora_abi_version(void);
+const char* clora_build_info(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CLORA_H */

@@ -1,0 +1,39 @@
+"""TEST INFRASTRUCTURE: compile the SAME kernel sources for the host fiber emulator
+(tests/hipemu/hipemu.h) -> tests/hipemu/_build/libclora_emu.so.  Used only by CPU tests."""
+from __future__ import annotations
+
+import glob
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+CSRC = os.path.join(ROOT, "controllora_amd", "csrc")
+OUT_DIR = os.path.join(HERE, "_build")
+LIB = os.path.join(OUT_DIR, "libclora_emu.so")
+CLANG = "/opt/rocm/lib/llvm/bin/clang++"
+
+
+def build(verbose: bool = False) -> str:
+    os.makedirs(OUT_DIR, exist_ok=True)
+    srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+    deps = srcs + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(HERE, "*.h")) + \
+        glob.glob(os.path.join(HERE, "*.cpp")) + [os.path.join(ROOT, "include", "clora.h")]
+    newest = max(os.path.getmtime(d) for d in deps)
+    objs = []
+    for src in srcs + [os.path.join(HERE, "hipemu.cpp")]:
+        obj = os.path.join(OUT_DIR, os.path.basename(src).rsplit(".", 1)[0] + ".emu.o")
+        if not os.path.exists(obj) or os.path.getmtime(obj) < newest:
+            cmd = [CLANG, "-O2", "-g0", "-std=c++17", "-fPIC", "-I", HERE, "-Wno-unknown-pragmas", "-Wno-pass-failed",
+                   "-x", "c++", "-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+        objs.append(obj)
+    if not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(o) for o in objs):
+        subprocess.check_call([CLANG, "-shared", "-fPIC", *objs, "-o", LIB])
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(verbose=True))

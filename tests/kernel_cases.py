@@ -1,0 +1,234 @@
+"""Per-kernel parity cases shared by the CPU (host-emulated kernels, small shapes) and GPU (-m gpu, real
+gfx950 library, real site shapes) test modules.  Every case compares a C-ABI entry point with the same
+operation written in plain torch fp32 on the SAME fp16-rounded inputs; tolerances are stated per case
+(fp16 output rounding is 2^-11 = 4.9e-4 relative)."""
+import math
+
+import torch
+import torch.nn.functional as F
+
+from controllora_amd import kernels as K
+
+f16, f32 = torch.float16, torch.float32
+
+
+def rel(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-20))
+
+
+def rnd(shape, dev, gen, scale=1.0, dtype=f16):
+    return (torch.randn(shape, generator=gen) * scale).to(dtype).to(dev)
+
+
+def case_gemm_plain(dev, M, N, K_, split_k=1, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    A, B = rnd((M, K_), dev, g), rnd((N, K_), dev, g, 1 / math.sqrt(K_))
+    out = K.gemm(A, B, M, N, K_, split_k=split_k)
+    assert rel(out, A.float() @ B.float().T) < 6e-4
+
+
+def case_gemm_epilogue(dev, M=200, N=96, K_=64, split_k=1):
+    g = torch.Generator().manual_seed(1)
+    A, B = rnd((M, K_), dev, g), rnd((N, K_), dev, g, 1 / math.sqrt(K_))
+    bias, rowadd, res = rnd((N,), dev, g, dtype=f32), rnd((4, N), dev, g), rnd((M, N), dev, g)
+    T, U = rnd((M, 8), dev, g, dtype=f32), rnd((N, 4), dev, g, dtype=f32)
+    out = K.gemm(A, B, M, N, K_, bias=bias, rowadd=rowadd, rows_per_batch=M // 4, residual=res, lora_t=T, lora_u=U,
+                 lora_seg=N // 2, lora_scale=0.7, split_k=split_k)
+    seg = torch.arange(N, device=dev) // (N // 2)
+    lora = torch.stack([T[:, int(s) * 4:(int(s) + 1) * 4] @ U[n] for n, s in enumerate(seg.tolist())], 1)
+    ref = (A.float() @ B.float().T + bias + rowadd.float().repeat_interleave(M // 4, 0) + 0.7 * lora).half().float() + res.float()
+    assert rel(out, ref) < 6e-4
+
+
+def case_conv(dev, Bn, H, W, Ci, Co, stride=1, pad=1, ups=False, asym=False, seed=2):
+    """forward, dgrad and wgrad of one 3x3 conv configuration against F.conv2d autograd."""
+    g = torch.Generator().manual_seed(seed)
+    x = rnd((Bn, Ci, H, W), dev, g)
+    w = rnd((Co, Ci, 3, 3), dev, g, 1 / math.sqrt(Ci * 9))
+    xin = x.float()
+    if ups:
+        xin = F.interpolate(xin, scale_factor=2.0, mode="nearest")
+    xin = xin.clone().requires_grad_(True)
+    w32 = w.float().clone().requires_grad_(True)
+    y = F.conv2d(F.pad(xin, (0, 1, 0, 1)), w32, stride=2) if asym else F.conv2d(xin, w32, stride=stride, padding=pad)
+    Ho, Wo = y.shape[2:]
+    dy = rnd((Bn, Co, Ho, Wo), dev, g)
+    y.backward(dy.float())
+    xn = x.permute(0, 2, 3, 1).contiguous()
+    wp = w.permute(0, 2, 3, 1).contiguous().reshape(Co, 9 * Ci)
+    cd, Ho2, Wo2 = K.conv_fwd_desc(H, W, Ci, 3, stride, pad, upsample=ups, asym_pad=asym)
+    assert (Ho2, Wo2) == (Ho, Wo)
+    M = Bn * Ho * Wo
+    out = K.gemm(xn, wp, M, Co, 9 * Ci, conv=cd)
+    assert rel(out, y.detach().permute(0, 2, 3, 1).reshape(M, Co)) < 6e-4
+    Hi, Wi = xin.shape[2:]
+    wd = w.permute(1, 2, 3, 0).contiguous().reshape(Ci, 9 * Co)
+    dyn = dy.permute(0, 2, 3, 1).contiguous()
+    cdd = K.conv_dgrad_desc(Ho, Wo, Co, Hi, Wi, 3, 2 if asym else stride, pad, asym_pad=asym)
+    dx = K.gemm(dyn, wd, Bn * Hi * Wi, Ci, 9 * Co, conv=cdd)
+    assert rel(dx, xin.grad.permute(0, 2, 3, 1).reshape(-1, Ci)) < 6e-4
+    if ups:
+        pooled = K.pool2x2_sum(dx.reshape(Bn, Hi * Wi, Ci), Bn, H, W, Ci)
+        ref = F.avg_pool2d(xin.grad, 2) * 4
+        assert rel(pooled, ref.permute(0, 2, 3, 1).reshape(Bn, H * W, Ci)) < 1e-3
+    dW = K.conv_wgrad(dyn, xn, M, Co, 9 * Ci, cd)
+    assert rel(dW, w32.grad.permute(0, 2, 3, 1).reshape(Co, 9 * Ci)) < 1e-4
+    db = K.colsum(dyn.reshape(M, Co), M, Co)
+    assert rel(db, dy.float().sum((0, 2, 3))) < 1e-4
+
+
+def _attn_ref(q, k, v, H, scale):
+    B, Nq, HD = q.shape
+    D = HD // H
+    qh = q.float().reshape(B, Nq, H, D).permute(0, 2, 1, 3)
+    kh = k.float().reshape(B, -1, H, D).permute(0, 2, 1, 3)
+    vh = v.float().reshape(B, -1, H, D).permute(0, 2, 1, 3)
+    p = torch.softmax(qh @ kh.transpose(-1, -2) * scale, dim=-1)
+    return (p @ vh).permute(0, 2, 1, 3).reshape(B, Nq, HD)
+
+
+def case_attention(dev, B, H, Nq, Nk, D, seed=3, fused_qkv=False, tol=2e-3):
+    g = torch.Generator().manual_seed(seed)
+    scale = D ** -0.5
+    if fused_qkv:   # q,k,v are column slices of one [B*N, 3*H*D] buffer (self-attention layout)
+        qkv = rnd((B * Nq, 3 * H * D), dev, g)
+        q2, k2, v2 = qkv[:, :H * D], qkv[:, H * D:2 * H * D], qkv[:, 2 * H * D:]
+    else:
+        q2, k2, v2 = rnd((B * Nq, H * D), dev, g), rnd((B * Nk, H * D), dev, g), rnd((B * Nk, H * D), dev, g)
+    q3 = q2.reshape(B, Nq, H * D).float().clone().requires_grad_(True)
+    k3 = k2.reshape(B, Nk, H * D).float().clone().requires_grad_(True)
+    v3 = v2.reshape(B, Nk, H * D).float().clone().requires_grad_(True)
+    ref = _attn_ref(q3, k3, v3, H, scale)
+    o, lse = K.attn_fwd(q2, k2, v2, B, H, Nq, Nk, D, scale)
+    assert rel(o, ref.detach().reshape(B * Nq, H * D)) < tol, rel(o, ref.detach().reshape(B * Nq, H * D))
+    dO = rnd((B * Nq, H * D), dev, g)
+    ref.backward(dO.reshape(B, Nq, H * D).float())
+    dq, dk, dv = torch.empty_like(q2.contiguous()), torch.empty_like(k2.contiguous()), torch.empty_like(v2.contiguous())
+    K.attn_bwd(q2, k2, v2, o, dO, lse, B, H, Nq, Nk, D, scale, dq, dk, dv)
+    for name, a, b_ in (("dq", dq, q3.grad), ("dk", dk, k3.grad), ("dv", dv, v3.grad)):
+        e = rel(a, b_.reshape(a.shape))
+        assert e < 2 * tol, (name, e)
+
+
+def case_groupnorm(dev, B, HW, C, G, silu, eps=1e-5, seed=4, train_params=False):
+    g = torch.Generator().manual_seed(seed)
+    x = (rnd((B, HW, C), dev, g).float() * 1.5 + 0.3).half()
+    gamma, beta = (1 + 0.2 * rnd((C,), dev, g, dtype=f32)), 0.2 * rnd((C,), dev, g, dtype=f32)
+    x32 = x.float().clone().requires_grad_(True)
+    g32, b32 = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    y = F.group_norm(x32.permute(0, 2, 1), G, g32, b32, eps).permute(0, 2, 1)
+    if silu:
+        y = F.silu(y)
+    out, stats = K.groupnorm_fwd(x, gamma, beta, G, eps, silu)
+    assert rel(out, y.detach()) < 8e-4
+    dy = rnd((B, HW, C), dev, g)
+    y.backward(dy.float())
+    dx, dg, db = K.groupnorm_bwd(x, dy, gamma, beta, stats, G, silu, want_param_grads=train_params)
+    assert rel(dx, x32.grad) < 2e-3
+    if train_params:
+        assert rel(dg, g32.grad) < 1e-3 and rel(db, b32.grad) < 1e-3
+
+
+def case_layernorm(dev, M, C, seed=5):
+    g = torch.Generator().manual_seed(seed)
+    x = rnd((M, C), dev, g)
+    gamma, beta = (1 + 0.2 * rnd((C,), dev, g, dtype=f32)), 0.2 * rnd((C,), dev, g, dtype=f32)
+    x32 = x.float().clone().requires_grad_(True)
+    y = F.layer_norm(x32, (C,), gamma, beta, 1e-5)
+    assert rel(K.layernorm_fwd(x, gamma, beta, 1e-5), y.detach()) < 6e-4
+    dy = rnd((M, C), dev, g)
+    y.backward(dy.float())
+    assert rel(K.layernorm_bwd(x, dy, gamma, 1e-5), x32.grad) < 1e-3
+
+
+def case_geglu(dev, M, Fdim, seed=6):
+    g = torch.Generator().manual_seed(seed)
+    h = rnd((M, 2 * Fdim), dev, g)
+    h32 = h.float().clone().requires_grad_(True)
+    a, gg = h32.chunk(2, -1)
+    y = a * F.gelu(gg)
+    assert rel(K.geglu_fwd(h), y.detach()) < 6e-4
+    dy = rnd((M, Fdim), dev, g)
+    y.backward(dy.float())
+    assert rel(K.geglu_bwd(h, dy), h32.grad) < 8e-4
+
+
+def case_lora(dev, M, Kd, N, R, x_rows=0, seed=7):
+    g = torch.Generator().manual_seed(seed)
+    rows = x_rows if x_rows else M
+    X = rnd((rows, Kd), dev, g)
+    D, U = rnd((R, Kd), dev, g, 0.3, f32), rnd((N, R), dev, g, 0.3, f32)
+    T = torch.zeros((M, R + 4), dtype=f32, device=dev)
+    K.lora_down(X, D, T, 4, M, Kd, x_rows=x_rows)
+    Xf = X.float().repeat(M // rows, 1) if x_rows else X.float()
+    Tref = Xf @ D.T
+    assert rel(T[:, 4:], Tref) < 1e-5
+    K.lora_down(X, D, T, 4, M, Kd, accumulate=True, x_rows=x_rows)
+    assert rel(T[:, 4:], 2 * Tref) < 1e-5
+    T[:, 4:] = Tref
+    base = rnd((M, N), dev, g)
+    y = K.lora_up(base, T, 4, U, M, N, 0.6)
+    ref = base.float() + (0.6 * (Tref @ U.T).half().float()).half().float()
+    assert rel(y, ref) < 6e-4
+    y0 = K.lora_up(None, T, 4, U, M, N, 1.0)
+    assert rel(y0, Tref @ U.T) < 6e-4
+    A = rnd((rows, N), dev, g)
+    G1 = torch.zeros((N, R), dtype=f32, device=dev)
+    K.lora_wgrad(A, T, 4, G1, R, 1, M, N, R, scale=0.5, a_rows=x_rows)
+    Af = A.float().repeat(M // rows, 1) if x_rows else A.float()
+    assert rel(G1, 0.5 * Af.T @ Tref) < 1e-4
+    G2 = torch.zeros((R, N), dtype=f32, device=dev)
+    K.lora_wgrad(A, T, 4, G2, 1, N, M, N, R, scale=1.0, a_rows=x_rows)
+    assert rel(G2, (Af.T @ Tref).T) < 1e-4
+
+
+def case_elementwise(dev, seed=8):
+    g = torch.Generator().manual_seed(seed)
+    a, b = rnd((6, 40, 24), dev, g), rnd((6, 40, 24), dev, g)
+    assert rel(K.add(a, b), a.float() + b.float()) < 5e-4
+    assert rel(K.silu(a), F.silu(a.float())) < 5e-4
+    a32 = a.float().clone().requires_grad_(True)
+    F.silu(a32).backward(b.float())
+    assert rel(K.silu_bwd(a, b), a32.grad) < 6e-4
+    c = rnd((6, 40, 16), dev, g)
+    cat = K.concat_channels(a, c)
+    assert torch.equal(cat.cpu(), torch.cat([a, c], -1).cpu())
+    sa, sc = K.split_channels(cat, 24)
+    assert torch.equal(sa.cpu(), a.cpu()) and torch.equal(sc.cpu(), c.cpu())
+
+
+def case_loss_and_optimizer(dev, n=5000, seed=9):
+    g = torch.Generator().manual_seed(seed)
+    pred, tgt = rnd((n * 8,), dev, g), rnd((n * 8,), dev, g)
+    loss = torch.zeros(1, dtype=f32, device=dev)
+    dpred = torch.empty_like(pred)
+    state = torch.zeros(16, dtype=f32, device=dev)
+    state[3] = 1024.0
+    K.mse(pred, tgt, loss, dpred, 2.0 / pred.numel(), state[3:4])
+    d = pred.float() - tgt.float()
+    assert abs(float(loss) / pred.numel() - float((d * d).mean())) < 1e-4
+    assert rel(dpred, 1024.0 * 2.0 / pred.numel() * d) < 6e-4
+    # optimizer vs torch.optim.AdamW + clip_grad_norm_ for 3 steps (one of them with an inf -> skipped)
+    p0 = rnd((n,), dev, g, dtype=f32)
+    p, m, v = p0.clone(), torch.zeros_like(p0), torch.zeros_like(p0)
+    pt = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([pt], lr=1e-2, betas=(0.9, 0.999), weight_decay=1e-2, eps=1e-8)
+    for step in range(3):
+        gr = rnd((n,), dev, g, 0.1, f32)
+        scaled = gr * state[3]
+        if step == 1:
+            scaled = scaled.clone()
+            scaled[7] = float("inf")
+        K.grad_sumsq(scaled, state)
+        K.optim_prep(state, 1.0, 0.9, 0.999, True, 2.0, 0.5, 2000)
+        K.adamw_flat(p, scaled, m, v, state, 1e-2, 0.9, 0.999, 1e-8, 1e-2)
+        if step != 1:
+            pt.grad = gr.clone()
+            torch.nn.utils.clip_grad_norm_([pt], 1.0)
+            opt.step()
+            assert float(state[3]) == (1024.0 if step == 0 else 512.0)
+        else:
+            assert float(state[6]) == 1.0 and float(state[3]) == 512.0
+        assert rel(p, pt.detach()) < 1e-6, (step, rel(p, pt.detach()))
+    assert float(state[2]) == 2.0

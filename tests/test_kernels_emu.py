@@ -1,0 +1,67 @@
+"""CPU tests of the kernel LOGIC: the same .hip sources compiled for the host fiber emulator
+(tests/hipemu) against plain torch fp32.  Small shapes; the real-size GPU runs are in
+tests/test_kernels_gpu.py (-m gpu)."""
+import pytest
+
+from tests import kernel_cases as KC
+from tests.emu_fixture import use_emulator
+
+
+@pytest.fixture(autouse=True)
+def _emu():
+    with use_emulator():
+        yield
+
+
+@pytest.mark.parametrize("M,N,K,split", [(300, 72, 96, 1), (130, 320, 64, 1), (520, 136, 160, 2), (256, 640, 320, 3),
+                                         (64, 8, 40, 1)])
+def test_gemm_plain(M, N, K, split):
+    KC.case_gemm_plain("cpu", M, N, K, split)
+
+
+@pytest.mark.parametrize("split", [1, 2])
+def test_gemm_epilogue(split):
+    KC.case_gemm_epilogue("cpu", split_k=split)
+
+
+@pytest.mark.parametrize("kw", [dict(stride=1, pad=1), dict(stride=2, pad=1), dict(asym=True, stride=2, pad=0), dict(ups=True)])
+def test_conv_fwd_dgrad_wgrad(kw):
+    KC.case_conv("cpu", 2, 12, 10, 16, 24, **kw)
+
+
+def test_conv_small_channels():
+    KC.case_conv("cpu", 1, 16, 16, 8, 32)       # hint-encoder conv_in shape class (3 -> padded 8 channels)
+
+
+@pytest.mark.parametrize("B,H,Nq,Nk,D,fused", [(1, 2, 70, 70, 40, True), (2, 2, 64, 77, 40, False), (1, 2, 33, 130, 80, False),
+                                               (1, 1, 40, 40, 160, True), (1, 2, 20, 20, 8, False), (1, 1, 150, 77, 64, False)])
+def test_attention(B, H, Nq, Nk, D, fused):
+    KC.case_attention("cpu", B, H, Nq, Nk, D, fused_qkv=fused)
+
+
+@pytest.mark.parametrize("B,HW,C,G,silu,train", [(2, 50, 320, 32, True, False), (1, 37, 64, 8, False, False),
+                                                 (2, 64, 32, 32, True, True), (1, 9, 2560, 32, True, False)])
+def test_groupnorm(B, HW, C, G, silu, train):
+    KC.case_groupnorm("cpu", B, HW, C, G, silu, train_params=train)
+
+
+@pytest.mark.parametrize("M,C", [(37, 320), (9, 1280), (5, 64)])
+def test_layernorm(M, C):
+    KC.case_layernorm("cpu", M, C)
+
+
+def test_geglu():
+    KC.case_geglu("cpu", 33, 256)
+
+
+@pytest.mark.parametrize("M,K,N,R,xr", [(300, 320, 64, 4, 0), (128, 72, 40, 8, 32), (70, 96, 32, 20, 0)])
+def test_lora(M, K, N, R, xr):
+    KC.case_lora("cpu", M, K, N, R, x_rows=xr)
+
+
+def test_elementwise():
+    KC.case_elementwise("cpu")
+
+
+def test_loss_and_optimizer():
+    KC.case_loss_and_optimizer("cpu")

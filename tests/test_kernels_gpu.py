@@ -1,0 +1,78 @@
+"""GPU parity tests (-m gpu): the gfx950 library through the C ABI vs plain torch fp32, at the real
+attention-site / resnet shapes of SD-1.5 plus ragged edge cases."""
+import pytest
+import torch
+
+from tests import kernel_cases as KC
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(autouse=True, scope="module")
+def _native_lib_loaded():
+    from controllora_amd import capi
+    L = capi.lib()
+    assert L.require_device and L.path.endswith("libclora.so")
+    yield
+
+
+@pytest.mark.parametrize("M,N,K,split", [(300, 72, 96, 1), (4096, 960, 320, 1), (1024, 1280, 1280, 1), (256, 1280, 1280, 4),
+                                         (308, 640, 768, 1), (4096, 2560, 320, 1), (1024, 320, 1280, 2), (64, 8, 40, 1)])
+def test_gemm_plain(M, N, K, split):
+    KC.case_gemm_plain(DEV, M, N, K, split)
+
+
+@pytest.mark.parametrize("split", [1, 2])
+def test_gemm_epilogue(split):
+    KC.case_gemm_epilogue(DEV, M=2000, N=320, K_=320, split_k=split)
+
+
+@pytest.mark.parametrize("kw", [dict(stride=1, pad=1), dict(stride=2, pad=1), dict(asym=True, stride=2, pad=0), dict(ups=True)])
+def test_conv_fwd_dgrad_wgrad(kw):
+    KC.case_conv(DEV, 2, 32, 32, 64, 128, **kw)
+
+
+def test_conv_unet_shape():
+    KC.case_conv(DEV, 1, 32, 32, 320, 640)
+
+
+def test_conv_small_channels():
+    KC.case_conv(DEV, 1, 64, 64, 8, 32)
+
+
+@pytest.mark.parametrize("B,H,Nq,Nk,D,fused", [
+    (1, 8, 4096, 4096, 40, True), (2, 8, 4096, 77, 40, False), (2, 8, 1024, 1024, 80, True), (2, 8, 1024, 77, 80, False),
+    (2, 8, 256, 256, 160, True), (2, 8, 64, 77, 160, False), (1, 2, 70, 70, 40, True), (1, 1, 150, 77, 64, False),
+    (1, 2, 20, 20, 8, False)])
+def test_attention(B, H, Nq, Nk, D, fused):
+    KC.case_attention(DEV, B, H, Nq, Nk, D, fused_qkv=fused)
+
+
+@pytest.mark.parametrize("B,HW,C,G,silu,train", [(2, 4096, 320, 32, True, False), (2, 1024, 960, 32, True, False),
+                                                 (1, 64, 2560, 32, True, False), (2, 4096, 32, 32, True, True),
+                                                 (1, 1024, 640, 32, False, False), (1, 37, 64, 8, False, True)])
+def test_groupnorm(B, HW, C, G, silu, train):
+    KC.case_groupnorm(DEV, B, HW, C, G, silu, train_params=train)
+
+
+@pytest.mark.parametrize("M,C", [(4096, 320), (1024, 640), (259, 1280)])
+def test_layernorm(M, C):
+    KC.case_layernorm(DEV, M, C)
+
+
+def test_geglu():
+    KC.case_geglu(DEV, 4096, 1280)
+
+
+@pytest.mark.parametrize("M,K,N,R,xr", [(8192, 320, 320, 4, 0), (8192, 320, 320, 8, 4096), (308, 768, 640, 8, 0), (512, 576, 320, 32, 0)])
+def test_lora(M, K, N, R, xr):
+    KC.case_lora(DEV, M, K, N, R, x_rows=xr)
+
+
+def test_elementwise():
+    KC.case_elementwise(DEV)
+
+
+def test_loss_and_optimizer():
+    KC.case_loss_and_optimizer(DEV, n=100000)
