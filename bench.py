@@ -1,0 +1,199 @@
+"""bench.py -- headline benchmark of the ControlLoRA hot path on MI355X (contract in the task brief).
+
+  python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank per GPU)
+
+One "step" = one full training step of the hot path on a synthetic fill50k-like batch resident in HBM:
+hint-encoder forward, SD-1.5 UNet forward with the 32 ControlLoRA processors, fp32 MSE, backward (dgrad
+through the frozen fp16 UNet, wgrad for adapters + hint encoder), [RCCL all-reduce of the flat 24 MB
+gradient], fused clip + AdamW.  Workload = BASELINE.json configs[1]: configs/fill50k.json, SD-1.5 topology
+with seeded random weights (no checkpoint offline), 512x512, batch 4 per GPU, fp16.  VAE-encode / CLIP are
+outside the named hot path: latents and text embeddings are synthetic inputs.
+
+Prints ONE JSON line (rank 0) with metric/value plus `roofline` (dominant kernel family, HIP-event timed in a
+separate profiling step after the timed region) and `cpu_baseline` (the CPU oracle, N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HOT_PATH_TFLOP_PER_IMAGE_512 = 1.81      # fwd 803.3 + bwd 929.4 GFLOP UNet + 3x(adapters + hint)
+MFMA_PEAK_TFLOPS = 2500.0                # dense fp16, MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+
+
+def synthetic_batch(B, res, dev, seed):
+    """fill50k-like: filled disc -> latents stand-in ~N(0,1); guide = disc outline (+1 on -1), 3 channels."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    L = res // 8
+    yy, xx = torch.meshgrid(torch.arange(res), torch.arange(res), indexing="ij")
+    guide = torch.empty(B, 3, res, res)
+    for b in range(B):
+        cx, cy = torch.randint(res // 4, 3 * res // 4, (2,), generator=g)
+        r = int(torch.randint(res // 16, res // 4, (1,), generator=g))
+        d = ((xx - cx) ** 2 + (yy - cy) ** 2).float().sqrt()
+        guide[b] = ((d - r).abs() < 2).float()[None] * 2 - 1
+    return dict(
+        guide=guide.to(dev).half(),
+        latents=torch.randn(B, 4, L, L, generator=g).to(dev).half(),
+        noise=torch.randn(B, 4, L, L, generator=g).to(dev).half(),
+        timesteps=torch.randint(0, 1000, (B,), generator=g).to(dev),
+        ehs=torch.randn(B, 77, 768, generator=g).to(dev).half(),
+    )
+
+
+def build_models(dev, seed=0):
+    from controllora_amd import models as M, unet as U
+    unet = U.UNet2DConditionModel()
+    unet.to(dev)
+    g = torch.Generator(device=dev).manual_seed(seed)
+    with torch.no_grad():
+        for name, p in unet.named_parameters():
+            if p.ndim >= 2:
+                p.normal_(0.0, 1.0 / math.sqrt(p[0].numel()), generator=g)
+            elif name.endswith("bias"):
+                p.zero_()
+            else:
+                p.fill_(1.0)
+    torch.manual_seed(seed)
+    clora = M.ControlLoRA.from_config(os.path.join(ROOT, "configs", "fill50k.json")).to(dev)
+    unet.set_attn_processor(M.map_processors_to_unet(unet, clora))
+    return unet, clora
+
+
+def cpu_baseline(steps=2):
+    """The CPU oracle (pure-torch fp32 restatement of the reference path, materialised attention) on BASELINE
+    configs[0]: fill50k.json, SD-1.5, 256x256, batch 1.  Bounded sample: 1 warm-up + `steps` timed steps."""
+    from oracle import cases, unet_ref
+    from oracle.controllora_ref import ControlLoRARef, map_processors_to_unet
+    torch.manual_seed(0)
+    unet = unet_ref.UNet2DConditionModel()
+    unet_ref.init_unet_weights_(unet, seed=0)
+    clora = ControlLoRARef.from_config(os.path.join(ROOT, "configs", "fill50k.json"))
+    unet.set_attn_processor(map_processors_to_unet(unet, clora))
+    opt = torch.optim.AdamW(clora.parameters(), lr=1e-4, weight_decay=1e-2)
+    b = synthetic_batch(1, 256, "cpu", 42)
+    inp = dict(guide=b["guide"].float(), latents=b["latents"].float(), noise=b["noise"].float(),
+               timesteps=b["timesteps"], ehs=b["ehs"].float())
+    times = []
+    for i in range(steps + 1):
+        t0 = time.perf_counter()
+        cases.oracle_train_step(unet, clora, clora, inp)
+        torch.nn.utils.clip_grad_norm_(clora.parameters(), 1.0)
+        opt.step()
+        opt.zero_grad()
+        if i > 0:
+            times.append(time.perf_counter() - t0)
+    sec = sum(times) / len(times)
+    return {"value": round(1.0 / sec, 4), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle (pure-torch fp32, materialised attention) train step, fill50k.json SD-1.5 256x256 bs1, "
+                      f"{steps} steps after 1 warm-up, {sec:.2f} s/step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=4, help="per-GPU batch (BASELINE: 4)")
+    ap.add_argument("--res", type=int, default=512)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    pg = None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl", device_id=dev)      # "nccl" IS RCCL on ROCm
+        pg = torch.distributed.group.WORLD
+
+    from controllora_amd import kernels as K
+    from controllora_amd.schedulers import DDPMScheduler
+    from controllora_amd.train import ControlLoRATrainer
+
+    unet, clora = build_models(dev)
+    trainer = ControlLoRATrainer(unet, clora, process_group=pg, world_size=world)
+    batch = synthetic_batch(args.batch, args.res, dev, 42 + rank)         # data-parallel: different samples per rank
+    noisy = DDPMScheduler().add_noise(batch["latents"], batch["noise"], batch["timesteps"]).half()
+
+    def step():
+        trainer.step(noisy, batch["timesteps"], batch["ehs"], batch["guide"], batch["noise"])
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t)
+    ms = elapsed / args.steps * 1e3
+    images_per_s = args.batch * world / (ms * 1e-3)
+    loss = trainer.loss(noisy.numel())
+    skipped = float(trainer.state[6])
+
+    roofline = None
+    if not args.no_roofline and rank == 0:
+        K.PROFILER = K.KernelProfiler()
+        step()
+        agg = K.PROFILER.summary()
+        K.PROFILER = None
+        total_ms = sum(a["ms"] for a in agg.values())
+        dom_name, dom = max(agg.items(), key=lambda kv: kv[1]["ms"])
+        fam = {k: {"calls": v["calls"], "ms": round(v["ms"], 3),
+                   "TFLOPs": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["flops"] else None}
+               for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])[:8]}
+        ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "kernel": dom_name, "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                    "launches": dom["calls"], "avg_launch_us": round(dom["ms"] * 1e3 / dom["calls"], 1),
+                    "kernel_ms_per_step": round(total_ms, 2), "families": fam,
+                    "whole_step_frac_of_mfma_peak": round(
+                        images_per_s / world * HOT_PATH_TFLOP_PER_IMAGE_512 * (args.res / 512) ** 2 / MFMA_PEAK_TFLOPS, 4)}
+
+    cpu = None
+    if world == 1 and rank == 0 and not args.no_cpu_baseline:
+        cpu = cpu_baseline()
+
+    if rank == 0:
+        print(json.dumps({
+            "metric": "train images/sec SD-1.5+ControlLoRA 512^2 bs4/GPU", "value": round(images_per_s, 3),
+            "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f16", "data": "synthetic",
+            "config": {"workload": f"configs/fill50k.json on SD-1.5 topology (seeded random weights), {args.res}x{args.res}, "
+                                   f"bs={args.batch}/GPU, fp16; hot path = hint encoder + UNet fwd/bwd + adapter AdamW; "
+                                   f"latents/text embeddings synthetic (VAE/CLIP outside the hot path)",
+                       "global_batch": args.batch * world, "parallelism": f"dp{world}",
+                       "allreduce_bytes": trainer.flat.numel * 4},
+            "loss": round(loss, 5), "steps_skipped_by_scaler": skipped,
+            "roofline": roofline, "cpu_baseline": cpu}))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

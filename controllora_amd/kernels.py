@@ -16,8 +16,37 @@ from .capi import ConvDesc, Epilogue, ptr
 f16, f32 = torch.float16, torch.float32
 
 
-def _call(name, *args):
+class KernelProfiler:
+    """Optional per-launch timing with HIP events recorded on the launch stream (bench.py's roofline leg).
+    Off by default; never active inside a timed region."""
+
+    def __init__(self):
+        self.records = []          # (entry point, start event, end event, algorithmic flops, algorithmic bytes)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        agg = {}
+        for name, e0, e1, fl, by in self.records:
+            a = agg.setdefault(name, dict(calls=0, ms=0.0, flops=0.0, bytes=0.0))
+            a["calls"] += 1
+            a["ms"] += e0.elapsed_time(e1)
+            a["flops"] += fl
+            a["bytes"] += by
+        return agg
+
+
+PROFILER: Optional[KernelProfiler] = None
+
+
+def _call(name, *args, flops=0.0, nbytes=0.0):
+    if PROFILER is None:
+        capi.lib().call(name, *args, capi.stream())
+        return
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
     capi.lib().call(name, *args, capi.stream())
+    e1.record()
+    PROFILER.records.append((name, e0, e1, float(flops), float(nbytes)))
 
 
 def _c2(t: torch.Tensor) -> torch.Tensor:
@@ -98,7 +127,8 @@ def gemm(A: torch.Tensor, Bw: torch.Tensor, M: int, N: int, K: int, *, lda: Opti
     ws = workspace(sk * M * N * 4, A.device) if sk > 1 else None
     _call("clora_gemm_f16", ptr(A), lda if lda is not None else K, ptr(Bw), ptr(C_), ldc, M, N, K,
           C.byref(conv) if conv is not None else None, C.byref(e), sk,
-          ptr(ws) if ws is not None else None, ws.numel() if ws is not None else 0)
+          ptr(ws) if ws is not None else None, ws.numel() if ws is not None else 0,
+          flops=2.0 * M * N * K, nbytes=2.0 * (A.numel() + N * K + M * N))
     return C_
 
 
@@ -116,7 +146,7 @@ def attn_fwd(q, k, v, B, H, Nq, Nk, D, scale, out=None):
     o = out if out is not None else torch.empty((B * Nq, H * D), dtype=f16, device=q.device)
     lse = torch.empty((B, H, Nq), dtype=f32, device=q.device)
     _call("clora_attn_fwd_f16", ptr(q, f16), q.stride(0), ptr(k, f16), k.stride(0), ptr(v, f16), v.stride(0),
-          ptr(o), o.stride(0), ptr(lse), B, H, Nq, Nk, D, float(scale))
+          ptr(o), o.stride(0), ptr(lse), B, H, Nq, Nk, D, float(scale), flops=4.0 * B * H * Nq * Nk * D)
     return o, lse
 
 
@@ -125,7 +155,7 @@ def attn_bwd(q, k, v, o, dO, lse, B, H, Nq, Nk, D, scale, dq, dk, dv):
     _call("clora_attn_bwd_f16", ptr(q, f16), q.stride(0), ptr(k, f16), k.stride(0), ptr(v, f16), v.stride(0),
           ptr(o, f16), o.stride(0), ptr(dO, f16), dO.stride(0), ptr(lse, f32), ptr(delta),
           ptr(dq, f16), dq.stride(0), ptr(dk, f16), dk.stride(0), ptr(dv, f16), dv.stride(0),
-          B, H, Nq, Nk, D, float(scale))
+          B, H, Nq, Nk, D, float(scale), flops=10.0 * B * H * Nq * Nk * D)
     return dq, dk, dv
 
 
@@ -190,8 +220,8 @@ def geglu_bwd(h, dy):
 # ------------------------------------------------------------------ adapters
 def lora_down(X, D, T, toff, M, K, accumulate=False, x_rows=0, ldx=None):
     """T[:, toff:toff+R] (+)= X . D^T ; X [rows, K] fp16 (row pitch ldx), D [R, K] fp32, T [M, ldt] fp32."""
-    assert D.dtype == f32 and D.is_contiguous() and T.dtype == f32 and T.is_contiguous()
-    _call("clora_lora_down_f16", ptr(X, f16), ldx if ldx is not None else X.stride(0), ptr(D), D.shape[1], ptr(T),
+    assert D.dtype == f32 and D.stride(1) == 1 and T.dtype == f32 and T.is_contiguous()
+    _call("clora_lora_down_f16", ptr(X, f16), ldx if ldx is not None else X.stride(0), ptr(D), D.stride(0), ptr(T),
           T.shape[1], toff, M, K, D.shape[0], int(accumulate), x_rows)
     return T
 

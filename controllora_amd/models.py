@@ -1,0 +1,450 @@
+"""ControlLoRA for MI355X: same public surface as the reference ``models.py`` (classes, constructor
+arguments, attribute / state-dict names, ``inject_*`` / ``skip_*`` methods, config schema -- SURVEY.md
+section 8b), with the math running on the gfx950 kernels.
+
+Reference map (file:line in /root/reference/models.py):
+  LoRACrossAttnProcessor            :72-152    -> LoRACrossAttnProcessor
+  ControlLoRACrossAttnProcessor     :155-287   -> ControlLoRACrossAttnProcessor
+  ControlLoRACrossAttnProcessorV2   :292-431   -> ControlLoRACrossAttnProcessorV2
+  ConvBlock2D / SimpleDownEncoderBlock2D :434-610 -> ConvBlock2D / SimpleDownEncoderBlock2D
+  ControlLoRA                       :618-835   -> ControlLoRA
+
+Per attention site the reference launches ~25-30 micro-kernels for the adapters and materialises the
+score matrix; here a site is: (control add) -> one fused q|k|v GEMM with the rank-r updates in its epilogue
+-> flash attention -> one out-projection GEMM (+ adapter + bias + residual).  Quirks C1-C9 of SURVEY.md
+Appendix C are kept.  Not yet on the fused path (raises NotImplementedError, SURVEY.md 8f "next"):
+``pre_loras`` / ``post_loras`` chaining and ``post_add=True``.
+"""
+from __future__ import annotations
+
+import inspect
+import json
+import os
+from dataclasses import dataclass
+from typing import List, Optional, Tuple, Union
+
+import torch
+import torch.nn as nn
+
+from . import kernels as K
+from . import ops
+
+f16, f32 = torch.float16, torch.float32
+
+
+class LoRALinearLayer(nn.Module):
+    """Parameter holder with upstream naming/initialisation: down ~ N(0, 1/rank), up = 0."""
+
+    def __init__(self, in_features, out_features, rank=4):
+        super().__init__()
+        if rank > min(in_features, out_features):
+            raise ValueError(f"LoRA rank {rank} must be less or equal than {min(in_features, out_features)}")
+        self.down = nn.Linear(in_features, rank, bias=False)
+        self.up = nn.Linear(rank, out_features, bias=False)
+        nn.init.normal_(self.down.weight, std=1 / rank)
+        nn.init.zeros_(self.up.weight)
+
+
+def _flat2(t):
+    return t.reshape(-1, t.shape[-1])
+
+
+class LoRACrossAttnProcessor(nn.Module):
+    fuses_residual = True
+
+    def __init__(self, hidden_size, cross_attention_dim=None, rank=4, post_add=False, key_states_skipped=False,
+                 value_states_skipped=False, output_states_skipped=False):
+        super().__init__()
+        self.hidden_size, self.cross_attention_dim, self.rank, self.post_add = hidden_size, cross_attention_dim, rank, post_add
+        kv_in = hidden_size if post_add else (cross_attention_dim or hidden_size)
+        self.to_q_lora = LoRALinearLayer(hidden_size, hidden_size, rank)
+        if not key_states_skipped:
+            self.to_k_lora = LoRALinearLayer(kv_in, hidden_size, rank)
+        if not value_states_skipped:
+            self.to_v_lora = LoRALinearLayer(kv_in, hidden_size, rank)
+        if not output_states_skipped:
+            self.to_out_lora = LoRALinearLayer(hidden_size, hidden_size, rank)
+        self.key_states_skipped: bool = key_states_skipped
+        self.value_states_skipped: bool = value_states_skipped
+        self.output_states_skipped: bool = output_states_skipped
+
+    def skip_key_states(self, is_skipped: bool = True):
+        if is_skipped == False:  # noqa: E712  (same truthiness test as the reference)
+            assert hasattr(self, "to_k_lora")
+        self.key_states_skipped = is_skipped
+
+    def skip_value_states(self, is_skipped: bool = True):
+        if is_skipped == False:  # noqa: E712
+            assert hasattr(self, "to_q_lora")       # quirk C4 kept
+        self.value_states_skipped = is_skipped
+
+    def skip_output_states(self, is_skipped: bool = True):
+        if is_skipped == False:  # noqa: E712
+            assert hasattr(self, "to_out_lora")
+        self.output_states_skipped = is_skipped
+
+    # -- shared fused pipeline ------------------------------------------------------------------
+    def _seg(self, name, xa, scale, skipped=False):
+        if skipped or not hasattr(self, name):
+            return None
+        layer = getattr(self, name)
+        return (xa, layer.down.weight, layer.up.weight, scale)
+
+    def _check_fast_path(self):
+        if self.post_add or getattr(self, "pre_loras", None) or getattr(self, "post_loras", None):
+            raise NotImplementedError("post_add / pre_loras / post_loras are not on the fused gfx950 path yet "
+                                      "(SURVEY.md section 8f rank 2)")
+
+    def _attend(self, attn, h2, q_in, e2, B, N, Nk, scale, out_in_fn, residual, own_out_always):
+        packs = attn.fused_packs()
+        if attn.is_cross:
+            q = ops.lora_proj(h2, packs[0], [self._seg("to_q_lora", q_in, scale)])
+            kv = ops.lora_proj(e2, packs[1], [self._seg("to_k_lora", e2, scale, self.key_states_skipped),
+                                             self._seg("to_v_lora", e2, scale, self.value_states_skipped)])
+            a = attn.attend(q, kv, B, N, Nk)
+        else:
+            qkv = ops.lora_proj(h2, packs[0], [self._seg("to_q_lora", q_in, scale),
+                                               self._seg("to_k_lora", h2, scale, self.key_states_skipped),
+                                               self._seg("to_v_lora", h2, scale, self.value_states_skipped)])
+            a = attn.attend(qkv, None, B, N, N)
+        a = out_in_fn(a)
+        out_seg = self._seg("to_out_lora", a, scale, (not own_out_always) and self.output_states_skipped)
+        res2 = _flat2(residual) if residual is not None else None
+        return ops.lora_proj(a, attn.to_out[0].pack(), [out_seg], residual=res2)
+
+    def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, scale=1.0, residual=None):
+        self._check_fast_path()
+        attn.prepare_attention_mask(attention_mask, hidden_states.shape[1])
+        B, N, C_ = hidden_states.shape
+        h2 = _flat2(hidden_states)
+        e2 = _flat2(encoder_hidden_states) if attn.is_cross else None
+        Nk = encoder_hidden_states.shape[1] if attn.is_cross else N
+        out = self._attend(attn, h2, h2, e2, B, N, Nk, scale, lambda a: a, residual, own_out_always=False)
+        return out.reshape(B, N, C_)
+
+
+class _ControlMixin:
+    def inject_pre_lora(self, lora_layer):
+        self.pre_loras.append(lora_layer)
+
+    def inject_post_lora(self, lora_layer):
+        self.post_loras.append(lora_layer)
+
+    def inject_control_states(self, control_states):
+        self.control_states = control_states
+
+    def _control_tokens(self, hidden_states):
+        """models.py:202-206 / :337-341: flatten NCHW -> [B, HW, C] once and cache on self (quirk C5).  The hint
+        encoder hands out NCHW *views* of NHWC memory, so this is a zero-copy reshape here."""
+        ctrl = self.control_states.to(hidden_states.dtype)
+        if hidden_states.ndim == 3 and ctrl.ndim == 4:
+            b, _, hh, ww = ctrl.shape
+            ctrl = ctrl.permute(0, 2, 3, 1).reshape(b, hh * ww, -1)
+            self.control_states = ctrl
+        return ctrl.contiguous()
+
+    def process_control_states(self, hidden_states, scale=1.0, is_out=False):
+        """Returns hidden_states + scale * to_control[_out](control | cat(hidden, control)) -- i.e. the sum the
+        reference forms right after calling its process_control_states (control_self_add is always False, C1)."""
+        ctrl = self._control_tokens(hidden_states)
+        layer = self.to_control_out if is_out else self.to_control
+        return ops.control_add(_flat2(hidden_states), _flat2(ctrl), layer.down.weight, layer.up.weight, scale,
+                               self.concat_hidden)
+
+
+class ControlLoRACrossAttnProcessor(_ControlMixin, LoRACrossAttnProcessor):
+    def __init__(self, hidden_size, cross_attention_dim=None, rank=4, control_rank=None, post_add=False,
+                 concat_hidden=False, control_channels=None, control_self_add=True, key_states_skipped=False,
+                 value_states_skipped=False, output_states_skipped=False, **kwargs):
+        super().__init__(hidden_size, cross_attention_dim, rank, post_add=post_add, key_states_skipped=key_states_skipped,
+                         value_states_skipped=value_states_skipped, output_states_skipped=output_states_skipped)
+        control_rank = rank if control_rank is None else control_rank
+        control_channels = hidden_size if control_channels is None else control_channels
+        self.concat_hidden = concat_hidden
+        self.control_self_add = False      # quirk C1: the reference's conditional can only yield False
+        self.control_states: Optional[torch.Tensor] = None
+        self.to_control = LoRALinearLayer(control_channels + (hidden_size if concat_hidden else 0), hidden_size, control_rank)
+        self.pre_loras: List[LoRACrossAttnProcessor] = []
+        self.post_loras: List[LoRACrossAttnProcessor] = []
+
+    def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, scale=1.0, residual=None):
+        assert self.control_states is not None
+        self._check_fast_path()
+        attn.prepare_attention_mask(attention_mask, hidden_states.shape[1])
+        B, N, C_ = hidden_states.shape
+        h2 = _flat2(hidden_states)
+        e2 = _flat2(encoder_hidden_states) if attn.is_cross else None
+        Nk = encoder_hidden_states.shape[1] if attn.is_cross else N
+        hc = self.process_control_states(hidden_states, scale)      # hidden + control term feeds ONLY the q adapter
+        out = self._attend(attn, h2, hc, e2, B, N, Nk, scale, lambda a: a, residual, own_out_always=True)  # quirk C2
+        return out.reshape(B, N, C_)
+
+
+class ControlLoRACrossAttnProcessorV2(_ControlMixin, LoRACrossAttnProcessor):
+    def __init__(self, hidden_size, cross_attention_dim=None, rank=4, control_rank=None, control_channels=None, **kwargs):
+        super().__init__(hidden_size, cross_attention_dim, rank, post_add=False, key_states_skipped=True,
+                         value_states_skipped=True, output_states_skipped=False)
+        control_rank = rank if control_rank is None else control_rank
+        control_channels = hidden_size if control_channels is None else control_channels
+        self.concat_hidden = True
+        self.control_self_add = False
+        self.control_states: Optional[torch.Tensor] = None
+        self.to_control = LoRALinearLayer(hidden_size + control_channels, hidden_size, control_rank)
+        self.to_control_out = LoRALinearLayer(hidden_size + control_channels, hidden_size, control_rank)
+        self.pre_loras: List[LoRACrossAttnProcessor] = []
+        self.post_loras: List[LoRACrossAttnProcessor] = []
+
+    def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, scale=1.0, residual=None):
+        assert self.control_states is not None
+        self._check_fast_path()
+        attn.prepare_attention_mask(attention_mask, hidden_states.shape[1])
+        B, N, C_ = hidden_states.shape
+        e2 = _flat2(encoder_hidden_states) if attn.is_cross else None
+        Nk = encoder_hidden_states.shape[1] if attn.is_cross else N
+        hp = self.process_control_states(hidden_states, scale)       # h' replaces h everywhere (models.py:369)
+        shape3 = hidden_states.shape
+
+        def post(a):                                                  # a' = a + control_out term (models.py:415)
+            return self.process_control_states(a.reshape(shape3), scale, is_out=True)
+
+        out = self._attend(attn, hp, hp, e2, B, N, Nk, scale, post, residual, own_out_always=True)
+        return out.reshape(B, N, C_)
+
+
+# ------------------------------------------------------------------------------------------------ hint encoder
+class _Conv2dParams(nn.Module):
+    """Parameter holder with nn.Conv2d naming (weight [Co,Ci,k,k], bias) and PyTorch's default init."""
+
+    def __init__(self, cin, cout, k):
+        super().__init__()
+        ref = nn.Conv2d(cin, cout, k)
+        self.weight, self.bias = ref.weight, ref.bias
+        self.k = k
+
+
+class ConvBlock2D(nn.Module):
+    """H1: SiLU(GN2(conv_k(SiLU(GN1(x)))))  -- reference models.py:512-547 with temb=None (non residual, C7)."""
+
+    def __init__(self, *, in_channels, out_channels=None, conv_kernel_size=3, groups=32, eps=1e-6, **unused):
+        super().__init__()
+        out_channels = in_channels if out_channels is None else out_channels
+        self.in_channels, self.out_channels, self.groups, self.eps = in_channels, out_channels, groups, eps
+        self.norm1 = nn.GroupNorm(groups, in_channels, eps=eps, affine=True)
+        self.conv1 = _Conv2dParams(in_channels, out_channels, conv_kernel_size)
+        self.norm2 = nn.GroupNorm(groups, out_channels, eps=eps, affine=True)
+
+    def forward(self, x, B, H, W):
+        h = ops.group_norm(x, self.norm1.weight, self.norm1.bias, self.groups, self.eps, True)
+        h = ops.train_conv(h.reshape(B * H * W, -1), self.conv1.weight, self.conv1.bias, B, H, W)
+        return ops.group_norm(h.reshape(B, H * W, -1), self.norm2.weight, self.norm2.bias, self.groups, self.eps, True)
+
+
+class _Down(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.conv = _Conv2dParams(c, c, 3)
+
+
+class SimpleDownEncoderBlock2D(nn.Module):
+    """H2: reference models.py:550-610; the downsampler is diffusers' Downsample2D(padding=0): pad (0,1,0,1) + stride 2."""
+
+    def __init__(self, in_channels, out_channels, num_layers=1, convnet_eps=1e-6, convnet_groups=32,
+                 convnet_kernel_size=3, add_downsample=True, downsample_padding=0, **unused):
+        super().__init__()
+        assert downsample_padding == 0
+        self.convnets = nn.ModuleList([
+            ConvBlock2D(in_channels=in_channels if i == 0 else out_channels, out_channels=out_channels,
+                        conv_kernel_size=convnet_kernel_size, groups=convnet_groups, eps=convnet_eps)
+            for i in range(num_layers)])
+        self.downsamplers = nn.ModuleList([_Down(out_channels)]) if add_downsample else None
+
+    def forward(self, x, B, H, W):
+        for c in self.convnets:
+            x = c(x, B, H, W)
+        if self.downsamplers is not None:
+            d = self.downsamplers[0].conv
+            x = ops.train_conv(x.reshape(B * H * W, -1), d.weight, d.bias, B, H, W, stride=2, asym_pad=True)
+            H, W = (H + 1 - 3) // 2 + 1, (W + 1 - 3) // 2 + 1
+            x = x.reshape(B, H * W, -1)
+        return x, H, W
+
+
+@dataclass
+class ControlLoRAOutput:
+    control_states: Tuple[torch.Tensor, ...]
+
+    def __getitem__(self, k):
+        return self.control_states if k in (0, "control_states") else (_ for _ in ()).throw(IndexError(k))
+
+
+DEFAULT_CROSS_DIMS = ([None, 768] * 5, [None, 768] * 5, [None, 768] * 5, [None, 768])
+CONFIG_NAME, WEIGHTS_NAME, SAFE_WEIGHTS_NAME = "config.json", "diffusion_pytorch_model.bin", "diffusion_pytorch_model.safetensors"
+
+
+class ControlLoRA(nn.Module):
+    def __init__(
+        self,
+        in_channels: int = 3,
+        down_block_types: Tuple[str] = ("SimpleDownEncoderBlock2D",) * 4,
+        block_out_channels: Tuple[int] = (32, 64, 128, 256),
+        layers_per_block: int = 1,
+        act_fn: str = "silu",
+        norm_num_groups: int = 32,
+        lora_pre_down_block_types: Tuple[str] = (None,) + ("SimpleDownEncoderBlock2D",) * 3,
+        lora_pre_down_layers_per_block: int = 1,
+        lora_pre_conv_skipped: bool = False,
+        lora_pre_conv_types: Tuple[str] = ("SimpleDownEncoderBlock2D",) * 4,
+        lora_pre_conv_layers_per_block: int = 1,
+        lora_pre_conv_layers_kernel_size: int = 1,
+        lora_block_in_channels: Tuple[int] = (256, 256, 256, 256),
+        lora_block_out_channels: Tuple[int] = (320, 640, 1280, 1280),
+        lora_cross_attention_dims: Tuple[List[int]] = DEFAULT_CROSS_DIMS,
+        lora_rank: int = 4,
+        lora_control_rank: int = None,
+        lora_post_add: bool = False,
+        lora_concat_hidden: bool = False,
+        lora_control_channels: Tuple[int] = (None, None, None, None),
+        lora_control_self_add: bool = True,
+        lora_key_states_skipped: bool = False,
+        lora_value_states_skipped: bool = False,
+        lora_output_states_skipped: bool = False,
+        lora_control_version: int = 1,
+    ):
+        super().__init__()
+        cfg = {k: v for k, v in locals().items() if k not in ("self", "__class__")}
+        self.config = cfg                                                # register_to_config equivalent
+        if act_fn not in ("silu", "swish"):
+            raise ValueError(f"unsupported act_fn {act_fn}: every shipped config uses silu")
+        cls = ControlLoRACrossAttnProcessorV2 if lora_control_version == 2 else ControlLoRACrossAttnProcessor
+        assert lora_block_in_channels[0] == block_out_channels[-1]
+        if lora_pre_conv_skipped:
+            lora_control_channels = lora_block_in_channels
+            lora_control_self_add = False
+        g = norm_num_groups
+        self.layers_per_block = layers_per_block
+        self.lora_pre_down_layers_per_block = lora_pre_down_layers_per_block
+        self.lora_pre_conv_layers_per_block = lora_pre_conv_layers_per_block
+        self.conv_in = _Conv2dParams(in_channels, block_out_channels[0], 3)
+        self.down_blocks = nn.ModuleList([])
+        self.pre_lora_layers = nn.ModuleList([])
+        self.lora_layers = nn.ModuleList([])
+        stages, c = [], block_out_channels[0]
+        for i, co in enumerate(block_out_channels):
+            stages.append(SimpleDownEncoderBlock2D(c, co, num_layers=layers_per_block, convnet_groups=g,
+                                                   add_downsample=i != len(block_out_channels) - 1))
+            c = co
+        for i in range(len(lora_pre_down_block_types)):
+            if i == 0:
+                self.down_blocks.append(nn.Sequential(*stages))
+                cin = lora_block_in_channels[0]
+            else:
+                cin_prev, cin = lora_block_in_channels[i - 1], lora_block_in_channels[i]
+                self.down_blocks.append(SimpleDownEncoderBlock2D(cin_prev, cin, num_layers=lora_pre_down_layers_per_block,
+                                                                 convnet_groups=g, add_downsample=True))
+            cc = lora_control_channels[i]
+            if lora_pre_conv_skipped:
+                self.pre_lora_layers.append(nn.Identity())
+            else:
+                self.pre_lora_layers.append(SimpleDownEncoderBlock2D(
+                    cin, lora_block_out_channels[i] if cc is None else cc, num_layers=lora_pre_conv_layers_per_block,
+                    convnet_groups=g, convnet_kernel_size=lora_pre_conv_layers_kernel_size, add_downsample=False))
+            self.lora_layers.append(nn.ModuleList([
+                cls(lora_block_out_channels[i], cross_attention_dim=cad, rank=lora_rank, control_rank=lora_control_rank,
+                    post_add=lora_post_add, concat_hidden=lora_concat_hidden, control_channels=cc,
+                    control_self_add=lora_control_self_add, key_states_skipped=lora_key_states_skipped,
+                    value_states_skipped=lora_value_states_skipped, output_states_skipped=lora_output_states_skipped)
+                for cad in lora_cross_attention_dims[i]]))
+
+    # ---- config / checkpoint surface (diffusers ConfigMixin / ModelMixin subset)
+    @classmethod
+    def load_config(cls, path_or_dict, subfolder=None):
+        if isinstance(path_or_dict, dict):
+            return dict(path_or_dict)
+        path = path_or_dict
+        if subfolder:
+            path = os.path.join(path, subfolder)
+        if os.path.isdir(path):
+            path = os.path.join(path, CONFIG_NAME)
+        with open(path) as f:
+            return json.load(f)
+
+    @classmethod
+    def from_config(cls, config, **kwargs):
+        cfg = cls.load_config(config)
+        accepted = set(inspect.signature(cls.__init__).parameters) - {"self"}
+        init = {k: v for k, v in cfg.items() if k in accepted}      # tolerates _class_name / _diffusers_version
+        init.update(kwargs)
+        return cls(**init)
+
+    def save_config(self, save_directory):
+        os.makedirs(save_directory, exist_ok=True)
+        d = {k: (list(v) if isinstance(v, tuple) else v) for k, v in self.config.items()}
+        d["_class_name"], d["_diffusers_version"] = "ControlLoRA", "0.13.0.dev0"
+        with open(os.path.join(save_directory, CONFIG_NAME), "w") as f:
+            json.dump(d, f, indent=2, sort_keys=True)
+
+    def save_pretrained(self, save_directory, safe_serialization=False):
+        self.save_config(save_directory)
+        sd = {k: v.detach().cpu().contiguous() for k, v in self.state_dict().items()}
+        if safe_serialization:
+            from safetensors.torch import save_file
+            save_file(sd, os.path.join(save_directory, SAFE_WEIGHTS_NAME))
+        else:
+            torch.save(sd, os.path.join(save_directory, WEIGHTS_NAME))
+
+    @classmethod
+    def from_pretrained(cls, path, subfolder=None, **kwargs):
+        root = os.path.join(path, subfolder) if subfolder else path
+        model = cls.from_config(os.path.join(root, CONFIG_NAME), **kwargs)
+        safe = os.path.join(root, SAFE_WEIGHTS_NAME)
+        if os.path.exists(safe):
+            from safetensors.torch import load_file
+            sd = load_file(safe)
+        else:
+            sd = torch.load(os.path.join(root, WEIGHTS_NAME), map_location="cpu")
+        model.load_state_dict(sd)
+        return model
+
+    # ---- forward (H4, reference models.py:810-835)
+    def forward(self, x: torch.Tensor, return_dict: bool = True) -> Union[ControlLoRAOutput, Tuple]:
+        orig_dtype = x.dtype
+        B, Cin, H, W = x.shape
+        xin = x.new_zeros((B, H, W, (Cin + 7) // 8 * 8), dtype=f16)
+        xin[..., :Cin] = x.permute(0, 2, 3, 1)
+        h = ops.train_conv(xin.reshape(B * H * W, -1), self.conv_in.weight, self.conv_in.bias, B, H, W, need_dx=False)
+        h = h.reshape(B, H * W, -1)
+        outs = []
+        for down, pre, procs in zip(self.down_blocks, self.pre_lora_layers, self.lora_layers):
+            for stage in (down if isinstance(down, nn.Sequential) else [down]):
+                h, H, W = stage(h, B, H, W)
+            c = h
+            if not isinstance(pre, nn.Identity):
+                c, _, _ = pre(h, B, H, W)
+            # NCHW-shaped *view* of the NHWC tensor: API parity with the reference at zero cost
+            ctrl = c.reshape(B, H, W, -1).permute(0, 3, 1, 2)
+            if orig_dtype != f16:
+                ctrl = ctrl.to(orig_dtype)
+            for p in procs:
+                p.inject_control_states(ctrl)
+            outs.append(ctrl)
+        if not return_dict:
+            return tuple(outs)
+        return ControlLoRAOutput(control_states=tuple(outs))
+
+
+def map_processors_to_unet(unet, control_lora) -> dict:
+    """M1: the name -> processor assignment of train_text_to_image_control_lora.py:469-487
+    (also apps/gradio_canny2image.py:43-63)."""
+    n = len(unet.config.block_out_channels)
+    pools = [list(l) for l in control_lora.lora_layers]
+    procs = {}
+    for name in unet.attn_processors.keys():
+        if name.startswith("mid_block"):
+            cid = n - 1
+        elif name.startswith("up_blocks"):
+            cid = n - 1 - int(name[len("up_blocks."):].split(".")[0])
+        else:
+            cid = int(name[len("down_blocks."):].split(".")[0])
+        if pools[cid]:
+            procs[name] = pools[cid].pop(0)
+    return procs

@@ -1,0 +1,458 @@
+"""torch.autograd.Function wrappers: how the HIP kernels plug into ``loss.backward()``.
+
+Every Function calls ``controllora_amd.kernels`` (the C ABI) in forward AND backward; frozen weights
+only ever get a dgrad (no wgrad is computed for the 860 M UNet parameters), adapter / hint-encoder
+parameters get fp32 gradients.  Activations are fp16, tokens x channels ([M, C], NHWC for images).
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import kernels as K
+
+f16, f32 = torch.float16, torch.float32
+
+
+# ------------------------------------------------------------------------------------------------ packs
+class LinearPack:
+    """Frozen Linear / 1x1-conv weight prepared for the kernels: W [N,K] (forward, K-contiguous),
+    Wt [K,N] (dgrad presented as a second K-contiguous operand), bias fp32."""
+
+    def __init__(self, weight: torch.Tensor, bias: Optional[torch.Tensor], pad_n_to: int = 8):
+        w = weight.detach().reshape(weight.shape[0], -1).to(f16)
+        N, Kd = w.shape
+        Np = (N + pad_n_to - 1) // pad_n_to * pad_n_to
+        if Np != N:
+            w = torch.cat([w, w.new_zeros(Np - N, Kd)], 0)
+        self.N, self.K, self.N_logical = Np, Kd, N
+        self.w = w.contiguous()
+        self.wt = w.t().contiguous()
+        self.bias = None
+        if bias is not None:
+            b = bias.detach().to(f32)
+            self.bias = torch.cat([b, b.new_zeros(Np - N)]) if Np != N else b.contiguous()
+
+
+class ConvPack:
+    """Frozen 3x3 conv: forward operand [Co, 9*Ci] in (ky,kx,ci) order, dgrad operand [Ci, 9*Co] in
+    (ky,kx,co) order (the gather descriptor walks the taps with kmul = -1, so no flip is needed)."""
+
+    def __init__(self, weight: torch.Tensor, bias: Optional[torch.Tensor], stride=1, pad=1, upsample=False,
+                 asym_pad=False, need_dgrad=True):
+        w = weight.detach().to(f16)
+        Co, Ci, kh, kw = w.shape
+        assert kh == 3 and kw == 3
+        Cip, Cop = (Ci + 7) // 8 * 8, (Co + 7) // 8 * 8
+        wp = w.new_zeros(Cop, 3, 3, Cip)
+        wp[:Co, :, :, :Ci] = w.permute(0, 2, 3, 1)
+        self.Ci, self.Co, self.Cip, self.Cop = Ci, Co, Cip, Cop
+        self.w = wp.reshape(Cop, 9 * Cip).contiguous()
+        self.wd = None
+        if need_dgrad:
+            wd = w.new_zeros(Cip, 3, 3, Cop)
+            wd[:Ci, :, :, :Co] = w.permute(1, 2, 3, 0)
+            self.wd = wd.reshape(Cip, 9 * Cop).contiguous()
+        self.bias = None
+        if bias is not None:
+            b = bias.detach().to(f32)
+            self.bias = torch.cat([b, b.new_zeros(Cop - Co)]) if Cop != Co else b.contiguous()
+        self.stride, self.pad, self.upsample, self.asym_pad = stride, pad, upsample, asym_pad
+
+
+# ------------------------------------------------------------------------------------------------ frozen layers
+class _FrozenLinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, pack: LinearPack, residual, rowadd, rows_per_batch):
+        M = x.shape[0]
+        y = K.gemm(x, pack.w, M, pack.N, pack.K, bias=pack.bias, residual=residual, rowadd=rowadd,
+                   rows_per_batch=rows_per_batch)
+        ctx.pack, ctx.has_res = pack, residual is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        p = ctx.pack
+        dx = K.gemm(dy, p.wt, dy.shape[0], p.K, p.N) if ctx.needs_input_grad[0] else None
+        return dx, None, (dy if ctx.has_res and ctx.needs_input_grad[2] else None), None, None
+
+
+def frozen_linear(x, pack: LinearPack, residual=None, rowadd=None, rows_per_batch=0):
+    """y = x W^T + b (+ rowadd[batch]) (+ residual); x [M,K] fp16."""
+    return _FrozenLinearFn.apply(x, pack, residual, rowadd, rows_per_batch)
+
+
+class _FrozenConvFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, pack: ConvPack, B, H, W, residual, rowadd):
+        cd, Ho, Wo = K.conv_fwd_desc(H, W, pack.Cip, 3, pack.stride, pack.pad, pack.upsample, pack.asym_pad)
+        M = B * Ho * Wo
+        y = K.gemm(x, pack.w, M, pack.Cop, 9 * pack.Cip, conv=cd, bias=pack.bias, residual=residual, rowadd=rowadd,
+                   rows_per_batch=Ho * Wo)
+        ctx.pack, ctx.dims, ctx.has_res = pack, (B, H, W, Ho, Wo), residual is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        p = ctx.pack
+        B, H, W, Ho, Wo = ctx.dims
+        dx = None
+        if ctx.needs_input_grad[0]:
+            Hi, Wi = (2 * H, 2 * W) if p.upsample else (H, W)
+            cdd = K.conv_dgrad_desc(Ho, Wo, p.Cop, Hi, Wi, 3, p.stride, p.pad, p.asym_pad)
+            dx = K.gemm(dy, p.wd, B * Hi * Wi, p.Cip, 9 * p.Cop, conv=cdd)
+            if p.upsample:
+                dx = K.pool2x2_sum(dx, B, H, W, p.Cip).reshape(B * H * W, p.Cip)
+        return dx, None, None, None, None, (dy if ctx.has_res and ctx.needs_input_grad[5] else None), None
+
+
+def frozen_conv3x3(x, pack: ConvPack, B, H, W, residual=None, rowadd=None):
+    """x [B*H*W, Cip] NHWC -> [B*Ho*Wo, Cop]."""
+    return _FrozenConvFn.apply(x, pack, B, H, W, residual, rowadd)
+
+
+# ------------------------------------------------------------------------------------------------ norms / activations
+class _GroupNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, G, eps, silu):
+        y, stats = K.groupnorm_fwd(x, gamma, beta, G, eps, silu)
+        ctx.save_for_backward(x, gamma, beta, stats)
+        ctx.cfg = (G, silu)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta, stats = ctx.saved_tensors
+        G, silu = ctx.cfg
+        train = ctx.needs_input_grad[1]
+        dx, dg, db = K.groupnorm_bwd(x, dy.contiguous(), gamma, beta, stats, G, silu, want_param_grads=train)
+        return dx, dg, db, None, None, None
+
+
+def group_norm(x, gamma, beta, G, eps, silu):
+    """x [B, HW, C] fp16, gamma/beta fp32 (frozen buffers or trainable parameters)."""
+    return _GroupNormFn.apply(x, gamma, beta, G, eps, silu)
+
+
+class _LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        ctx.save_for_backward(x, gamma)
+        ctx.eps = eps
+        return K.layernorm_fwd(x, gamma, beta, eps)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma = ctx.saved_tensors
+        return K.layernorm_bwd(x, dy.contiguous(), gamma, ctx.eps), None, None, None
+
+
+def layer_norm(x, gamma, beta, eps=1e-5):
+    return _LayerNormFn.apply(x, gamma, beta, eps)
+
+
+class _GegluFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, h):
+        ctx.save_for_backward(h)
+        return K.geglu_fwd(h)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (h,) = ctx.saved_tensors
+        return K.geglu_bwd(h, dy.contiguous())
+
+
+def geglu(h):
+    return _GegluFn.apply(h)
+
+
+class _AddFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        return K.add(a, b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, dy
+
+
+def add(a, b):
+    return _AddFn.apply(a, b)
+
+
+class _ConcatFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        ctx.ca = a.shape[-1]
+        return K.concat_channels(a, b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return K.split_channels(dy.contiguous(), ctx.ca)
+
+
+def concat_channels(a, b):
+    return _ConcatFn.apply(a, b)
+
+
+# ------------------------------------------------------------------------------------------------ attention
+class _AttnSelfFn(torch.autograd.Function):
+    """qkv: [B*N, 3*H*D] (q | k | v column blocks, as written by the fused projection)."""
+
+    @staticmethod
+    def forward(ctx, qkv, B, H, N, D, scale):
+        C_ = H * D
+        o, lse = K.attn_fwd(qkv[:, :C_], qkv[:, C_:2 * C_], qkv[:, 2 * C_:], B, H, N, N, D, scale)
+        ctx.save_for_backward(qkv, o, lse)
+        ctx.cfg = (B, H, N, D, scale)
+        return o
+
+    @staticmethod
+    def backward(ctx, dO):
+        qkv, o, lse = ctx.saved_tensors
+        B, H, N, D, scale = ctx.cfg
+        C_ = H * D
+        d = torch.empty_like(qkv)
+        K.attn_bwd(qkv[:, :C_], qkv[:, C_:2 * C_], qkv[:, 2 * C_:], o, dO.contiguous(), lse, B, H, N, N, D, scale,
+                   d[:, :C_], d[:, C_:2 * C_], d[:, 2 * C_:])
+        return d, None, None, None, None, None
+
+
+class _AttnCrossFn(torch.autograd.Function):
+    """q: [B*N, H*D]; kv: [B*Nk, 2*H*D] (k | v)."""
+
+    @staticmethod
+    def forward(ctx, q, kv, B, H, N, Nk, D, scale):
+        C_ = H * D
+        o, lse = K.attn_fwd(q, kv[:, :C_], kv[:, C_:], B, H, N, Nk, D, scale)
+        ctx.save_for_backward(q, kv, o, lse)
+        ctx.cfg = (B, H, N, Nk, D, scale)
+        return o
+
+    @staticmethod
+    def backward(ctx, dO):
+        q, kv, o, lse = ctx.saved_tensors
+        B, H, N, Nk, D, scale = ctx.cfg
+        C_ = H * D
+        dq, dkv = torch.empty_like(q), torch.empty_like(kv)
+        K.attn_bwd(q, kv[:, :C_], kv[:, C_:], o, dO.contiguous(), lse, B, H, N, Nk, D, scale, dq, dkv[:, :C_], dkv[:, C_:])
+        return dq, dkv, None, None, None, None, None, None
+
+
+def attention_self(qkv, B, H, N, D, scale):
+    return _AttnSelfFn.apply(qkv, B, H, N, D, scale)
+
+
+def attention_cross(q, kv, B, H, N, Nk, D, scale):
+    return _AttnCrossFn.apply(q, kv, B, H, N, Nk, D, scale)
+
+
+# ------------------------------------------------------------------------------------------------ adapters
+class _LoraProjFn(torch.autograd.Function):
+    """y = x W^T (+b) (+residual) + scale_s * up_s(down_s(xa_s)) on column segment s.
+
+    One frozen GEMM over x with the rank-r updates applied in its epilogue.
+    ``segs[s]`` is None (no adapter on that segment) or (xa_index, scale) where xa_index selects the adapter
+    input among ``xas`` (0 = x itself).  Tensor arguments are flattened as
+    (x, residual, *xas[1:], D_0, U_0, D_1, U_1, ...) for autograd."""
+
+    @staticmethod
+    def forward(ctx, pack: LinearPack, segs, n_xa, x, residual, *rest):
+        xas = [x] + list(rest[:n_xa - 1])
+        params = rest[n_xa - 1:]
+        S = len(segs)
+        seg_w = pack.N // S
+        M = x.shape[0]
+        r = max([params[2 * i].shape[0] for i in range(len(params) // 2)] + [1])
+        T = torch.zeros((M, S * r), dtype=f32, device=x.device)
+        U = torch.zeros((pack.N, r), dtype=f32, device=x.device)
+        pi = 0
+        meta = []
+        for s, sg in enumerate(segs):
+            if sg is None:
+                meta.append(None)
+                continue
+            xi, sc = sg
+            D, Uw = params[2 * pi], params[2 * pi + 1]
+            pi += 1
+            rs = D.shape[0]
+            K.lora_down(xas[xi], D, T, s * r, M, D.shape[1])
+            U[s * seg_w:(s + 1) * seg_w, :rs] = Uw * sc
+            meta.append((xi, sc, rs))
+        y = K.gemm(x, pack.w, M, pack.N, pack.K, bias=pack.bias, residual=residual, lora_t=T, lora_u=U,
+                   lora_seg=seg_w, lora_scale=1.0)
+        ctx.pack, ctx.meta, ctx.n_xa, ctx.r, ctx.has_res = pack, meta, n_xa, r, residual is not None
+        ctx.save_for_backward(T, *xas, *params)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        pack, meta, n_xa, r = ctx.pack, ctx.meta, ctx.n_xa, ctx.r
+        saved = ctx.saved_tensors
+        T, xas, params = saved[0], saved[1:1 + n_xa], saved[1 + n_xa:]
+        S = len(meta)
+        seg_w = pack.N // S
+        M = dy.shape[0]
+        dev = dy.device
+        dT = torch.zeros((M, S * r), dtype=f32, device=dev)
+        # rank-r part of dx for adapters fed by x itself goes into the dgrad GEMM epilogue
+        Dx = torch.zeros((pack.K, S * r), dtype=f32, device=dev)
+        grads_params: List[Optional[torch.Tensor]] = []
+        d_xas: List[Optional[torch.Tensor]] = [None] * n_xa
+        pi = 0
+        for s, m in enumerate(meta):
+            if m is None:
+                continue
+            xi, sc, rs = m
+            D, Uw = params[2 * pi], params[2 * pi + 1]
+            pi += 1
+            dys = dy[:, s * seg_w:(s + 1) * seg_w]
+            # dT_s = sc * dy_s . U_s   (a "down" projection of dy with U^T as the matrix)
+            K.lora_down(dys, (Uw * sc).t().contiguous(), dT, s * r, M, seg_w, ldx=pack.N)
+            dU = torch.zeros_like(Uw)
+            K.lora_wgrad(dys, T, s * r, dU, Uw.shape[1], 1, M, seg_w, rs, scale=sc, lda=pack.N)
+            dD = torch.zeros_like(D)
+            K.lora_wgrad(xas[xi], dT, s * r, dD, 1, D.shape[1], M, D.shape[1], rs, scale=1.0)
+            grads_params += [dD, dU]
+            if xi == 0:
+                Dx[:, s * r:s * r + rs] = D.t()
+            elif ctx.needs_input_grad[4 + xi]:
+                g = K.lora_up(None, dT, s * r, D.t().contiguous(), M, D.shape[1], 1.0)
+                d_xas[xi] = g if d_xas[xi] is None else K.add(d_xas[xi], g)
+        dx = None
+        if ctx.needs_input_grad[3]:
+            dx = K.gemm(dy, pack.wt, M, pack.K, pack.N, lora_t=dT, lora_u=Dx, lora_seg=pack.K, lora_scale=1.0)
+        dres = dy if ctx.has_res and ctx.needs_input_grad[4] else None
+        return (None, None, None, dx, dres, *d_xas[1:], *grads_params)
+
+
+def lora_proj(x, pack: LinearPack, segs: Sequence[Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor, float]]],
+              residual=None):
+    """segs[s] = None or (xa, down_weight [r,K], up_weight [seg,r], scale)."""
+    xas = [x]
+    meta, params = [], []
+    for sg in segs:
+        if sg is None:
+            meta.append(None)
+            continue
+        xa, D, U, sc = sg
+        idx = next((i for i, t in enumerate(xas) if t is xa), None)
+        if idx is None:
+            xas.append(xa)
+            idx = len(xas) - 1
+        meta.append((idx, float(sc)))
+        params += [D, U]
+    return _LoraProjFn.apply(pack, tuple(meta), len(xas), x, residual, *xas[1:], *params)
+
+
+class _ControlAddFn(torch.autograd.Function):
+    """y = h + fp16(scale * fp16(up(down(ctrl))))            (v1, reference models.py:214-218, 237-238)
+       y = h + fp16(scale * fp16(up(down(cat(h, ctrl)))))    (concat_hidden / V2, models.py:209-214, 343-349)
+    ctrl [Mc, Cc] may hold fewer batch elements than h (control batch 1 broadcast, quirk C6)."""
+
+    @staticmethod
+    def forward(ctx, h, ctrl, D, U, scale, concat):
+        M, C_ = h.shape
+        Mc, Cc = ctrl.shape
+        R = D.shape[0]
+        T = torch.empty((M, R), dtype=f32, device=h.device)
+        xr = Mc if Mc != M else 0
+        if concat:
+            K.lora_down(h, D, T, 0, M, C_)                          # D[:, :C] acts on h (row pitch ldd = C + Cc)
+            K.lora_down(ctrl, D[:, C_:], T, 0, M, Cc, accumulate=True, x_rows=xr)
+        else:
+            K.lora_down(ctrl, D, T, 0, M, Cc, x_rows=xr)
+        y = K.lora_up(h, T, 0, U, M, C_, scale)
+        ctx.save_for_backward(h, ctrl, D, U, T)
+        ctx.cfg = (scale, concat, xr)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        h, ctrl, D, U, T = ctx.saved_tensors
+        scale, concat, xr = ctx.cfg
+        M, C_ = h.shape
+        Mc, Cc = ctrl.shape
+        R = D.shape[0]
+        dT = torch.empty((M, R), dtype=f32, device=dy.device)
+        K.lora_down(dy, (U * scale).t().contiguous(), dT, 0, M, C_)
+        dU = torch.zeros_like(U)
+        K.lora_wgrad(dy, T, 0, dU, R, 1, M, C_, R, scale=scale)
+        dD = torch.zeros_like(D)
+        dh = dy
+        dctrl = None
+        if concat:
+            K.lora_wgrad(h, dT, 0, dD, 1, D.shape[1], M, C_, R)
+            K.lora_wgrad(ctrl, dT, 0, dD[:, C_:], 1, D.shape[1], M, Cc, R, a_rows=xr)
+            dh = K.lora_up(dy, dT, 0, D[:, :C_].t().contiguous(), M, C_, 1.0)
+            Dc_t = D[:, C_:].t().contiguous()
+        else:
+            K.lora_wgrad(ctrl, dT, 0, dD, 1, D.shape[1], M, Cc, R, a_rows=xr)
+            Dc_t = D.t().contiguous()
+        if ctx.needs_input_grad[1]:
+            dctrl = K.lora_up(None, dT, 0, Dc_t, M, Cc, 1.0)
+            if xr:
+                dctrl = dctrl.reshape(M // Mc, Mc, Cc).float().sum(0).to(f16)
+        return dh, dctrl, dD, dU, None, None
+
+
+def control_add(h, ctrl, D, U, scale, concat):
+    return _ControlAddFn.apply(h, ctrl, D, U, float(scale), bool(concat))
+
+
+# ------------------------------------------------------------------------------------------------ trainable conv (hint encoder)
+class _TrainConvFn(torch.autograd.Function):
+    """Conv2d of the trainable hint encoder (reference models.py:470, 529, 594-597, 684): fp32 master
+    weight, fp16 compute (what accelerate's autocast does around control_lora.forward)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, B, H, W, stride, asym_pad, need_dx):
+        Co, Ci, k, _ = weight.shape
+        Cip = x.shape[1]
+        if k == 3:
+            wp = torch.zeros((Co, 3, 3, Cip), dtype=f16, device=x.device)
+            wp[:, :, :, :Ci] = weight.detach().permute(0, 2, 3, 1)
+            cd, Ho, Wo = K.conv_fwd_desc(H, W, Cip, 3, stride, 0 if asym_pad else 1, False, asym_pad)
+            y = K.gemm(x, wp.reshape(Co, 9 * Cip), B * Ho * Wo, Co, 9 * Cip, conv=cd, bias=bias.detach())
+        else:
+            wp = weight.detach().reshape(Co, Ci).to(f16)
+            cd, Ho, Wo = None, H, W
+            y = K.gemm(x, wp, B * H * W, Co, Ci, bias=bias.detach())
+        ctx.save_for_backward(x, weight)
+        ctx.cfg = (B, H, W, Ho, Wo, stride, asym_pad, need_dx, cd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        x, weight = ctx.saved_tensors
+        B, H, W, Ho, Wo, stride, asym_pad, need_dx, cd = ctx.cfg
+        Co, Ci, k, _ = weight.shape
+        Cip = x.shape[1]
+        M = B * Ho * Wo
+        dx = None
+        if k == 3:
+            if need_dx:
+                wd = torch.zeros((Cip, 3, 3, Co), dtype=f16, device=x.device)
+                wd[:Ci] = weight.detach().permute(1, 2, 3, 0)
+                cdd = K.conv_dgrad_desc(Ho, Wo, Co, H, W, 3, stride, 1, asym_pad)
+                dx = K.gemm(dy, wd.reshape(Cip, 9 * Co), B * H * W, Cip, 9 * Co, conv=cdd)
+            dWp = K.conv_wgrad(dy, x, M, Co, 9 * Cip, cd)
+            dW = dWp.reshape(Co, 3, 3, Cip)[:, :, :, :Ci].permute(0, 3, 1, 2).contiguous()
+        else:
+            if need_dx:
+                dx = K.gemm(dy, weight.detach().reshape(Co, Ci).t().contiguous().to(f16), M, Ci, Co)
+            dW = K.conv_wgrad(dy, x, M, Co, Ci, None).reshape(Co, Ci, 1, 1)
+        db = K.colsum(dy, M, Co)
+        return dx, dW, db, None, None, None, None, None, None
+
+
+def train_conv(x, weight, bias, B, H, W, stride=1, asym_pad=False, need_dx=True):
+    """x [B*H*W, Cip] fp16 NHWC (Cip = channels padded to 8), weight [Co,Ci,k,k] fp32 parameter."""
+    return _TrainConvFn.apply(x, weight, bias, B, H, W, stride, asym_pad, need_dx)

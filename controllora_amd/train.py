@@ -1,0 +1,102 @@
+"""The training step of the path (reference train_text_to_image_control_lora.py:751-796), device resident:
+
+  hint-encode guide -> UNet(noisy latents) -> fp32 MSE -> scaled backward (dgrad through the frozen UNet,
+  wgrad only for adapters + hint encoder) -> [RCCL all-reduce of ONE flat fp32 gradient buffer] ->
+  fused unscale + clip_grad_norm_(1.0) + AdamW (+ GradScaler skip / growth) over ONE flat parameter buffer.
+
+No host synchronisation happens inside a step (loss and grad-norm stay on the device until asked for).
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+import torch.nn as nn
+
+from . import kernels as K
+
+f16, f32 = torch.float16, torch.float32
+
+
+class FlatParams:
+    """Re-homes every trainable parameter (and its .grad) as a view into one contiguous fp32 buffer, so the
+    optimizer is one kernel and data parallelism is one all-reduce (24.19 MB for v1)."""
+
+    def __init__(self, module: nn.Module):
+        params = [p for p in module.parameters() if p.requires_grad]
+        assert params and all(p.dtype == f32 for p in params)
+        dev = params[0].device
+        n = sum(p.numel() for p in params)
+        self.numel = n
+        self.data = torch.empty(n, dtype=f32, device=dev)
+        self.grad = torch.zeros(n, dtype=f32, device=dev)
+        self.exp_avg = torch.zeros(n, dtype=f32, device=dev)
+        self.exp_avg_sq = torch.zeros(n, dtype=f32, device=dev)
+        off = 0
+        self.params = params
+        with torch.no_grad():
+            for p in params:
+                k = p.numel()
+                self.data[off:off + k].copy_(p.reshape(-1))
+                p.data = self.data[off:off + k].view_as(p)
+                p.grad = self.grad[off:off + k].view_as(p)
+                off += k
+
+    def zero_grad(self):
+        self.grad.zero_()
+
+
+class ControlLoRATrainer:
+    def __init__(self, unet, control_lora, lr=1e-4, betas=(0.9, 0.999), weight_decay=1e-2, eps=1e-8, max_grad_norm=1.0,
+                 init_scale=65536.0, dynamic_scale=True, growth_interval=2000, process_group=None, world_size=1):
+        self.unet, self.control_lora = unet, control_lora
+        trainable = {id(p) for p in control_lora.parameters()}
+        for p in unet.parameters():          # the installed processors are sub-modules of the UNet too: keep them trainable
+            if id(p) not in trainable:
+                p.requires_grad_(False)
+        self.flat = FlatParams(control_lora)
+        dev = self.flat.data.device
+        self.hp = dict(lr=lr, beta1=betas[0], beta2=betas[1], wd=weight_decay, eps=eps, max_norm=max_grad_norm,
+                       dynamic=dynamic_scale, interval=growth_interval)
+        self.state = torch.zeros(16, dtype=f32, device=dev)
+        self.state[3] = init_scale
+        self.loss_sum = torch.zeros(1, dtype=f32, device=dev)
+        self.pg, self.world = process_group, world_size
+        if world_size > 1:
+            torch.distributed.broadcast(self.flat.data, src=0, group=process_group)   # identical adapter init
+
+    # -- pieces (kept separate so tests can check each against the oracle)
+    def forward_backward(self, noisy_latents, timesteps, encoder_hidden_states, guide, target):
+        self.flat.zero_grad()
+        self.loss_sum.zero_()
+        self.control_lora(guide)                                    # injects control states into the 32 processors
+        pred = self.unet(noisy_latents, timesteps, encoder_hidden_states).sample
+        pred_c = pred.contiguous()
+        dpred = torch.empty_like(pred_c)
+        n = pred_c.numel()
+        K.mse(pred_c, target.to(f16).contiguous(), self.loss_sum, dpred, 2.0 / n, self.state[3:4])
+        pred_c.backward(dpred)
+        return pred
+
+    def optimizer_step(self):
+        g = self.flat.grad
+        if self.world > 1:
+            torch.distributed.all_reduce(g, group=self.pg)           # RCCL over xGMI: one flat 24 MB buffer
+            g.mul_(1.0 / self.world)
+        K.grad_sumsq(g, self.state)
+        K.optim_prep(self.state, self.hp["max_norm"], self.hp["beta1"], self.hp["beta2"], self.hp["dynamic"], 2.0, 0.5,
+                     self.hp["interval"])
+        K.adamw_flat(self.flat.data, g, self.flat.exp_avg, self.flat.exp_avg_sq, self.state, self.hp["lr"], self.hp["beta1"],
+                     self.hp["beta2"], self.hp["eps"], self.hp["wd"])
+
+    def step(self, noisy_latents, timesteps, encoder_hidden_states, guide, target):
+        pred = self.forward_backward(noisy_latents, timesteps, encoder_hidden_states, guide, target)
+        self.optimizer_step()
+        return pred
+
+    # -- host-visible scalars (each forces a sync; call outside the timed region)
+    def loss(self, numel) -> float:
+        return float(self.loss_sum) / numel
+
+    def unscaled_grads(self) -> torch.Tensor:
+        return self.flat.grad / self.state[3]

@@ -1,0 +1,495 @@
+"""Host-side SD-1.5 ``UNet2DConditionModel`` for the MI355X path.
+
+Mirrors the module tree / state-dict keys / attention-processor protocol of the diffusers UNet the
+reference loads (``train_text_to_image_control_lora.py:407-409``), so diffusers
+format checkpoints load unchanged and ``unet.set_attn_processor({...})`` works exactly like upstream --
+but the forward/backward runs on the hand-written gfx950 kernels (``controllora_amd.ops``):
+
+* activations are fp16 NHWC ("tokens x channels") end to end: the NCHW<->token permutes of
+  Transformer2DModel and head_to_batch_dim disappear, 3x3 convs are implicit GEMMs;
+* weights are frozen fp16; each layer keeps a K-contiguous packed copy for the forward GEMM and a
+  second one for the dgrad GEMM (no wgrad is ever computed for the 860 M frozen parameters);
+* GroupNorm+SiLU, bias, time-embedding add, residual adds and the rank-r adapter updates are fused
+  into the producing kernels' epilogues.
+"""
+from __future__ import annotations
+
+import math
+from types import SimpleNamespace
+from typing import Dict, Optional
+
+import torch
+import torch.nn as nn
+
+from . import kernels as K
+from . import ops
+
+f16, f32 = torch.float16, torch.float32
+
+SD15_CONFIG = dict(
+    in_channels=4, out_channels=4, block_out_channels=(320, 640, 1280, 1280), layers_per_block=2,
+    down_block_types=("CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "DownBlock2D"),
+    up_block_types=("UpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D"),
+    attention_head_dim=8, cross_attention_dim=768, norm_num_groups=32, norm_eps=1e-5)
+
+
+def _frozen(t: torch.Tensor) -> nn.Parameter:
+    return nn.Parameter(t, requires_grad=False)
+
+
+class _Packed(nn.Module):
+    """A frozen layer whose kernel-ready operands are built lazily and rebuilt if the weights change."""
+
+    def __init__(self):
+        super().__init__()
+        self._pack = None
+        self._pack_key = None
+
+    def _key(self):
+        return tuple((p.data_ptr(), p._version, str(p.device)) for p in self.parameters(recurse=False))
+
+    def pack(self):
+        k = self._key()
+        if self._pack is None or self._pack_key != k:
+            self._pack, self._pack_key = self._build(), k
+        return self._pack
+
+
+class Conv3x3(_Packed):
+    def __init__(self, cin, cout, stride=1, pad=1, upsample=False, need_dgrad=True):
+        super().__init__()
+        self.weight = _frozen(torch.empty(cout, cin, 3, 3, dtype=f16))
+        self.bias = _frozen(torch.empty(cout, dtype=f16))
+        self.cfg = dict(stride=stride, pad=pad, upsample=upsample, need_dgrad=need_dgrad)
+
+    def _build(self):
+        return ops.ConvPack(self.weight, self.bias, **self.cfg)
+
+    def forward(self, x, B, H, W, residual=None, rowadd=None):
+        return ops.frozen_conv3x3(x, self.pack(), B, H, W, residual, rowadd)
+
+
+class Conv1x1(_Packed):
+    """state-dict layout of a Conv2d(k=1) ([Co,Ci,1,1]); runs as a plain GEMM on NHWC tokens."""
+
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.weight = _frozen(torch.empty(cout, cin, 1, 1, dtype=f16))
+        self.bias = _frozen(torch.empty(cout, dtype=f16))
+
+    def _build(self):
+        return ops.LinearPack(self.weight, self.bias)
+
+    def forward(self, x, residual=None):
+        return ops.frozen_linear(x, self.pack(), residual)
+
+
+class Linear(_Packed):
+    def __init__(self, cin, cout, bias=True):
+        super().__init__()
+        self.weight = _frozen(torch.empty(cout, cin, dtype=f16))
+        self.bias = _frozen(torch.empty(cout, dtype=f16)) if bias else None
+
+    def _build(self):
+        return ops.LinearPack(self.weight, self.bias)
+
+    def forward(self, x, residual=None):
+        return ops.frozen_linear(x, self.pack(), residual)
+
+
+class _Norm(_Packed):
+    def __init__(self, c):
+        super().__init__()
+        self.weight = _frozen(torch.empty(c, dtype=f16))
+        self.bias = _frozen(torch.empty(c, dtype=f16))
+
+    def _build(self):
+        return self.weight.detach().to(f32).contiguous(), self.bias.detach().to(f32).contiguous()
+
+
+class GroupNorm(_Norm):
+    def __init__(self, groups, c, eps):
+        super().__init__(c)
+        self.groups, self.eps = groups, eps
+
+    def forward(self, x, silu):
+        g, b = self.pack()
+        return ops.group_norm(x, g, b, self.groups, self.eps, silu)
+
+
+class LayerNorm(_Norm):
+    def forward(self, x):
+        g, b = self.pack()
+        return ops.layer_norm(x, g, b, 1e-5)
+
+
+# ------------------------------------------------------------------------------------------------ attention
+class CrossAttnProcessor:
+    """Plain attention without adapters (what a bare UNet runs)."""
+
+    def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, residual=None):
+        return attn.plain_attention(hidden_states, encoder_hidden_states, residual)
+
+
+class CrossAttention(nn.Module):
+    """Same attribute surface the reference processors use: to_q/to_k/to_v/to_out,
+    heads, scale, processor, set_processor -- plus packed fused operands for the kernels."""
+
+    def __init__(self, query_dim, cross_attention_dim=None, heads=8, dim_head=64):
+        super().__init__()
+        inner = heads * dim_head
+        self.is_cross = cross_attention_dim is not None
+        ctx = cross_attention_dim if cross_attention_dim is not None else query_dim
+        self.heads, self.dim_head, self.scale, self.inner_dim, self.query_dim = heads, dim_head, dim_head ** -0.5, inner, query_dim
+        self.to_q = Linear(query_dim, inner, bias=False)
+        self.to_k = Linear(ctx, inner, bias=False)
+        self.to_v = Linear(ctx, inner, bias=False)
+        self.to_out = nn.ModuleList([Linear(inner, query_dim), nn.Dropout(0.0)])
+        self.processor = CrossAttnProcessor()
+        self._fused = None
+        self._fused_key = None
+
+    def set_processor(self, processor):
+        if isinstance(getattr(self, "processor", None), nn.Module) and not isinstance(processor, nn.Module):
+            self._modules.pop("processor")
+        self.processor = processor
+
+    def prepare_attention_mask(self, attention_mask, target_length, batch_size=None):
+        if attention_mask is not None:
+            raise NotImplementedError("attention masks are never used on this path (SURVEY.md A2)")
+        return None
+
+    def fused_packs(self):
+        """self-attn: one [3C, C] operand for q|k|v; cross-attn: [C, C] for q and [2C, ctx] for k|v."""
+        key = tuple((m.weight.data_ptr(), m.weight._version) for m in (self.to_q, self.to_k, self.to_v))
+        if self._fused is None or self._fused_key != key:
+            if self.is_cross:
+                self._fused = (ops.LinearPack(self.to_q.weight, None),
+                               ops.LinearPack(torch.cat([self.to_k.weight, self.to_v.weight], 0), None))
+            else:
+                self._fused = (ops.LinearPack(torch.cat([self.to_q.weight, self.to_k.weight, self.to_v.weight], 0), None),)
+            self._fused_key = key
+        return self._fused
+
+    def forward(self, hidden_states, encoder_hidden_states=None, attention_mask=None, residual=None, **kw):
+        if residual is not None and getattr(self.processor, "fuses_residual", True) is False:
+            out = self.processor(self, hidden_states, encoder_hidden_states=encoder_hidden_states,
+                                 attention_mask=attention_mask, **kw)
+            return ops.add(out.reshape(residual.shape), residual)
+        return self.processor(self, hidden_states, encoder_hidden_states=encoder_hidden_states,
+                              attention_mask=attention_mask, residual=residual, **kw)
+
+    def attend(self, q_or_qkv, kv, B, N, Nk):
+        if kv is None:
+            return ops.attention_self(q_or_qkv, B, self.heads, N, self.dim_head, self.scale)
+        return ops.attention_cross(q_or_qkv, kv, B, self.heads, N, Nk, self.dim_head, self.scale)
+
+    def plain_attention(self, hidden_states, encoder_hidden_states=None, residual=None):
+        B, N, C_ = hidden_states.shape
+        h2 = hidden_states.reshape(B * N, C_)
+        packs = self.fused_packs()
+        if self.is_cross:
+            e2 = encoder_hidden_states.reshape(-1, encoder_hidden_states.shape[-1])
+            q = ops.frozen_linear(h2, packs[0])
+            kv = ops.frozen_linear(e2, packs[1])
+            a = self.attend(q, kv, B, N, encoder_hidden_states.shape[1])
+        else:
+            a = self.attend(ops.frozen_linear(h2, packs[0]), None, B, N, N)
+        res2 = residual.reshape(B * N, C_) if residual is not None else None
+        return self.to_out[0](a, res2).reshape(B, N, C_)
+
+
+class GEGLU(nn.Module):
+    def __init__(self, dim_in, dim_out):
+        super().__init__()
+        self.proj = Linear(dim_in, dim_out * 2)
+
+
+class FeedForward(nn.Module):
+    def __init__(self, dim, mult=4):
+        super().__init__()
+        self.net = nn.ModuleList([GEGLU(dim, dim * mult), nn.Dropout(0.0), Linear(dim * mult, dim)])
+
+    def forward(self, x, residual):
+        return self.net[2](ops.geglu(self.net[0].proj(x)), residual)
+
+
+class BasicTransformerBlock(nn.Module):
+    def __init__(self, dim, heads, dim_head, cross_attention_dim):
+        super().__init__()
+        self.attn1 = CrossAttention(dim, None, heads, dim_head)
+        self.ff = FeedForward(dim)
+        self.attn2 = CrossAttention(dim, cross_attention_dim, heads, dim_head)
+        self.norm1, self.norm2, self.norm3 = LayerNorm(dim), LayerNorm(dim), LayerNorm(dim)
+
+    def forward(self, x, ehs, kw):
+        B, N, C_ = x.shape
+        x = self.attn1(self.norm1(x), residual=x, **kw)
+        x = self.attn2(self.norm2(x), encoder_hidden_states=ehs, residual=x, **kw)
+        x2 = x.reshape(B * N, C_)
+        return self.ff(self.norm3(x).reshape(B * N, C_), x2).reshape(B, N, C_)
+
+
+class Transformer2DModel(nn.Module):
+    def __init__(self, heads, dim_head, in_channels, cross_attention_dim, groups):
+        super().__init__()
+        inner = heads * dim_head
+        self.norm = GroupNorm(groups, in_channels, 1e-6)
+        self.proj_in = Conv1x1(in_channels, inner)
+        self.transformer_blocks = nn.ModuleList([BasicTransformerBlock(inner, heads, dim_head, cross_attention_dim)])
+        self.proj_out = Conv1x1(inner, in_channels)
+
+    def forward(self, x, ehs, kw):
+        B, N, C_ = x.shape
+        h = self.proj_in(self.norm(x, False).reshape(B * N, C_)).reshape(B, N, -1)
+        for blk in self.transformer_blocks:
+            h = blk(h, ehs, kw)
+        return self.proj_out(h.reshape(B * N, -1), x.reshape(B * N, C_)).reshape(B, N, C_)
+
+
+# ------------------------------------------------------------------------------------------------ resnet / samplers
+class ResnetBlock2D(nn.Module):
+    def __init__(self, cin, cout, temb_c, groups, eps):
+        super().__init__()
+        self.norm1 = GroupNorm(groups, cin, eps)
+        self.conv1 = Conv3x3(cin, cout)
+        self.time_emb_proj = Linear(temb_c, cout)
+        self.norm2 = GroupNorm(groups, cout, eps)
+        self.conv2 = Conv3x3(cout, cout)
+        self.conv_shortcut = Conv1x1(cin, cout) if cin != cout else None
+
+    def forward(self, x, temb_act, H, W):
+        B, N, Cin = x.shape
+        with torch.no_grad():  # the time embedding has no trainable ancestor
+            t = self.time_emb_proj(temb_act)
+        h = self.conv1(self.norm1(x, True).reshape(B * N, Cin), B, H, W, rowadd=t)
+        Cout = h.shape[1]
+        h = self.norm2(h.reshape(B, N, Cout), True).reshape(B * N, Cout)
+        x2 = x.reshape(B * N, Cin)
+        sc = self.conv_shortcut(x2) if self.conv_shortcut is not None else x2
+        return self.conv2(h, B, H, W, residual=sc).reshape(B, N, Cout)
+
+
+class Downsample2D(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.conv = Conv3x3(c, c, stride=2, pad=1)
+
+    def forward(self, x, H, W):
+        B, N, C_ = x.shape
+        return self.conv(x.reshape(B * N, C_), B, H, W).reshape(B, (H // 2) * (W // 2), C_)
+
+
+class Upsample2D(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.conv = Conv3x3(c, c, upsample=True)
+
+    def forward(self, x, H, W):
+        B, N, C_ = x.shape
+        return self.conv(x.reshape(B * N, C_), B, H, W).reshape(B, 4 * N, C_)
+
+
+class CrossAttnDownBlock2D(nn.Module):
+    has_attn = True
+
+    def __init__(self, cin, cout, temb_c, layers, heads, ctx, groups, eps, add_down):
+        super().__init__()
+        self.resnets = nn.ModuleList([ResnetBlock2D(cin if i == 0 else cout, cout, temb_c, groups, eps) for i in range(layers)])
+        self.attentions = nn.ModuleList([Transformer2DModel(heads, cout // heads, cout, ctx, groups) for _ in range(layers)])
+        self.downsamplers = nn.ModuleList([Downsample2D(cout)]) if add_down else None
+
+
+class DownBlock2D(nn.Module):
+    has_attn = False
+
+    def __init__(self, cin, cout, temb_c, layers, groups, eps, add_down):
+        super().__init__()
+        self.resnets = nn.ModuleList([ResnetBlock2D(cin if i == 0 else cout, cout, temb_c, groups, eps) for i in range(layers)])
+        self.downsamplers = nn.ModuleList([Downsample2D(cout)]) if add_down else None
+
+
+class UNetMidBlock2DCrossAttn(nn.Module):
+    def __init__(self, c, temb_c, heads, ctx, groups, eps):
+        super().__init__()
+        self.attentions = nn.ModuleList([Transformer2DModel(heads, c // heads, c, ctx, groups)])
+        self.resnets = nn.ModuleList([ResnetBlock2D(c, c, temb_c, groups, eps), ResnetBlock2D(c, c, temb_c, groups, eps)])
+
+
+class _UpBase(nn.Module):
+    def __init__(self, cin, prev, cout, temb_c, layers, groups, eps, add_up):
+        super().__init__()
+        rs = []
+        for i in range(layers):
+            skip = cin if i == layers - 1 else cout
+            rin = prev if i == 0 else cout
+            rs.append(ResnetBlock2D(rin + skip, cout, temb_c, groups, eps))
+        self.resnets = nn.ModuleList(rs)
+        self.upsamplers = nn.ModuleList([Upsample2D(cout)]) if add_up else None
+
+
+class UpBlock2D(_UpBase):
+    has_attn = False
+
+
+class CrossAttnUpBlock2D(_UpBase):
+    has_attn = True
+
+    def __init__(self, cin, prev, cout, temb_c, layers, heads, ctx, groups, eps, add_up):
+        super().__init__(cin, prev, cout, temb_c, layers, groups, eps, add_up)
+        self.attentions = nn.ModuleList([Transformer2DModel(heads, cout // heads, cout, ctx, groups) for _ in range(layers)])
+
+
+class TimestepEmbedding(nn.Module):
+    def __init__(self, cin, ct):
+        super().__init__()
+        self.linear_1, self.linear_2 = Linear(cin, ct), Linear(ct, ct)
+
+
+class UNetOutput:
+    def __init__(self, sample):
+        self.sample = sample
+
+
+class UNet2DConditionModel(nn.Module):
+    def __init__(self, **cfg):
+        super().__init__()
+        c = dict(SD15_CONFIG)
+        c.update(cfg)
+        self.config = SimpleNamespace(**c)
+        boc = tuple(c["block_out_channels"])
+        heads, ctx, groups, eps, layers = (c["attention_head_dim"], c["cross_attention_dim"], c["norm_num_groups"],
+                                           c["norm_eps"], c["layers_per_block"])
+        temb_c = boc[0] * 4
+        self.conv_in = Conv3x3(c["in_channels"], boc[0], need_dgrad=False)
+        self.time_embedding = TimestepEmbedding(boc[0], temb_c)
+        self.down_blocks = nn.ModuleList()
+        out_c = boc[0]
+        for i, t in enumerate(c["down_block_types"]):
+            in_c, out_c = out_c, boc[i]
+            last = i == len(boc) - 1
+            if t == "CrossAttnDownBlock2D":
+                self.down_blocks.append(CrossAttnDownBlock2D(in_c, out_c, temb_c, layers, heads, ctx, groups, eps, not last))
+            else:
+                self.down_blocks.append(DownBlock2D(in_c, out_c, temb_c, layers, groups, eps, not last))
+        self.mid_block = UNetMidBlock2DCrossAttn(boc[-1], temb_c, heads, ctx, groups, eps)
+        self.up_blocks = nn.ModuleList()
+        rev = list(reversed(boc))
+        out_c = rev[0]
+        for i, t in enumerate(c["up_block_types"]):
+            prev, out_c = out_c, rev[i]
+            in_c = rev[min(i + 1, len(boc) - 1)]
+            last = i == len(boc) - 1
+            if t == "CrossAttnUpBlock2D":
+                self.up_blocks.append(CrossAttnUpBlock2D(in_c, prev, out_c, temb_c, layers + 1, heads, ctx, groups, eps, not last))
+            else:
+                self.up_blocks.append(UpBlock2D(in_c, prev, out_c, temb_c, layers + 1, groups, eps, not last))
+        self.conv_norm_out = GroupNorm(groups, boc[0], eps)
+        self.conv_out = Conv3x3(boc[0], c["out_channels"])
+
+    # ---- attention-processor protocol (identical naming to upstream)
+    def _walk_attn(self, fn):
+        def walk(name, module):
+            if hasattr(module, "set_processor"):
+                fn(f"{name}.processor", module)
+            for sub, child in module.named_children():
+                if sub != "processor":
+                    walk(f"{name}.{sub}", child)
+        for name, module in self.named_children():
+            walk(name, module)
+
+    @property
+    def attn_processors(self) -> Dict[str, object]:
+        out = {}
+        self._walk_attn(lambda n, m: out.__setitem__(n, m.processor))
+        return out
+
+    def set_attn_processor(self, processor):
+        count = len(self.attn_processors)
+        if isinstance(processor, dict) and len(processor) != count:
+            raise ValueError(f"A dict of processors was passed, but the number of processors {len(processor)} does "
+                             f"not match the number of attention layers: {count}.")
+        self._walk_attn(lambda n, m: m.set_processor(processor[n] if isinstance(processor, dict) else processor))
+
+    # ---- forward
+    def time_embed(self, timestep, batch, device):
+        if not torch.is_tensor(timestep):
+            timestep = torch.tensor([timestep], dtype=torch.long, device=device)
+        timestep = timestep.reshape(-1).to(device).expand(batch)
+        half = self.config.block_out_channels[0] // 2
+        exponent = -math.log(10000) * torch.arange(half, dtype=f32, device=device) / half
+        arg = timestep[:, None].float() * torch.exp(exponent)[None, :]
+        t_emb = torch.cat([torch.cos(arg), torch.sin(arg)], dim=-1).to(f16)        # flip_sin_to_cos, shift 0
+        with torch.no_grad():
+            e = self.time_embedding.linear_1(t_emb)
+            e = self.time_embedding.linear_2(K.silu(e))
+            return K.silu(e)   # every resnet applies SiLU to emb before time_emb_proj
+
+    def forward(self, sample, timestep, encoder_hidden_states, cross_attention_kwargs=None, return_dict=True):
+        kw = cross_attention_kwargs or {}
+        B, Cin, H, W = sample.shape
+        dev = sample.device
+        temb_act = self.time_embed(timestep, B, dev)
+        ehs = encoder_hidden_states.to(f16).contiguous()
+        x = sample.new_zeros((B, H, W, self.conv_in.pack().Cip), dtype=f16)
+        x[..., :Cin] = sample.permute(0, 2, 3, 1)
+        x = self.conv_in(x.reshape(B * H * W, -1), B, H, W).reshape(B, H * W, -1)
+        skips = [(x, H, W)]
+        for blk in self.down_blocks:
+            for j, r in enumerate(blk.resnets):
+                x = r(x, temb_act, H, W)
+                if blk.has_attn:
+                    x = blk.attentions[j](x, ehs, kw)
+                skips.append((x, H, W))
+            if blk.downsamplers is not None:
+                x = blk.downsamplers[0](x, H, W)
+                H, W = H // 2, W // 2
+                skips.append((x, H, W))
+        x = self.mid_block.resnets[0](x, temb_act, H, W)
+        x = self.mid_block.attentions[0](x, ehs, kw)
+        x = self.mid_block.resnets[1](x, temb_act, H, W)
+        for blk in self.up_blocks:
+            for j, r in enumerate(blk.resnets):
+                s, _, _ = skips.pop()
+                x = r(ops.concat_channels(x, s), temb_act, H, W)
+                if blk.has_attn:
+                    x = blk.attentions[j](x, ehs, kw)
+            if blk.upsamplers is not None:
+                x = blk.upsamplers[0](x, H, W)
+                H, W = 2 * H, 2 * W
+        x = self.conv_norm_out(x, True)
+        y = self.conv_out(x.reshape(B * H * W, -1), B, H, W)
+        Co = self.config.out_channels
+        out = y.reshape(B, H, W, -1)[..., :Co].permute(0, 3, 1, 2)
+        return UNetOutput(out) if return_dict else (out,)
+
+
+def load_from_oracle_(unet: UNet2DConditionModel, oracle_unet: nn.Module) -> None:
+    """Copy weights from the fp32 oracle UNet (same key names) -- used by tests / smoke / bench init."""
+    sd = {k: v for k, v in oracle_unet.state_dict().items() if ".processor." not in k}
+    own = unet.state_dict()
+    missing = set(own) - set(sd)
+    extra = set(sd) - set(own)
+    assert not missing and not extra, (sorted(missing)[:5], sorted(extra)[:5])
+    with torch.no_grad():
+        for k, v in own.items():
+            v.copy_(sd[k].to(v.dtype))
+
+
+def init_random_(unet: UNet2DConditionModel, seed: int = 0, chunk: int = 1 << 24) -> None:
+    """Seeded synthetic weights at the configured shapes, directly on the module's device (fan-in scaled
+    normal for matrices/filters, zeros for biases, ones for norm scales) -- bench.py uses this because no
+    SD-1.5 checkpoint is available offline."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    with torch.no_grad():
+        for name, p in unet.named_parameters():
+            if ".processor." in name:
+                continue
+            if p.ndim >= 2:
+                fan_in = p[0].numel()
+                w = torch.randn(p.shape, generator=g, dtype=f32) / math.sqrt(fan_in)
+                p.copy_(w.to(p.dtype))
+            elif name.endswith("bias"):
+                p.zero_()
+            else:
+                p.fill_(1.0)

@@ -2,8 +2,11 @@
 Prints achieved TFLOP/s (MFMA kernels) or GB/s (HBM-bound kernels).  Run on the GPU box."""
 import json
 import math
+import os
 import sys
 import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 import torch
 
