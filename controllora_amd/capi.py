@@ -41,9 +41,10 @@ class Epilogue(C.Structure):
 _P, _I, _Z, _F = C.c_void_p, C.c_int, C.c_size_t, C.c_float
 _PROTOS = {
     "clora_gemm_f16": [_P, _I, _P, _P, _I, _I, _I, _I, C.POINTER(ConvDesc), C.POINTER(Epilogue), _I, _P, _Z, _P],
+    "clora_gemm_f16_ex": [_P, _I, _P, _P, _I, _I, _I, _I, C.POINTER(ConvDesc), C.POINTER(Epilogue), _I, _I, _P, _Z, _P],
     "clora_conv_wgrad_f16": [_P, _I, _P, _I, _P, _I, _I, _I, C.POINTER(ConvDesc), _P],
     "clora_attn_fwd_f16": [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _F, _P],
-    "clora_attn_bwd_f16": [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _F, _P],
+    "clora_attn_bwd_f16": [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _F, _P, _Z, _P],
     "clora_groupnorm_fwd_f16": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P, _Z, _P],
     "clora_groupnorm_bwd_f16": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _Z, _P],
     "clora_layernorm_fwd_f16": [_P, _P, _P, _P, _I, _I, _F, _P],
@@ -66,6 +67,7 @@ _PROTOS = {
     "clora_optim_prep_f32": [_P, _F, _F, _F, _I, _F, _F, _I, _P],
     "clora_adamw_flat_f32": [_P, _P, _P, _P, _Z, _P, _F, _F, _F, _F, _F, _P],
     "clora_abi_version": [],
+    "clora_groupnorm_workspace_bytes": [_I, _I, _I, _I, _I, _I],
 }
 
 
@@ -85,6 +87,7 @@ class Lib:
             fn.argtypes = argtypes
             fn.restype = C.c_int
         self.cdll.clora_build_info.restype = C.c_char_p
+        self.cdll.clora_groupnorm_workspace_bytes.restype = C.c_size_t
 
     def call(self, name: str, *args) -> None:
         rc = getattr(self.cdll, name)(*args)

@@ -30,6 +30,8 @@ struct AttnArgs {
     int ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv;
     int B, H, Nq, Nk, D;
     float scale;
+    int nsplit, q_per_split;   // dK/dV: split the query loop over grid.z (cross-attention: few keys, many queries)
+    float* acc32;              // [2][B, Nk, H*D] fp32 accumulators for the split path
 };
 
 constexpr float kLog2e = 1.4426950408889634f;
@@ -335,8 +337,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs p) {
     for (int i = 0; i < DT; ++i) { dkacc[i][0] = zero4f(); dkacc[i][1] = zero4f(); dvacc[i][0] = zero4f(); dvacc[i][1] = zero4f(); }
     const float c = p.scale * kLog2e;
 
-    for (int qq = 0; qq < p.Nq; qq += BQT) {
-        const int rows = (p.Nq - qq < BQT) ? p.Nq - qq : BQT;
+    const int q_beg = blockIdx.z * p.q_per_split;
+    const int q_end = (q_beg + p.q_per_split < p.Nq) ? q_beg + p.q_per_split : p.Nq;
+    for (int qq = q_beg; qq < q_end; qq += BQT) {
+        const int rows = (q_end - qq < BQT) ? q_end - qq : BQT;
         const half_t* qg_ = p.q + ((size_t)b * p.Nq + qq) * p.ldq + h * D;
         const half_t* dog = p.dO + ((size_t)b * p.Nq + qq) * p.lddo + h * D;
         __syncthreads();
@@ -403,14 +407,41 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs p) {
             for (int dt = 0; dt < DT; ++dt) {
                 const int d = dt * 16 + 4 * g;
                 if (d < D) {
-                    half4v ok_, ov;
+                    if (p.nsplit > 1) {
+                        const size_t o = ((size_t)b * p.Nk + key) * (p.H * D) + h * D + d;
+                        const size_t plane = (size_t)p.B * p.Nk * p.H * D;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) { ok_[r] = (half_t)(dkacc[dt][kg][r] * p.scale); ov[r] = (half_t)dvacc[dt][kg][r]; }
-                    st4(p.dk + ((size_t)b * p.Nk + key) * p.lddk + h * D + d, ok_);
-                    st4(p.dv + ((size_t)b * p.Nk + key) * p.lddv + h * D + d, ov);
+                        for (int r = 0; r < 4; ++r) {
+                            atomicAdd(p.acc32 + o + r, dkacc[dt][kg][r] * p.scale);
+                            atomicAdd(p.acc32 + plane + o + r, dvacc[dt][kg][r]);
+                        }
+                    } else {
+                        half4v ok_, ov;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { ok_[r] = (half_t)(dkacc[dt][kg][r] * p.scale); ov[r] = (half_t)dvacc[dt][kg][r]; }
+                        st4(p.dk + ((size_t)b * p.Nk + key) * p.lddk + h * D + d, ok_);
+                        st4(p.dv + ((size_t)b * p.Nk + key) * p.lddv + h * D + d, ov);
+                    }
                 }
             }
         }
+    }
+}
+
+// split path epilogue: fp32 accumulators -> fp16 dk / dv (row-strided)
+__global__ __launch_bounds__(256) void attn_dkv_convert_kernel(AttnArgs p) {
+    const int HD = p.H * p.D;
+    const size_t rows = (size_t)p.B * p.Nk, total = rows * (HD / 4), plane = rows * HD;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t row = i / (HD / 4);
+        const int c = (int)(i - row * (HD / 4)) * 4;
+        const floatx4 a = *reinterpret_cast<const floatx4*>(p.acc32 + row * HD + c);
+        const floatx4 bb = *reinterpret_cast<const floatx4*>(p.acc32 + plane + row * HD + c);
+        half4v ka, va;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { ka[r] = (half_t)a[r]; va[r] = (half_t)bb[r]; }
+        st4(p.dk + row * p.lddk + c, ka);
+        st4(p.dv + row * p.lddv + c, va);
     }
 }
 
@@ -424,7 +455,13 @@ int launch_bwd(const AttnArgs& a, hipStream_t s) {
     hipLaunchKernelGGL((attn_bwd_dq_kernel<DP, DT, BT>), dim3(clora_cdiv(a.Nq, 128), a.B * a.H), dim3(256), 0, s, a);
     int rc = clora_check_launch();
     if (rc != CLORA_OK) return rc;
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<DP, DT, BT>), dim3(clora_cdiv(a.Nk, 128), a.B * a.H), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<DP, DT, BT>), dim3(clora_cdiv(a.Nk, 128), a.B * a.H, a.nsplit), dim3(256), 0, s, a);
+    if (a.nsplit > 1) {
+        const size_t total = (size_t)a.B * a.Nk * (a.H * a.D / 4);
+        int blocks = (int)((total + 255) / 256);
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(attn_dkv_convert_kernel, dim3(blocks), dim3(256), 0, s, a);
+    }
     return clora_check_launch();
 }
 
@@ -462,7 +499,7 @@ extern "C" int clora_attn_bwd_f16(const clora_half* q, int ldq, const clora_half
                                   int ldv, const clora_half* o, int ldo, const clora_half* dO, int lddo,
                                   const float* lse, float* delta, clora_half* dq, int lddq, clora_half* dk, int lddk,
                                   clora_half* dv, int lddv, int B, int H, int Nq, int Nk, int D, float scale,
-                                  void* stream) {
+                                  void* workspace, size_t workspace_bytes, void* stream) {
     if (!q || !k || !v || !o || !dO || !lse || !delta || !dq || !dk || !dv || bad_dims(B, H, Nq, Nk, D) ||
         ((ldq | ldk | ldv | ldo | lddo | lddq | lddk | lddv) & 7))
         return CLORA_ERR_ARG;
@@ -473,6 +510,21 @@ extern "C" int clora_attn_bwd_f16(const clora_half* q, int ldq, const clora_half
     a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.lddo = lddo; a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
     a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.D = D; a.scale = scale;
     hipStream_t s = (hipStream_t)stream;
+    // few key blocks (cross-attention, Nk = 77): split the query loop so the dK/dV kernel fills the chip
+    a.nsplit = 1;
+    a.q_per_split = Nq;
+    const long kv_blocks = (long)clora_cdiv(Nk, 128) * B * H;
+    if (kv_blocks < 256 && Nq >= 512) {
+        int ns = (int)(512 / kv_blocks);
+        if (ns > Nq / 128) ns = Nq / 128;
+        const size_t need = (size_t)2 * B * Nk * H * D * sizeof(float);
+        if (ns > 1 && workspace && workspace_bytes >= need) {
+            a.q_per_split = clora_cdiv(clora_cdiv(Nq, ns), 64) * 64;
+            a.nsplit = clora_cdiv(Nq, a.q_per_split);
+            a.acc32 = (float*)workspace;
+            (void)hipMemsetAsync(workspace, 0, need, s);
+        }
+    }
     const size_t total = (size_t)B * Nq * H;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;

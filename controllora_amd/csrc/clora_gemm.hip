@@ -350,9 +350,40 @@ int launch_gemm(GemmArgs& a, int splits, hipStream_t s) {
 
 }  // namespace
 
-extern "C" int clora_gemm_f16(const clora_half* A, int lda, const clora_half* B, clora_half* C, int ldc, int M, int N,
-                              int K, const clora_conv_t* conv, const clora_epilogue_t* epi, int split_k,
-                              void* workspace, size_t workspace_bytes, void* stream) {
+// ---- launch planning --------------------------------------------------------------------------------
+// Tile shape and split-K are chosen by a small cost model: time ~ ceil(blocks / 256 CUs) * (tile MACs /
+// per-CU rate of that tile shape) + split-K reduction traffic.  The per-shape efficiencies were calibrated
+// with tools/kbench.py on MI355X (see profiles/): bigger tiles amortise LDS traffic better, smaller tiles
+// and split-K fill the chip when M*N alone gives fewer than ~256 tiles (the 8x8 / 16x16 UNet levels are
+// weight-streaming problems: M = 256..1024 rows against 3-59 MB of weights).
+namespace {
+struct TileCfg { int bm, bn; double eff; };
+const TileCfg kTiles[3] = {{128, 128, 0.34}, {128, 64, 0.26}, {64, 64, 0.17}};
+
+void plan_gemm(int M, int N, int K, int max_split, int& tile, int& splits) {
+    const double cu_rate = 2500.0e12 / 256.0;
+    const int ksteps = clora_cdiv(K, 32);
+    double best = 1e30;
+    tile = 0; splits = 1;
+    for (int c = 0; c < 3; ++c) {
+        const TileCfg& tc = kTiles[c];
+        const long tiles = (long)clora_cdiv(M, tc.bm) * clora_cdiv(N, tc.bn);
+        for (int s = 1; s <= max_split && s <= 16; ++s) {
+            if (s > 1 && ksteps / s < 8) break;
+            const int kps = clora_cdiv(ksteps, s) * 32;
+            const int real_s = clora_cdiv(K, kps);
+            const long blocks = tiles * real_s;
+            double t = (double)((blocks + 255) / 256) * (2.0 * tc.bm * tc.bn * kps) / (cu_rate * tc.eff) + 2.0e-6;
+            if (real_s > 1) t += (double)M * N * 8.0 * real_s / 2.5e12 + 3.0e-6;
+            if (t < best) { best = t; tile = c; splits = real_s; }
+        }
+    }
+}
+}  // namespace
+
+extern "C" int clora_gemm_f16_ex(const clora_half* A, int lda, const clora_half* B, clora_half* C, int ldc, int M, int N,
+                                 int K, const clora_conv_t* conv, const clora_epilogue_t* epi, int split_k, int tile_cfg,
+                                 void* workspace, size_t workspace_bytes, void* stream) {
     if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || (K & 7) || (N & 7) || (ldc & 7)) return CLORA_ERR_ARG;
     GemmArgs a;
     a.A = (const half_t*)A; a.B = (const half_t*)B; a.C = (half_t*)C; a.partial = nullptr;
@@ -370,21 +401,24 @@ extern "C" int clora_gemm_f16(const clora_half* A, int lda, const clora_half* B,
     if (a.epi.rowadd && a.epi.rows_per_batch <= 0) return CLORA_ERR_ARG;
     if (a.epi.residual && (a.epi.ldr & 7)) return CLORA_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
-    int splits = split_k < 1 ? 1 : split_k;
-    const int ksteps = clora_cdiv(K, 32);
-    if (splits > ksteps) splits = ksteps;
-    a.k_per_split = clora_cdiv(ksteps, splits) * 32;
+    // split_k: 0 = automatic (bounded by the workspace the caller provided), >= 1 = forced
+    int tile = 0, splits = 1;
+    const int ws_cap = workspace ? (int)(workspace_bytes / ((size_t)M * N * sizeof(float))) : 1;
+    plan_gemm(M, N, K, split_k >= 1 ? 1 : (ws_cap < 1 ? 1 : ws_cap), tile, splits);
+    if (split_k >= 1) {
+        const int ksteps = clora_cdiv(K, 32);
+        splits = split_k > ksteps ? ksteps : split_k;
+    }
+    if (tile_cfg >= 1 && tile_cfg <= 3) tile = tile_cfg - 1;
+    a.k_per_split = clora_cdiv(clora_cdiv(K, 32), splits) * 32;
     splits = clora_cdiv(K, a.k_per_split);
     if (splits > 1) {
         if (!workspace || workspace_bytes < (size_t)splits * M * N * sizeof(float)) return CLORA_ERR_WORKSPACE;
         a.partial = (float*)workspace;
     }
     int rc;
-    // tile choice: big tiles when they still fill the 256 CUs, otherwise smaller ones
-    const long t128 = (long)clora_cdiv(M, 128) * clora_cdiv(N, 128) * splits;
-    const long t12864 = (long)clora_cdiv(M, 128) * clora_cdiv(N, 64) * splits;
-    if (N > 64 && t128 >= 512) rc = launch_gemm<128, 128, 2, 2>(a, splits, s);
-    else if (t12864 >= 384 || M >= 4096) rc = launch_gemm<128, 64, 4, 1>(a, splits, s);
+    if (tile == 0) rc = launch_gemm<128, 128, 2, 2>(a, splits, s);
+    else if (tile == 1) rc = launch_gemm<128, 64, 4, 1>(a, splits, s);
     else rc = launch_gemm<64, 64, 2, 2>(a, splits, s);
     if (rc != CLORA_OK) return rc;
     if (splits > 1) {
@@ -395,6 +429,12 @@ extern "C" int clora_gemm_f16(const clora_half* A, int lda, const clora_half* B,
         rc = clora_check_launch();
     }
     return rc;
+}
+
+extern "C" int clora_gemm_f16(const clora_half* A, int lda, const clora_half* B, clora_half* C, int ldc, int M, int N,
+                              int K, const clora_conv_t* conv, const clora_epilogue_t* epi, int split_k,
+                              void* workspace, size_t workspace_bytes, void* stream) {
+    return clora_gemm_f16_ex(A, lda, B, C, ldc, M, N, K, conv, epi, split_k, 0, workspace, workspace_bytes, stream);
 }
 
 extern "C" int clora_conv_wgrad_f16(const clora_half* dY, int ldy, const clora_half* X, int ldx, float* dW, int M,

@@ -14,58 +14,51 @@
 
 namespace {
 
-struct DownArgs {
-    const half_t* X;
-    const float* D;
-    float* T;
-    int ldx, ldd, ldt, toff, M, K, R, accumulate, x_rows;
-};
-
-// one thread = one row m; X is staged through LDS in [256 x 64] tiles so global reads stay coalesced
+// one thread = one row m; X is staged through LDS in [256 x 64] tiles so global reads stay coalesced; the
+// adapter matrix D is wave-uniform and read with SCALAR loads straight into SGPR operands of v_pk_fma_f32
+// (the __restrict__ kernel arguments are what lets hipcc prove that) -- no LDS traffic for D at all.
 template <int RT>
-__global__ __launch_bounds__(256) void lora_down_kernel(DownArgs p) {
+__global__ __launch_bounds__(256) void lora_down_kernel(const half_t* __restrict__ X, const float* __restrict__ D,
+                                                        float* __restrict__ T, int ldx, int ldd, int ldt, int toff, int M,
+                                                        int K, int R, int accumulate, int x_rows) {
     constexpr int BKC = 64, LDX = BKC + 8;
     __shared__ __attribute__((aligned(16))) half_t Xs[256 * LDX];
-    __shared__ float Ds[RT * BKC];
     const int t = threadIdx.x;
     const int m0 = blockIdx.x * 256;
     float acc[RT];
 #pragma unroll
     for (int j = 0; j < RT; ++j) acc[j] = 0.f;
-    for (int k0 = 0; k0 < p.K; k0 += BKC) {
+    for (int k0 = 0; k0 < K; k0 += BKC) {
         __syncthreads();
         for (int c = t; c < 256 * 8; c += 256) {
             const int row = c >> 3, col = (c & 7) * 8;
             const int m = m0 + row;
             half8 v = zero8();
-            if (m < p.M && k0 + col < p.K) {
-                const int xr = p.x_rows > 0 ? m % p.x_rows : m;
-                v = ld8(p.X + (size_t)xr * p.ldx + k0 + col);
+            if (m < M && k0 + col < K) {
+                const int xr = x_rows > 0 ? m % x_rows : m;
+                v = ld8(X + (size_t)xr * ldx + k0 + col);
             }
             st8(Xs + row * LDX + col, v);
         }
-        for (int c = t; c < RT * BKC; c += 256) {
-            const int j = c / BKC, kk = c - j * BKC;
-            Ds[c] = (j < p.R && k0 + kk < p.K) ? p.D[(size_t)j * p.ldd + k0 + kk] : 0.f;
-        }
         __syncthreads();
-#pragma unroll
-        for (int c8 = 0; c8 < 8; ++c8) {
+        const int kc_end = (K - k0 < BKC) ? (K - k0) / 8 : 8;   // K % 8 == 0
+        for (int c8 = 0; c8 < kc_end; ++c8) {
             const half8 v = ld8(Xs + t * LDX + c8 * 8);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float xf = (float)v[e];
 #pragma unroll
-                for (int j = 0; j < RT; ++j) acc[j] += xf * Ds[j * BKC + c8 * 8 + e];
+                for (int j = 0; j < RT; ++j)
+                    if (j < R) acc[j] += xf * D[(size_t)j * ldd + k0 + c8 * 8 + e];
             }
         }
     }
     const int m = m0 + t;
-    if (m < p.M) {
-        float* out = p.T + (size_t)m * p.ldt + p.toff;
+    if (m < M) {
+        float* out = T + (size_t)m * ldt + toff;
 #pragma unroll
         for (int j = 0; j < RT; ++j)
-            if (j < p.R) out[j] = p.accumulate ? out[j] + acc[j] : acc[j];
+            if (j < R) out[j] = accumulate ? out[j] + acc[j] : acc[j];
     }
 }
 
@@ -109,44 +102,69 @@ __global__ __launch_bounds__(256) void lora_up_kernel(UpArgs p) {
     }
 }
 
-struct WgArgs {
-    const half_t* A;
-    const float* T;
-    float* G;
-    int lda, ldt, toff, gs_n, gs_j, M, N, R, a_rows, rows_per_block;
-    float scale;
-};
-
-// block = 128 columns x rows_per_block rows; wave w takes rows == w (mod 4); lane owns 2 columns
+// G[n*gs_n + j*gs_j] += scale * sum_m A[m, n] * T[m, toff + j]
+// block = 128 columns x rows_per_block rows; wave w takes rows == w (mod 4), 8 rows in flight per wave (memory
+// level parallelism: these reductions are pure HBM streams); lane owns 2 columns; the T row is wave-uniform
+// (scalar loads); the 4 waves are combined in LDS so each block issues one atomic per output element.
 template <int RT>
-__global__ __launch_bounds__(256) void lora_wgrad_kernel(WgArgs p) {
-    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+__global__ __launch_bounds__(256) void lora_wgrad_kernel(const half_t* __restrict__ A, const float* __restrict__ T,
+                                                         float* __restrict__ G, int lda, int ldt, int toff, int gs_n,
+                                                         int gs_j, int M, int N, int R, int a_rows, int rows_per_block,
+                                                         float scale) {
+    __shared__ float red[3 * 64 * 2 * RT];
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l = threadIdx.x & 63;
     const int n = blockIdx.x * 128 + 2 * l;
-    const int m_beg = blockIdx.y * p.rows_per_block;
-    const int m_end = (m_beg + p.rows_per_block < p.M) ? m_beg + p.rows_per_block : p.M;
-    const bool nok = n < p.N;  // N is even (multiple of 8)
+    const int m_beg = blockIdx.y * rows_per_block;
+    const int m_end = (m_beg + rows_per_block < M) ? m_beg + rows_per_block : M;
+    const bool nok = n < N;  // N is even
     float acc0[RT], acc1[RT];
 #pragma unroll
     for (int j = 0; j < RT; ++j) { acc0[j] = 0.f; acc1[j] = 0.f; }
-    for (int m = m_beg + w; m < m_end; m += 4) {
-        const int ar = p.a_rows > 0 ? m % p.a_rows : m;
-        half2v a = {0, 0};
-        if (nok) a = *reinterpret_cast<const half2v*>(p.A + (size_t)ar * p.lda + n);
-        const float a0 = (float)a[0], a1 = (float)a[1];
-        const float* tr = p.T + (size_t)m * p.ldt + p.toff;
+    constexpr int UN = 8;
+    for (int mb = m_beg + w; mb < m_end; mb += 4 * UN) {
+        half2v a[UN];
 #pragma unroll
-        for (int j = 0; j < RT; ++j) {
-            const float tv = (j < p.R) ? tr[j] : 0.f;
-            acc0[j] += a0 * tv;
-            acc1[j] += a1 * tv;
+        for (int u = 0; u < UN; ++u) {
+            const int m = mb + 4 * u;
+            half2v z = {0, 0};
+            a[u] = z;
+            if (nok && m < m_end) {
+                const int ar = a_rows > 0 ? m % a_rows : m;
+                a[u] = *reinterpret_cast<const half2v*>(A + (size_t)ar * lda + n);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int m = mb + 4 * u;
+            if (m < m_end) {
+                const float a0 = (float)a[u][0], a1 = (float)a[u][1];
+                const float* tr = T + (size_t)m * ldt + toff;
+#pragma unroll
+                for (int j = 0; j < RT; ++j)
+                    if (j < R) { const float tv = tr[j]; acc0[j] += a0 * tv; acc1[j] += a1 * tv; }
+            }
         }
     }
-    if (nok) {
+    if (w > 0) {
+#pragma unroll
+        for (int j = 0; j < RT; ++j) {
+            red[(((w - 1) * 64 + l) * 2 + 0) * RT + j] = acc0[j];
+            red[(((w - 1) * 64 + l) * 2 + 1) * RT + j] = acc1[j];
+        }
+    }
+    __syncthreads();
+    if (w == 0 && nok) {
 #pragma unroll
         for (int j = 0; j < RT; ++j)
-            if (j < p.R) {
-                atomicAdd(p.G + (size_t)n * p.gs_n + (size_t)j * p.gs_j, p.scale * acc0[j]);
-                atomicAdd(p.G + (size_t)(n + 1) * p.gs_n + (size_t)j * p.gs_j, p.scale * acc1[j]);
+            if (j < R) {
+                float s0 = acc0[j], s1 = acc1[j];
+#pragma unroll
+                for (int ww = 0; ww < 3; ++ww) {
+                    s0 += red[((ww * 64 + l) * 2 + 0) * RT + j];
+                    s1 += red[((ww * 64 + l) * 2 + 1) * RT + j];
+                }
+                atomicAdd(G + (size_t)n * gs_n + (size_t)j * gs_j, scale * s0);
+                atomicAdd(G + (size_t)(n + 1) * gs_n + (size_t)j * gs_j, scale * s1);
             }
     }
 }
@@ -157,15 +175,14 @@ extern "C" int clora_lora_down_f16(const clora_half* X, int ldx, const float* D,
                                    int M, int K, int R, int accumulate, int x_rows, void* stream) {
     if (!X || !D || !T || M <= 0 || K <= 0 || R <= 0 || (K & 7) || (ldx & 7)) return CLORA_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
+    const half_t* Xh = (const half_t*)X;
     for (int r0 = 0; r0 < R; r0 += 16) {  // ranks > 16 (danbooru-sketch control_rank 256) take several passes over X
-        DownArgs a;
-        a.X = (const half_t*)X; a.D = D + (size_t)r0 * ldd; a.T = T;
-        a.ldx = ldx; a.ldd = ldd; a.ldt = ldt; a.toff = toff + r0; a.M = M; a.K = K;
-        a.R = (R - r0 < 16) ? R - r0 : 16; a.accumulate = accumulate; a.x_rows = x_rows;
+        const float* Dp = D + (size_t)r0 * ldd;
+        const int Rp = (R - r0 < 16) ? R - r0 : 16, to = toff + r0;
         const dim3 grid(clora_cdiv(M, 256));
-        if (a.R <= 4) hipLaunchKernelGGL((lora_down_kernel<4>), grid, dim3(256), 0, s, a);
-        else if (a.R <= 8) hipLaunchKernelGGL((lora_down_kernel<8>), grid, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((lora_down_kernel<16>), grid, dim3(256), 0, s, a);
+        if (Rp <= 4) hipLaunchKernelGGL((lora_down_kernel<4>), grid, dim3(256), 0, s, Xh, Dp, T, ldx, ldd, ldt, to, M, K, Rp, accumulate, x_rows);
+        else if (Rp <= 8) hipLaunchKernelGGL((lora_down_kernel<8>), grid, dim3(256), 0, s, Xh, Dp, T, ldx, ldd, ldt, to, M, K, Rp, accumulate, x_rows);
+        else hipLaunchKernelGGL((lora_down_kernel<16>), grid, dim3(256), 0, s, Xh, Dp, T, ldx, ldd, ldt, to, M, K, Rp, accumulate, x_rows);
     }
     return clora_check_launch();
 }
@@ -186,16 +203,16 @@ extern "C" int clora_lora_wgrad_f16(const clora_half* A, int lda, const float* T
                                     int gs_j, int M, int N, int R, float scale, int a_rows, void* stream) {
     if (!A || !T || !G || M <= 0 || N <= 0 || R <= 0 || (N & 7) || (lda & 1)) return CLORA_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
+    const half_t* Ah = (const half_t*)A;
+    int rpb = 128;
+    while (rpb < 1024 && (long)clora_cdiv(N, 128) * clora_cdiv(M, rpb) > 1024) rpb *= 2;
     for (int r0 = 0; r0 < R; r0 += 16) {
-        WgArgs a;
-        a.A = (const half_t*)A; a.T = T; a.G = G + (size_t)r0 * gs_j;
-        a.lda = lda; a.ldt = ldt; a.toff = toff + r0; a.gs_n = gs_n; a.gs_j = gs_j; a.M = M; a.N = N;
-        a.R = (R - r0 < 16) ? R - r0 : 16; a.a_rows = a_rows; a.scale = scale;
-        a.rows_per_block = 256;
-        const dim3 grid(clora_cdiv(N, 128), clora_cdiv(M, a.rows_per_block));
-        if (a.R <= 4) hipLaunchKernelGGL((lora_wgrad_kernel<4>), grid, dim3(256), 0, s, a);
-        else if (a.R <= 8) hipLaunchKernelGGL((lora_wgrad_kernel<8>), grid, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((lora_wgrad_kernel<16>), grid, dim3(256), 0, s, a);
+        float* Gp = G + (size_t)r0 * gs_j;
+        const int Rp = (R - r0 < 16) ? R - r0 : 16, to = toff + r0;
+        const dim3 grid(clora_cdiv(N, 128), clora_cdiv(M, rpb));
+        if (Rp <= 4) hipLaunchKernelGGL((lora_wgrad_kernel<4>), grid, dim3(256), 0, s, Ah, T, Gp, lda, ldt, to, gs_n, gs_j, M, N, Rp, a_rows, rpb, scale);
+        else if (Rp <= 8) hipLaunchKernelGGL((lora_wgrad_kernel<8>), grid, dim3(256), 0, s, Ah, T, Gp, lda, ldt, to, gs_n, gs_j, M, N, Rp, a_rows, rpb, scale);
+        else hipLaunchKernelGGL((lora_wgrad_kernel<16>), grid, dim3(256), 0, s, Ah, T, Gp, lda, ldt, to, gs_n, gs_j, M, N, Rp, a_rows, rpb, scale);
     }
     return clora_check_launch();
 }

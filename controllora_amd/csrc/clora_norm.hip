@@ -11,7 +11,8 @@
 
 namespace {
 
-constexpr int kMaxCols = 4;  // column chunks (of 8 channels) owned by one thread: C <= 8192
+constexpr int kMaxCols = 2;   // column chunks (of 8 channels) owned by one thread in the GroupNorm passes: C <= 4096
+constexpr int kLnCols = 4;    // LayerNorm: chunks per lane, C <= 2048
 
 struct GnArgs {
     const half_t* x;
@@ -21,7 +22,8 @@ struct GnArgs {
     const float* beta;
     float* stats;   // [B, G, 2]  (mean, rstd)
     float* partial; // [B, nchunk, G, 2]
-    float* gsum;    // bwd: [B, G, 2] (s1, s2)
+    float* chpart;  // bwd, trainable affine: [B, nchunk, C, 2] per-channel (sum dyp, sum dyp*xhat)
+    float* table;   // fwd: [2][B][C] (scale, shift); bwd: [5][B][C] (scale, shift, k1, k2, k3)
     float* dgamma;
     float* dbeta;
     int B, HW, C, G, nchunk, rows_per_chunk;
@@ -35,13 +37,50 @@ __device__ __forceinline__ void gn_thread_map(int t, int CH, int& rl, int& nrl, 
     else { nrl = 256 / CH; rl = t / CH; c0 = t - rl * CH; cstep = CH; active = rl < nrl; }
 }
 
+// Deterministic block reduction: per-thread per-channel pairs -> LDS [nrl][C][2] -> per-channel totals in
+// red[0][c][*] -> per-group sums (optionally weighted by gamma) written to out_group[g*2 + {0,1}].
+__device__ __forceinline__ void gn_block_reduce(float* red, const float (&a)[kMaxCols][8], const float (&b)[kMaxCols][8],
+                                                int t, int C, int G, int rl, int nrl, int c0, int cstep, bool active,
+                                                const float* weight, float* out_group, float* out_channel) {
+    const int CH = C / 8, cpg = C / G;
+    if (active) {
+#pragma unroll
+        for (int j = 0; j < kMaxCols; ++j) {
+            const int cc = c0 + j * cstep;
+            if (cc < CH && (j == 0 || cstep == 256)) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    red[((size_t)rl * C + cc * 8 + e) * 2] = a[j][e];
+                    red[((size_t)rl * C + cc * 8 + e) * 2 + 1] = b[j][e];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int c = t; c < C; c += 256) {   // fold the row lanes (fixed order)
+        float sa = 0.f, sb = 0.f;
+        for (int r = 0; r < nrl; ++r) { sa += red[((size_t)r * C + c) * 2]; sb += red[((size_t)r * C + c) * 2 + 1]; }
+        red[c * 2] = sa; red[c * 2 + 1] = sb;
+        if (out_channel) { out_channel[c * 2] = sa; out_channel[c * 2 + 1] = sb; }
+    }
+    __syncthreads();
+    if (t < G) {
+        float sa = 0.f, sb = 0.f;
+        for (int c = t * cpg; c < (t + 1) * cpg; ++c) {
+            const float w = weight ? weight[c] : 1.0f;
+            sa += w * red[c * 2]; sb += w * red[c * 2 + 1];
+        }
+        out_group[t * 2] = sa; out_group[t * 2 + 1] = sb;
+    }
+}
+
+constexpr int kRedFloats = 2 * 4096;   // LDS: max(nrl*C, C) * 2 floats with nrl*C <= 2048 for CH < 256
+
 // ---- forward, pass 1
 __global__ __launch_bounds__(256) void gn_fwd_partial_kernel(GnArgs p) {
-    __shared__ float gs[64 * 2];
+    __shared__ float red[kRedFloats];
     const int t = threadIdx.x, b = blockIdx.y, chunk = blockIdx.x;
-    const int CH = p.C / 8, cpg = p.C / p.G;
-    for (int i = t; i < p.G * 2; i += 256) gs[i] = 0.f;
-    __syncthreads();
+    const int CH = p.C / 8;
     int rl, nrl, c0, cstep; bool active;
     gn_thread_map(t, CH, rl, nrl, c0, cstep, active);
     const int r_beg = chunk * p.rows_per_chunk;
@@ -52,6 +91,7 @@ __global__ __launch_bounds__(256) void gn_fwd_partial_kernel(GnArgs p) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) { s[j][e] = 0.f; q[j][e] = 0.f; }
     if (active) {
+#pragma unroll 4
         for (int r = r_beg + rl; r < r_end; r += nrl) {
             const half_t* row = p.x + ((size_t)b * p.HW + r) * p.C;
 #pragma unroll
@@ -64,56 +104,63 @@ __global__ __launch_bounds__(256) void gn_fwd_partial_kernel(GnArgs p) {
                 }
             }
         }
-#pragma unroll
-        for (int j = 0; j < kMaxCols; ++j) {
-            const int cc = c0 + j * cstep;
-            if (cc < CH && (j == 0 || cstep == 256)) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const int grp = (cc * 8 + e) / cpg;
-                    atomicAdd(&gs[grp * 2], s[j][e]);
-                    atomicAdd(&gs[grp * 2 + 1], q[j][e]);
-                }
-            }
+    }
+    gn_block_reduce(red, s, q, t, p.C, p.G, rl, nrl, c0, cstep, active, nullptr,
+                    p.partial + ((size_t)b * p.nchunk + chunk) * p.G * 2, nullptr);
+}
+
+// ---- forward, pass 2: mean / rstd per (b, g) and the per-(b, channel) scale/shift table
+__global__ __launch_bounds__(256) void gn_fwd_finalize_kernel(GnArgs p) {
+    __shared__ float mr[64 * 2];
+    const int t = threadIdx.x, b = blockIdx.x;
+    const int cpg = p.C / p.G;
+    if (t < p.G) {
+        float s = 0.f, q = 0.f;
+        for (int c = 0; c < p.nchunk; ++c) {
+            const float* pp = p.partial + (((size_t)b * p.nchunk + c) * p.G + t) * 2;
+            s += pp[0]; q += pp[1];
         }
+        const float n = (float)p.HW * (float)cpg;
+        const float mean = s / n;
+        float var = q / n - mean * mean;
+        var = var < 0.f ? 0.f : var;
+        const float rstd = rsqrtf(var + p.eps);
+        mr[t * 2] = mean; mr[t * 2 + 1] = rstd;
+        p.stats[((size_t)b * p.G + t) * 2] = mean;
+        p.stats[((size_t)b * p.G + t) * 2 + 1] = rstd;
     }
     __syncthreads();
-    for (int i = t; i < p.G * 2; i += 256) p.partial[((size_t)b * p.nchunk + chunk) * p.G * 2 + i] = gs[i];
-}
-
-// ---- forward, pass 2: mean / rstd
-__global__ __launch_bounds__(256) void gn_fwd_finalize_kernel(GnArgs p) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= p.B * p.G) return;
-    const int b = i / p.G, g = i - b * p.G;
-    float s = 0.f, q = 0.f;
-    for (int c = 0; c < p.nchunk; ++c) {
-        const float* pp = p.partial + (((size_t)b * p.nchunk + c) * p.G + g) * 2;
-        s += pp[0]; q += pp[1];
+    float* scale = p.table + (size_t)b * p.C;
+    float* shift = p.table + (size_t)(p.B + b) * p.C;
+    for (int c = t; c < p.C; c += 256) {
+        const int g = c / cpg;
+        const float sc = mr[g * 2 + 1] * p.gamma[c];
+        scale[c] = sc;
+        shift[c] = p.beta[c] - mr[g * 2] * sc;
     }
-    const float n = (float)p.HW * (float)(p.C / p.G);
-    const float mean = s / n;
-    float var = q / n - mean * mean;
-    var = var < 0.f ? 0.f : var;
-    p.stats[i * 2] = mean;
-    p.stats[i * 2 + 1] = rsqrtf(var + p.eps);
 }
 
-// ---- forward, pass 3
+__device__ __forceinline__ void ld8f(const float* p, float (&o)[8]) {
+    const floatx4 a = *reinterpret_cast<const floatx4*>(p), b = *reinterpret_cast<const floatx4*>(p + 4);
+    o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3]; o[4] = b[0]; o[5] = b[1]; o[6] = b[2]; o[7] = b[3];
+}
+
+// ---- forward, pass 3: y = x*scale + shift (+SiLU)
 __global__ __launch_bounds__(256) void gn_fwd_apply_kernel(GnArgs p) {
-    const int CH = p.C / 8, cpg = p.C / p.G;
+    const int CH = p.C / 8;
     const size_t total = (size_t)p.B * p.HW * CH;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const size_t row = i / CH;
         const int cc = (int)(i - row * CH);
         const int b = (int)(row / p.HW);
         const half8 v = ld8(p.x + row * p.C + cc * 8);
+        float sc[8], sh[8];
+        ld8f(p.table + (size_t)b * p.C + cc * 8, sc);
+        ld8f(p.table + (size_t)(p.B + b) * p.C + cc * 8, sh);
         half8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const int ch = cc * 8 + e;
-            const float* st = p.stats + ((size_t)b * p.G + ch / cpg) * 2;
-            float yv = ((float)v[e] - st[0]) * st[1] * p.gamma[ch] + p.beta[ch];
+            float yv = (float)v[e] * sc[e] + sh[e];
             if (p.fuse_silu) yv = silu_f(yv);
             o[e] = (half_t)yv;
         }
@@ -121,23 +168,29 @@ __global__ __launch_bounds__(256) void gn_fwd_apply_kernel(GnArgs p) {
     }
 }
 
-// ---- backward, pass 1: s1 = sum dyp*gamma, s2 = sum dyp*gamma*xhat per (b, group); dgamma/dbeta
+// ---- backward, pass 1: per channel a1 = sum dyp, a2 = sum dyp*xhat over this block's rows
 __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(GnArgs p) {
-    __shared__ float gs[64 * 2];
+    __shared__ float red[kRedFloats];
     const int t = threadIdx.x, b = blockIdx.y, chunk = blockIdx.x;
     const int CH = p.C / 8, cpg = p.C / p.G;
-    for (int i = t; i < p.G * 2; i += 256) gs[i] = 0.f;
-    __syncthreads();
     int rl, nrl, c0, cstep; bool active;
     gn_thread_map(t, CH, rl, nrl, c0, cstep, active);
     const int r_beg = chunk * p.rows_per_chunk;
     const int r_end = (r_beg + p.rows_per_chunk < p.HW) ? r_beg + p.rows_per_chunk : p.HW;
-    float a1[kMaxCols][8], a2[kMaxCols][8];  // per channel: sum dyp, sum dyp*xhat
+    float a1[kMaxCols][8], a2[kMaxCols][8];
+    float kmean[kMaxCols][8], krstd[kMaxCols][8], kg[kMaxCols][8], kb[kMaxCols][8];
 #pragma unroll
     for (int j = 0; j < kMaxCols; ++j)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { a1[j][e] = 0.f; a2[j][e] = 0.f; }
+        for (int e = 0; e < 8; ++e) {
+            a1[j][e] = 0.f; a2[j][e] = 0.f;
+            const int cc = c0 + j * cstep;
+            const int ch = (cc < CH ? cc : 0) * 8 + e;
+            const float* st = p.stats + ((size_t)b * p.G + ch / cpg) * 2;
+            kmean[j][e] = st[0]; krstd[j][e] = st[1]; kg[j][e] = p.gamma[ch]; kb[j][e] = p.beta[ch];
+        }
     if (active) {
+#pragma unroll 2
         for (int r = r_beg + rl; r < r_end; r += nrl) {
             const size_t off = ((size_t)b * p.HW + r) * p.C;
 #pragma unroll
@@ -147,71 +200,84 @@ __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(GnArgs p) {
                     const half8 xv = ld8(p.x + off + cc * 8), gv = ld8(p.dy + off + cc * 8);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
-                        const int ch = cc * 8 + e;
-                        const float* st = p.stats + ((size_t)b * p.G + ch / cpg) * 2;
-                        const float xh = ((float)xv[e] - st[0]) * st[1];
+                        const float xh = ((float)xv[e] - kmean[j][e]) * krstd[j][e];
                         float d = (float)gv[e];
-                        if (p.fuse_silu) d *= dsilu_f(xh * p.gamma[ch] + p.beta[ch]);
+                        if (p.fuse_silu) d *= dsilu_f(xh * kg[j][e] + kb[j][e]);
                         a1[j][e] += d;
                         a2[j][e] += d * xh;
                     }
                 }
             }
         }
-#pragma unroll
-        for (int j = 0; j < kMaxCols; ++j) {
-            const int cc = c0 + j * cstep;
-            if (cc < CH && (j == 0 || cstep == 256)) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const int ch = cc * 8 + e, grp = ch / cpg;
-                    const float gm = p.gamma[ch];
-                    atomicAdd(&gs[grp * 2], a1[j][e] * gm);
-                    atomicAdd(&gs[grp * 2 + 1], a2[j][e] * gm);
-                    if (p.dgamma) {
-                        atomicAdd(p.dgamma + ch, a2[j][e]);
-                        atomicAdd(p.dbeta + ch, a1[j][e]);
-                    }
-                }
-            }
-        }
     }
-    __syncthreads();
-    for (int i = t; i < p.G * 2; i += 256) p.partial[((size_t)b * p.nchunk + chunk) * p.G * 2 + i] = gs[i];
+    gn_block_reduce(red, a1, a2, t, p.C, p.G, rl, nrl, c0, cstep, active, p.gamma,
+                    p.partial + ((size_t)b * p.nchunk + chunk) * p.G * 2,
+                    p.chpart ? p.chpart + ((size_t)b * p.nchunk + chunk) * p.C * 2 : nullptr);
 }
 
+// ---- backward, pass 2: per (b, channel) coefficients  dx = k1*dyp + k2*x + k3
 __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(GnArgs p) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= p.B * p.G) return;
-    const int b = i / p.G, g = i - b * p.G;
-    float s = 0.f, q = 0.f;
-    for (int c = 0; c < p.nchunk; ++c) {
-        const float* pp = p.partial + (((size_t)b * p.nchunk + c) * p.G + g) * 2;
-        s += pp[0]; q += pp[1];
+    __shared__ float gs[64 * 2];
+    const int t = threadIdx.x, b = blockIdx.x;
+    const int cpg = p.C / p.G;
+    if (t < p.G) {
+        float s = 0.f, q = 0.f;
+        for (int c = 0; c < p.nchunk; ++c) {
+            const float* pp = p.partial + (((size_t)b * p.nchunk + c) * p.G + t) * 2;
+            s += pp[0]; q += pp[1];
+        }
+        const float n = (float)p.HW * (float)cpg;
+        gs[t * 2] = s / n; gs[t * 2 + 1] = q / n;
     }
-    const float n = (float)p.HW * (float)(p.C / p.G);
-    p.gsum[i * 2] = s / n;
-    p.gsum[i * 2 + 1] = q / n;
+    __syncthreads();
+    const size_t plane = (size_t)p.B * p.C;
+    for (int c = t; c < p.C; c += 256) {
+        const int g = c / cpg;
+        const float mean = p.stats[((size_t)b * p.G + g) * 2], rstd = p.stats[((size_t)b * p.G + g) * 2 + 1];
+        const float sc = rstd * p.gamma[c];
+        const size_t o = (size_t)b * p.C + c;
+        p.table[o] = sc;
+        p.table[plane + o] = p.beta[c] - mean * sc;
+        p.table[2 * plane + o] = sc;                                  // k1 = rstd*gamma
+        const float k2 = -rstd * rstd * gs[g * 2 + 1];
+        p.table[3 * plane + o] = k2;
+        p.table[4 * plane + o] = -k2 * mean - rstd * gs[g * 2];       // k3
+    }
+}
+
+// ---- backward, trainable affine: dgamma[c] = sum_{b,chunk} a2, dbeta[c] = sum a1  (fixed order)
+__global__ __launch_bounds__(256) void gn_bwd_params_kernel(GnArgs p) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= p.C) return;
+    float sa = 0.f, sb = 0.f;
+    for (int i = 0; i < p.B * p.nchunk; ++i) {
+        const float* pp = p.chpart + ((size_t)i * p.C + c) * 2;
+        sa += pp[0]; sb += pp[1];
+    }
+    p.dbeta[c] = sa;
+    p.dgamma[c] = sb;
 }
 
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(GnArgs p) {
-    const int CH = p.C / 8, cpg = p.C / p.G;
+    const int CH = p.C / 8;
     const size_t total = (size_t)p.B * p.HW * CH;
+    const size_t plane = (size_t)p.B * p.C;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const size_t row = i / CH;
         const int cc = (int)(i - row * CH);
         const int b = (int)(row / p.HW);
         const half8 xv = ld8(p.x + row * p.C + cc * 8), gv = ld8(p.dy + row * p.C + cc * 8);
+        const float* tb = p.table + (size_t)b * p.C + cc * 8;
+        float sc[8], sh[8], k1[8], k2[8], k3[8];
+        ld8f(tb + 2 * plane, k1); ld8f(tb + 3 * plane, k2); ld8f(tb + 4 * plane, k3);
+        if (p.fuse_silu) { ld8f(tb, sc); ld8f(tb + plane, sh); }
         half8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const int ch = cc * 8 + e, grp = ch / cpg;
-            const float* st = p.stats + ((size_t)b * p.G + grp) * 2;
-            const float* gsm = p.gsum + ((size_t)b * p.G + grp) * 2;
-            const float xh = ((float)xv[e] - st[0]) * st[1];
+            const float xf = (float)xv[e];
             float d = (float)gv[e];
-            if (p.fuse_silu) d *= dsilu_f(xh * p.gamma[ch] + p.beta[ch]);
-            o[e] = (half_t)(st[1] * (d * p.gamma[ch] - gsm[0] - xh * gsm[1]));
+            if (p.fuse_silu) d *= dsilu_f(xf * sc[e] + sh[e]);
+            o[e] = (half_t)(k1[e] * d + k2[e] * xf + k3[e]);
         }
         st8(p.y + row * p.C + cc * 8, o);
     }
@@ -235,10 +301,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs p) {
     const bool rok = row < p.M;
     const int CH = p.C / 8;
     const size_t off = (size_t)(rok ? row : 0) * p.C;
-    half8 xv[kMaxCols], gv[kMaxCols];
+    half8 xv[kLnCols], gv[kLnCols];
     float s = 0.f;
 #pragma unroll
-    for (int j = 0; j < kMaxCols; ++j) {
+    for (int j = 0; j < kLnCols; ++j) {
         const int cc = l + 64 * j;
         xv[j] = zero8(); gv[j] = zero8();
         if (cc < CH) {
@@ -251,7 +317,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs p) {
     const float mean = wave_sum(s) / (float)p.C;
     float q = 0.f;
 #pragma unroll
-    for (int j = 0; j < kMaxCols; ++j)
+    for (int j = 0; j < kLnCols; ++j)
         if (l + 64 * j < CH) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) { const float d = (float)xv[j][e] - mean; q += d * d; }
@@ -259,7 +325,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs p) {
     const float rstd = rsqrtf(wave_sum(q) / (float)p.C + p.eps);
     if (!BWD) {
 #pragma unroll
-        for (int j = 0; j < kMaxCols; ++j) {
+        for (int j = 0; j < kLnCols; ++j) {
             const int cc = l + 64 * j;
             if (cc < CH && rok) {
                 half8 o;
@@ -272,7 +338,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs p) {
     } else {
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int j = 0; j < kMaxCols; ++j) {
+        for (int j = 0; j < kLnCols; ++j) {
             const int cc = l + 64 * j;
             if (cc < CH) {
 #pragma unroll
@@ -286,7 +352,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs p) {
         s1 = wave_sum(s1) / (float)p.C;
         s2 = wave_sum(s2) / (float)p.C;
 #pragma unroll
-        for (int j = 0; j < kMaxCols; ++j) {
+        for (int j = 0; j < kLnCols; ++j) {
             const int cc = l + 64 * j;
             if (cc < CH && rok) {
                 half8 o;
@@ -301,20 +367,23 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs p) {
     }
 }
 
-int gn_plan(GnArgs& a, void* ws, size_t ws_bytes, bool bwd) {
-    if (a.B <= 0 || a.HW <= 0 || a.C <= 0 || a.G <= 0 || a.G > 64 || (a.C % a.G) || (a.C & 7) || a.C / 8 > 256 * kMaxCols)
+int gn_plan(GnArgs& a, void* ws, size_t ws_bytes, bool bwd, bool params) {
+    if (a.B <= 0 || a.HW <= 0 || a.C <= 0 || a.G <= 0 || a.G > 64 || (a.C % a.G) || (a.C & 7) || a.C > 4096)
         return CLORA_ERR_ARG;
-    int nchunk = 1024 / a.B;
-    if (nchunk < 1) nchunk = 1;
-    int rpc = clora_cdiv(a.HW, nchunk);
-    if (rpc < 8) rpc = 8;
-    nchunk = clora_cdiv(a.HW, rpc);
-    a.nchunk = nchunk;
-    a.rows_per_chunk = rpc;
-    const size_t need = ((size_t)a.B * nchunk * a.G * 2 + (bwd ? (size_t)a.B * a.G * 2 : 0)) * sizeof(float);
-    if (!ws || ws_bytes < need) return CLORA_ERR_WORKSPACE;
+    const int CH = a.C / 8;
+    const int nrl = CH >= 256 ? 1 : 256 / CH;
+    long rpc = ((long)a.HW * a.B + 511) / 512;          // ~512 blocks in flight
+    if (rpc < 32) rpc = 32;
+    if (rpc < 2 * nrl) rpc = 2 * nrl;
+    if (rpc > a.HW) rpc = a.HW;
+    a.rows_per_chunk = (int)rpc;
+    a.nchunk = clora_cdiv(a.HW, rpc);
+    size_t need = (size_t)a.B * a.nchunk * a.G * 2 + (size_t)(bwd ? 5 : 2) * a.B * a.C;
+    if (params) need += (size_t)a.B * a.nchunk * a.C * 2;
+    if (!ws || ws_bytes < need * sizeof(float)) return CLORA_ERR_WORKSPACE;
     a.partial = (float*)ws;
-    a.gsum = a.partial + (size_t)a.B * nchunk * a.G * 2;
+    a.table = a.partial + (size_t)a.B * a.nchunk * a.G * 2;
+    a.chpart = params ? a.table + (size_t)5 * a.B * a.C : nullptr;
     return CLORA_OK;
 }
 
@@ -325,6 +394,16 @@ int ew_blocks(size_t n) {
 
 }  // namespace
 
+extern "C" size_t clora_groupnorm_workspace_bytes(int B, int HW, int C, int G, int backward, int param_grads) {
+    GnArgs a = GnArgs();
+    a.B = B; a.HW = HW; a.C = C; a.G = G;
+    static float dummy;
+    if (gn_plan(a, &dummy, (size_t)-1, backward != 0, param_grads != 0) != CLORA_OK) return 0;
+    size_t need = (size_t)B * a.nchunk * G * 2 + (size_t)(backward ? 5 : 2) * B * C;
+    if (param_grads) need += (size_t)B * a.nchunk * C * 2;
+    return need * sizeof(float);
+}
+
 extern "C" int clora_groupnorm_fwd_f16(const clora_half* x, clora_half* y, const float* gamma, const float* beta,
                                        float* stats, int B, int HW, int C, int G, float eps, int fuse_silu,
                                        void* workspace, size_t workspace_bytes, void* stream) {
@@ -332,11 +411,11 @@ extern "C" int clora_groupnorm_fwd_f16(const clora_half* x, clora_half* y, const
     GnArgs a = GnArgs();
     a.x = (const half_t*)x; a.y = (half_t*)y; a.gamma = gamma; a.beta = beta; a.stats = stats;
     a.B = B; a.HW = HW; a.C = C; a.G = G; a.eps = eps; a.fuse_silu = fuse_silu;
-    int rc = gn_plan(a, workspace, workspace_bytes, false);
+    int rc = gn_plan(a, workspace, workspace_bytes, false, false);
     if (rc != CLORA_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(gn_fwd_partial_kernel, dim3(a.nchunk, B), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(gn_fwd_finalize_kernel, dim3(clora_cdiv(B * G, 256)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(gn_fwd_finalize_kernel, dim3(B), dim3(256), 0, s, a);
     hipLaunchKernelGGL(gn_fwd_apply_kernel, dim3(ew_blocks((size_t)B * HW * (C / 8))), dim3(256), 0, s, a);
     return clora_check_launch();
 }
@@ -350,18 +429,19 @@ extern "C" int clora_groupnorm_bwd_f16(const clora_half* x, const clora_half* dy
     a.x = (const half_t*)x; a.dy = (const half_t*)dy; a.y = (half_t*)dx; a.gamma = gamma; a.beta = beta;
     a.stats = const_cast<float*>(stats); a.dgamma = dgamma; a.dbeta = dbeta;
     a.B = B; a.HW = HW; a.C = C; a.G = G; a.fuse_silu = fuse_silu;
-    int rc = gn_plan(a, workspace, workspace_bytes, true);
+    int rc = gn_plan(a, workspace, workspace_bytes, true, dgamma != nullptr);
     if (rc != CLORA_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(gn_bwd_partial_kernel, dim3(a.nchunk, B), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(clora_cdiv(B * G, 256)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(B), dim3(256), 0, s, a);
+    if (dgamma) hipLaunchKernelGGL(gn_bwd_params_kernel, dim3(clora_cdiv(C, 256)), dim3(256), 0, s, a);
     hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(ew_blocks((size_t)B * HW * (C / 8))), dim3(256), 0, s, a);
     return clora_check_launch();
 }
 
 extern "C" int clora_layernorm_fwd_f16(const clora_half* x, clora_half* y, const float* gamma, const float* beta, int M,
                                        int C, float eps, void* stream) {
-    if (!x || !y || !gamma || !beta || M <= 0 || C <= 0 || (C & 7) || C / 8 > 64 * kMaxCols) return CLORA_ERR_ARG;
+    if (!x || !y || !gamma || !beta || M <= 0 || C <= 0 || (C & 7) || C / 8 > 64 * kLnCols) return CLORA_ERR_ARG;
     LnArgs a = LnArgs();
     a.x = (const half_t*)x; a.y = (half_t*)y; a.gamma = gamma; a.beta = beta; a.M = M; a.C = C; a.eps = eps;
     hipLaunchKernelGGL((layernorm_kernel<false>), dim3(clora_cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, a);
@@ -370,7 +450,7 @@ extern "C" int clora_layernorm_fwd_f16(const clora_half* x, clora_half* y, const
 
 extern "C" int clora_layernorm_bwd_f16(const clora_half* x, const clora_half* dy, clora_half* dx, const float* gamma,
                                        int M, int C, float eps, void* stream) {
-    if (!x || !dy || !dx || !gamma || M <= 0 || C <= 0 || (C & 7) || C / 8 > 64 * kMaxCols) return CLORA_ERR_ARG;
+    if (!x || !dy || !dx || !gamma || M <= 0 || C <= 0 || (C & 7) || C / 8 > 64 * kLnCols) return CLORA_ERR_ARG;
     LnArgs a = LnArgs();
     a.x = (const half_t*)x; a.dy = (const half_t*)dy; a.y = (half_t*)dx; a.gamma = gamma; a.M = M; a.C = C; a.eps = eps;
     hipLaunchKernelGGL((layernorm_kernel<true>), dim3(clora_cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, a);

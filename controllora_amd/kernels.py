@@ -91,19 +91,13 @@ def workspace(nbytes: int, device) -> torch.Tensor:
     return w
 
 
-def pick_split_k(M, N, K) -> int:
-    """split-K when the output tiles alone cannot fill 256 CUs (weight-streaming regime: small M, big K)."""
-    tiles = ((M + 63) // 64) * ((N + 63) // 64)
-    if tiles >= 256 or K < 1024:
-        return 1
-    s = min(16, max(1, 512 // tiles), K // 256)
-    return max(1, s)
+GEMM_WS_BYTES = 256 << 20   # split-K slab budget handed to the library's launch planner
 
 
 def gemm(A: torch.Tensor, Bw: torch.Tensor, M: int, N: int, K: int, *, lda: Optional[int] = None,
          conv: Optional[ConvDesc] = None, bias=None, rowadd=None, rows_per_batch=0, residual=None,
          lora_t=None, lora_u=None, lora_seg=0, lora_scale=1.0, out: Optional[torch.Tensor] = None,
-         split_k: Optional[int] = None) -> torch.Tensor:
+         split_k: int = 0, tile_cfg: int = 0) -> torch.Tensor:
     """C[M,N] = A . Bw^T with the fused epilogue of clora_epilogue_t."""
     assert A.dtype == f16 and Bw.dtype == f16 and Bw.shape == (N, K) and Bw.is_contiguous()
     C_ = out if out is not None else torch.empty((M, N), dtype=f16, device=A.device)
@@ -123,10 +117,9 @@ def gemm(A: torch.Tensor, Bw: torch.Tensor, M: int, N: int, K: int, *, lda: Opti
         assert lora_t.dtype == f32 and lora_u.dtype == f32 and lora_t.is_contiguous() and lora_u.is_contiguous()
         e.lora_t, e.ldt, e.lora_u, e.lora_r = ptr(lora_t), lora_t.shape[-1], ptr(lora_u), lora_u.shape[-1]
         e.lora_seg, e.lora_scale = (lora_seg or N), float(lora_scale)
-    sk = pick_split_k(M, N, K) if split_k is None else split_k
-    ws = workspace(sk * M * N * 4, A.device) if sk > 1 else None
-    _call("clora_gemm_f16", ptr(A), lda if lda is not None else K, ptr(Bw), ptr(C_), ldc, M, N, K,
-          C.byref(conv) if conv is not None else None, C.byref(e), sk,
+    ws = workspace(GEMM_WS_BYTES if split_k == 0 else max(split_k, 1) * M * N * 4, A.device) if split_k != 1 else None
+    _call("clora_gemm_f16_ex", ptr(A), lda if lda is not None else K, ptr(Bw), ptr(C_), ldc, M, N, K,
+          C.byref(conv) if conv is not None else None, C.byref(e), split_k, tile_cfg,
           ptr(ws) if ws is not None else None, ws.numel() if ws is not None else 0,
           flops=2.0 * M * N * K, nbytes=2.0 * (A.numel() + N * K + M * N))
     return C_
@@ -152,23 +145,28 @@ def attn_fwd(q, k, v, B, H, Nq, Nk, D, scale, out=None):
 
 def attn_bwd(q, k, v, o, dO, lse, B, H, Nq, Nk, D, scale, dq, dk, dv):
     delta = torch.empty((B, H, Nq), dtype=f32, device=q.device)
+    ws = workspace(2 * B * Nk * H * D * 4, q.device) if Nk <= 1024 else None
     _call("clora_attn_bwd_f16", ptr(q, f16), q.stride(0), ptr(k, f16), k.stride(0), ptr(v, f16), v.stride(0),
           ptr(o, f16), o.stride(0), ptr(dO, f16), dO.stride(0), ptr(lse, f32), ptr(delta),
           ptr(dq, f16), dq.stride(0), ptr(dk, f16), dk.stride(0), ptr(dv, f16), dv.stride(0),
-          B, H, Nq, Nk, D, float(scale), flops=10.0 * B * H * Nq * Nk * D)
+          B, H, Nq, Nk, D, float(scale), ptr(ws) if ws is not None else None, ws.numel() if ws is not None else 0,
+          flops=10.0 * B * H * Nq * Nk * D)
     return dq, dk, dv
 
 
 # ------------------------------------------------------------------ norms
-def _gn_ws(B, HW, G, device):
-    return workspace((B * 1024 * G * 2 + B * G * 2) * 4 + 4096, device)
+def _gn_ws(B, HW, Cc, G, device, bwd, params):
+    n = capi.lib().cdll.clora_groupnorm_workspace_bytes(B, HW, Cc, G, int(bwd), int(params))
+    if n == 0:
+        raise capi.CloraError(f"unsupported GroupNorm shape B={B} HW={HW} C={Cc} G={G}")
+    return workspace(n, device)
 
 
 def groupnorm_fwd(x, gamma, beta, G, eps, silu):
     B, HW, Cc = x.shape
     y = torch.empty_like(x)
     stats = torch.empty((B, G, 2), dtype=f32, device=x.device)
-    ws = _gn_ws(B, HW, G, x.device)
+    ws = _gn_ws(B, HW, Cc, G, x.device, False, False)
     _call("clora_groupnorm_fwd_f16", ptr(x, f16), ptr(y), ptr(gamma, f32), ptr(beta, f32), ptr(stats), B, HW, Cc, G,
           float(eps), int(silu), ptr(ws), ws.numel())
     return y, stats
@@ -179,9 +177,9 @@ def groupnorm_bwd(x, dy, gamma, beta, stats, G, silu, want_param_grads=False):
     dx = torch.empty_like(x)
     dg = db = None
     if want_param_grads:
-        dg = torch.zeros(Cc, dtype=f32, device=x.device)
-        db = torch.zeros(Cc, dtype=f32, device=x.device)
-    ws = _gn_ws(B, HW, G, x.device)
+        dg = torch.empty(Cc, dtype=f32, device=x.device)
+        db = torch.empty(Cc, dtype=f32, device=x.device)
+    ws = _gn_ws(B, HW, Cc, G, x.device, True, want_param_grads)
     _call("clora_groupnorm_bwd_f16", ptr(x, f16), ptr(dy, f16), ptr(dx), ptr(gamma, f32), ptr(beta, f32), ptr(stats, f32),
           ptr(dg), ptr(db), B, HW, Cc, G, int(silu), ptr(ws), ws.numel())
     return dx, dg, db

@@ -67,10 +67,15 @@ typedef struct {
  * (reference models.py:124-147,231-282 `attn.to_q/to_k/to_v/to_out`; upstream ResnetBlock2D /
  * Transformer2DModel / FeedForward, SURVEY.md U1,U4,U5) and of the hint encoder (models.py:470,529,684).
  * `conv` may be NULL (plain GEMM, A row stride lda).  K must be a multiple of 8, N a multiple of 8.
+ * split_k: 0 = chosen by the library's cost model (bounded by the workspace provided), >= 1 = forced;
  * split_k > 1 needs workspace >= split_k*M*N*4 bytes. */
 int clora_gemm_f16(const clora_half* A, int lda, const clora_half* B, clora_half* C, int ldc,
                    int M, int N, int K, const clora_conv_t* conv, const clora_epilogue_t* epi,
                    int split_k, void* workspace, size_t workspace_bytes, void* stream);
+/* same, with the tile shape forced (tile_cfg 1: 128x128, 2: 128x64, 3: 64x64; 0 = automatic) -- tuning / tests */
+int clora_gemm_f16_ex(const clora_half* A, int lda, const clora_half* B, clora_half* C, int ldc,
+                      int M, int N, int K, const clora_conv_t* conv, const clora_epilogue_t* epi,
+                      int split_k, int tile_cfg, void* workspace, size_t workspace_bytes, void* stream);
 
 /* dW[N, K] += dY[M,N]^T . gather(X)[M,K]   (fp32 atomics; caller zeroes dW).
  * Weight gradient of the trainable hint-encoder convolutions (reference models.py:470,529,594-597,684:
@@ -85,11 +90,13 @@ int clora_conv_wgrad_f16(const clora_half* dY, int ldy, const clora_half* X, int
 int clora_attn_fwd_f16(const clora_half* q, int ldq, const clora_half* k, int ldk, const clora_half* v, int ldv,
                        clora_half* o, int ldo, float* lse, int B, int H, int Nq, int Nk, int D, float scale,
                        void* stream);
-/* dq/dk/dv given do (autograd of the same lines). delta: [B,H,Nq] fp32 scratch. */
+/* dq/dk/dv given do (autograd of the same lines). delta: [B,H,Nq] fp32 scratch.  workspace (optional,
+ * 2*B*Nk*H*D*4 bytes) lets the dK/dV kernel split its query loop when there are few keys (cross-attention). */
 int clora_attn_bwd_f16(const clora_half* q, int ldq, const clora_half* k, int ldk, const clora_half* v, int ldv,
                        const clora_half* o, int ldo, const clora_half* dO, int lddo, const float* lse,
                        float* delta, clora_half* dq, int lddq, clora_half* dk, int lddk, clora_half* dv, int lddv,
-                       int B, int H, int Nq, int Nk, int D, float scale, void* stream);
+                       int B, int H, int Nq, int Nk, int D, float scale, void* workspace, size_t workspace_bytes,
+                       void* stream);
 
 /* ---- GroupNorm (+ optional SiLU), NHWC.  Replaces torch GroupNorm + F.silu pairs
  * (upstream ResnetBlock2D / Transformer2DModel.norm / conv_norm_out; reference models.py:515-516,537-543).
@@ -97,7 +104,8 @@ int clora_attn_bwd_f16(const clora_half* q, int ldq, const clora_half* k, int ld
 int clora_groupnorm_fwd_f16(const clora_half* x, clora_half* y, const float* gamma, const float* beta, float* stats,
                             int B, int HW, int C, int G, float eps, int fuse_silu, void* workspace,
                             size_t workspace_bytes, void* stream);
-/* dx (and, when dgamma != NULL, dgamma/dbeta += ... fp32 atomics; caller zeroes them). */
+/* dx (and, when dgamma != NULL, dgamma/dbeta are WRITTEN: deterministic two-stage reduction, no atomics). */
+size_t clora_groupnorm_workspace_bytes(int B, int HW, int C, int G, int backward, int param_grads);
 int clora_groupnorm_bwd_f16(const clora_half* x, const clora_half* dy, clora_half* dx, const float* gamma,
                             const float* beta, const float* stats, float* dgamma, float* dbeta, int B, int HW, int C,
                             int G, int fuse_silu, void* workspace, size_t workspace_bytes, void* stream);

@@ -79,6 +79,7 @@ static inline hipemu_floatx4 __builtin_amdgcn_mfma_f32_16x16x32_f16(hipemu_half8
     return hipemu::mfma_16x16x32_f16(a, b, c);
 }
 
+static inline int __builtin_amdgcn_readfirstlane(int x) { return x; }
 static inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }
 static inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v; return o; }
 static inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }

@@ -34,7 +34,8 @@ def test_conv_small_channels():
 
 
 @pytest.mark.parametrize("B,H,Nq,Nk,D,fused", [(1, 2, 70, 70, 40, True), (2, 2, 64, 77, 40, False), (1, 2, 33, 130, 80, False),
-                                               (1, 1, 40, 40, 160, True), (1, 2, 20, 20, 8, False), (1, 1, 150, 77, 64, False)])
+                                               (1, 1, 40, 40, 160, True), (1, 2, 20, 20, 8, False), (1, 1, 150, 77, 64, False),
+                                               (1, 2, 640, 77, 40, False)])
 def test_attention(B, H, Nq, Nk, D, fused):
     KC.case_attention("cpu", B, H, Nq, Nk, D, fused_qkv=fused)
 

@@ -42,22 +42,39 @@ def report(name, secs, flops=None, bytes_=None):
     print(json.dumps(r), flush=True)
 
 
-def bench_gemm(name, M, N, Kd, split=None):
+SWEEP = False
+
+
+def _sweep_or_auto(name, fn, flops, nbytes):
+    s = timeit(lambda: fn(0, 0))
+    report(f"{name} auto", s, flops, nbytes)
+    if SWEEP:
+        for tile in (1, 2, 3):
+            for split in (1, 2, 4, 8):
+                try:
+                    s = timeit(lambda: fn(split, tile), iters=8, warm=2)
+                except Exception as e:      # workspace too small etc.
+                    continue
+                report(f"{name} tile={tile} sk={split}", s, flops, nbytes)
+
+
+def bench_gemm(name, M, N, Kd):
     A = torch.randn(M, Kd, device=dev).half()
     B = (torch.randn(N, Kd, device=dev) / math.sqrt(Kd)).half()
     out = torch.empty(M, N, device=dev, dtype=f16)
-    s = timeit(lambda: K.gemm(A, B, M, N, Kd, out=out, split_k=split))
-    report(f"gemm {name} {M}x{N}x{Kd} sk={split}", s, 2.0 * M * N * Kd, 2.0 * (M * Kd + N * Kd + M * N))
+    _sweep_or_auto(f"gemm {name} {M}x{N}x{Kd}", lambda sk, tc: K.gemm(A, B, M, N, Kd, out=out, split_k=sk, tile_cfg=tc),
+                   2.0 * M * N * Kd, 2.0 * (M * Kd + N * Kd + M * N))
 
 
-def bench_conv(name, Bn, H, Ci, Co, split=None):
+def bench_conv(name, Bn, H, Ci, Co):
     x = torch.randn(Bn, H * H, Ci, device=dev).half()
     w = (torch.randn(Co, 9 * Ci, device=dev) / math.sqrt(9 * Ci)).half()
     cd, Ho, Wo = K.conv_fwd_desc(H, H, Ci)
     M = Bn * Ho * Wo
     out = torch.empty(M, Co, device=dev, dtype=f16)
-    s = timeit(lambda: K.gemm(x, w, M, Co, 9 * Ci, conv=cd, out=out, split_k=split))
-    report(f"conv3x3 {name} B{Bn} {H}^2 {Ci}->{Co} sk={split}", s, 2.0 * M * Co * 9 * Ci, 2.0 * (M * Ci + Co * 9 * Ci + M * Co))
+    _sweep_or_auto(f"conv3x3 {name} B{Bn} {H}^2 {Ci}->{Co}",
+                   lambda sk, tc: K.gemm(x, w, M, Co, 9 * Ci, conv=cd, out=out, split_k=sk, tile_cfg=tc),
+                   2.0 * M * Co * 9 * Ci, 2.0 * (M * Ci + Co * 9 * Ci + M * Co))
 
 
 def bench_attn(B, H, N, Nk, D):
@@ -101,6 +118,8 @@ def bench_lora(M, Kd):
 
 if __name__ == "__main__":
     torch.manual_seed(0)
+    SWEEP = "--sweep" in sys.argv
+    sys.argv = [a for a in sys.argv if a != "--sweep"]
     Bn = 4
     bench_gemm("qkv.s0", Bn * 4096, 960, 320)
     bench_gemm("out.s0", Bn * 4096, 320, 320)
@@ -124,6 +143,8 @@ if __name__ == "__main__":
     bench_norm(Bn, 4096, 320)
     bench_norm(Bn, 1024, 640)
     bench_lora(Bn * 4096, 320)
+    bench_norm(Bn, 262144, 32)
+    bench_attn(Bn, 8, 1024, 77, 80)
     if len(sys.argv) > 1:
         with open(sys.argv[1], "w") as f:
             json.dump(rows, f, indent=1)
