@@ -351,17 +351,18 @@ int launch_gemm(GemmArgs& a, int splits, hipStream_t s) {
 }  // namespace
 
 // ---- launch planning --------------------------------------------------------------------------------
-// Tile shape and split-K are chosen by a small cost model: time ~ ceil(blocks / 256 CUs) * (tile MACs /
-// per-CU rate of that tile shape) + split-K reduction traffic.  The per-shape efficiencies were calibrated
-// with tools/kbench.py on MI355X (see profiles/): bigger tiles amortise LDS traffic better, smaller tiles
-// and split-K fill the chip when M*N alone gives fewer than ~256 tiles (the 8x8 / 16x16 UNet levels are
-// weight-streaming problems: M = 256..1024 rows against 3-59 MB of weights).
+// Tile shape and split-K come from a latency model calibrated with tools/kbench.py --sweep on MI355X
+// (profiles/kbench_r01.json): with the single-stage register prefetch of this kernel one BK=32 step costs a
+// roughly constant t_k (global-load latency bound) per resident block, and a CU keeps `conc` blocks of a
+// given tile shape in flight, so
+//     time = ceil(blocks / (256 * conc)) * (k_steps * t_k + t_fix)  +  split-K reduction traffic.
+// Predictions are within ~15% of the sweep for the 15 UNet shapes; the model prefers split-K whenever
+// M*N alone gives fewer than ~3 blocks per CU (the 16x16 / 8x8 UNet levels are weight-streaming problems).
 namespace {
-struct TileCfg { int bm, bn; double eff; };
-const TileCfg kTiles[3] = {{128, 128, 0.34}, {128, 64, 0.26}, {64, 64, 0.17}};
+struct TileCfg { int bm, bn, conc; double t_k; };
+const TileCfg kTiles[3] = {{128, 128, 3, 0.95e-6}, {128, 64, 5, 0.92e-6}, {64, 64, 7, 0.62e-6}};
 
 void plan_gemm(int M, int N, int K, int max_split, int& tile, int& splits) {
-    const double cu_rate = 2500.0e12 / 256.0;
     const int ksteps = clora_cdiv(K, 32);
     double best = 1e30;
     tile = 0; splits = 1;
@@ -369,12 +370,13 @@ void plan_gemm(int M, int N, int K, int max_split, int& tile, int& splits) {
         const TileCfg& tc = kTiles[c];
         const long tiles = (long)clora_cdiv(M, tc.bm) * clora_cdiv(N, tc.bn);
         for (int s = 1; s <= max_split && s <= 16; ++s) {
-            if (s > 1 && ksteps / s < 8) break;
-            const int kps = clora_cdiv(ksteps, s) * 32;
-            const int real_s = clora_cdiv(K, kps);
+            if (s > 1 && ksteps / s < 4) break;
+            const int kps = clora_cdiv(ksteps, s);
+            const int real_s = clora_cdiv(ksteps, kps);
             const long blocks = tiles * real_s;
-            double t = (double)((blocks + 255) / 256) * (2.0 * tc.bm * tc.bn * kps) / (cu_rate * tc.eff) + 2.0e-6;
-            if (real_s > 1) t += (double)M * N * 8.0 * real_s / 2.5e12 + 3.0e-6;
+            const long rounds = (blocks + 256L * tc.conc - 1) / (256L * tc.conc);
+            double t = (double)rounds * (kps * tc.t_k + 3.0e-6);
+            if (real_s > 1) t += (double)M * N * (8.0 * real_s + 2.0) / 6.0e12 + 4.0e-6;
             if (t < best) { best = t; tile = c; splits = real_s; }
         }
     }

@@ -8,57 +8,57 @@
 //                                        share X write disjoint column ranges of one T buffer
 //   up   : acc += s * T . U^T            inside the projection GEMM epilogue (clora_gemm.hip)
 //   up (explicit) for the control term   hidden + s*to_control(ctrl)     (this file)
-//   wgrad: dU = s * dY^T . T,  dD = dT^T . X    skinny reductions over M with fp32 atomics (this file)
+//   wgrad: dU = s * dY^T . T,  dD = dT^T . X    skinny reductions over M, two-stage and deterministic (this file)
 #include "clora_common.h"
 #include "../../include/clora.h"
 
 namespace {
 
-// one thread = one row m; X is staged through LDS in [256 x 64] tiles so global reads stay coalesced; the
-// adapter matrix D is wave-uniform and read with SCALAR loads straight into SGPR operands of v_pk_fma_f32
-// (the __restrict__ kernel arguments are what lets hipcc prove that) -- no LDS traffic for D at all.
-template <int RT>
+// T[m, toff+j] (+)= sum_k X[m,k] * D[j,k] on the matrix cores with fp32-equivalent accuracy:
+// D (fp32) is split on the fly into hi + lo fp16 halves (|D - hi - lo| <= 2^-22 |D|), X is exact fp16, products
+// are exact in the fp32 accumulator -- two v_mfma_f32_16x16x32_f16 per k-step.  One wave = 16 rows, fragments
+// are loaded straight from global (16 B per lane, 64-B row segments), no LDS: the kernel is a pure stream
+// over X with 1024 independent waves at the 64x64 level.
 __global__ __launch_bounds__(256) void lora_down_kernel(const half_t* __restrict__ X, const float* __restrict__ D,
                                                         float* __restrict__ T, int ldx, int ldd, int ldt, int toff, int M,
                                                         int K, int R, int accumulate, int x_rows) {
-    constexpr int BKC = 64, LDX = BKC + 8;
-    __shared__ __attribute__((aligned(16))) half_t Xs[256 * LDX];
-    const int t = threadIdx.x;
-    const int m0 = blockIdx.x * 256;
-    float acc[RT];
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63, g = l >> 4, li = l & 15;
+    const int m0 = (blockIdx.x * 4 + w) * 16;
+    const int m = m0 + li;
+    const bool mok = m < M;
+    const size_t xoff = (size_t)(mok ? (x_rows > 0 ? m % x_rows : m) : 0) * ldx;
+    const bool jok = li < R;
+    const float* drow = D + (size_t)(jok ? li : 0) * ldd;
+    floatx4 acc = zero4f();
+    for (int k0 = 0; k0 < K; k0 += 32) {
+        const int k = k0 + g * 8;
+        half8 a = zero8(), bh = zero8(), bl = zero8();
+        if (k < K) {                       // K % 8 == 0: a chunk is all-valid or all-out
+            if (mok) a = ld8(X + xoff + k);
+            if (jok) {
+                const floatx4 d0 = *reinterpret_cast<const floatx4*>(drow + k);
+                const floatx4 d1 = *reinterpret_cast<const floatx4*>(drow + k + 4);
 #pragma unroll
-    for (int j = 0; j < RT; ++j) acc[j] = 0.f;
-    for (int k0 = 0; k0 < K; k0 += BKC) {
-        __syncthreads();
-        for (int c = t; c < 256 * 8; c += 256) {
-            const int row = c >> 3, col = (c & 7) * 8;
-            const int m = m0 + row;
-            half8 v = zero8();
-            if (m < M && k0 + col < K) {
-                const int xr = x_rows > 0 ? m % x_rows : m;
-                v = ld8(X + (size_t)xr * ldx + k0 + col);
-            }
-            st8(Xs + row * LDX + col, v);
-        }
-        __syncthreads();
-        const int kc_end = (K - k0 < BKC) ? (K - k0) / 8 : 8;   // K % 8 == 0
-        for (int c8 = 0; c8 < kc_end; ++c8) {
-            const half8 v = ld8(Xs + t * LDX + c8 * 8);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float xf = (float)v[e];
-#pragma unroll
-                for (int j = 0; j < RT; ++j)
-                    if (j < R) acc[j] += xf * D[(size_t)j * ldd + k0 + c8 * 8 + e];
+                for (int e = 0; e < 4; ++e) {
+                    const half_t h0 = (half_t)d0[e], h1 = (half_t)d1[e];
+                    bh[e] = h0; bh[4 + e] = h1;
+                    bl[e] = (half_t)(d0[e] - (float)h0); bl[4 + e] = (half_t)(d1[e] - (float)h1);
+                }
             }
         }
+        acc = mfma16(a, bh, acc);
+        acc = mfma16(a, bl, acc);
     }
-    const int m = m0 + t;
-    if (m < M) {
-        float* out = T + (size_t)m * ldt + toff;
+    // C layout: lane holds T[m0 + 4g + r][toff + li]
+    if (jok) {
 #pragma unroll
-        for (int j = 0; j < RT; ++j)
-            if (j < R) out[j] = accumulate ? out[j] + acc[j] : acc[j];
+        for (int r = 0; r < 4; ++r) {
+            const int mm = m0 + 4 * g + r;
+            if (mm < M) {
+                float* out = T + (size_t)mm * ldt + toff + li;
+                *out = accumulate ? *out + acc[r] : acc[r];
+            }
+        }
     }
 }
 
@@ -102,87 +102,85 @@ __global__ __launch_bounds__(256) void lora_up_kernel(UpArgs p) {
     }
 }
 
-// G[n*gs_n + j*gs_j] += scale * sum_m A[m, n] * T[m, toff + j]
-// block = 128 columns x rows_per_block rows; wave w takes rows == w (mod 4), 8 rows in flight per wave (memory
-// level parallelism: these reductions are pure HBM streams); lane owns 2 columns; the T row is wave-uniform
-// (scalar loads); the 4 waves are combined in LDS so each block issues one atomic per output element.
+// G[n*gs_n + j*gs_j] += scale * sum_m A[m, n] * T[m, toff + j]      (adapter weight gradients)
+// Pure HBM stream over A.  One WAVE per block: lane owns 8 columns (16-byte loads, a wave spans 512 columns),
+// 8 rows in flight; the T row is wave-uniform (scalar loads); each block writes its partial [N, RT] slab to the
+// workspace and a second kernel folds the slabs in a fixed order -- no atomics, bit-reproducible gradients.
 template <int RT>
-__global__ __launch_bounds__(256) void lora_wgrad_kernel(const half_t* __restrict__ A, const float* __restrict__ T,
-                                                         float* __restrict__ G, int lda, int ldt, int toff, int gs_n,
-                                                         int gs_j, int M, int N, int R, int a_rows, int rows_per_block,
-                                                         float scale) {
-    __shared__ float red[3 * 64 * 2 * RT];
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l = threadIdx.x & 63;
-    const int n = blockIdx.x * 128 + 2 * l;
+__global__ __launch_bounds__(64) void lora_wgrad_kernel(const half_t* __restrict__ A, const float* __restrict__ T,
+                                                        float* __restrict__ part, int lda, int ldt, int toff, int M, int N,
+                                                        int R, int a_rows, int rows_per_block) {
+    const int l = threadIdx.x;
+    const int n = (blockIdx.x * 64 + l) * 8;
     const int m_beg = blockIdx.y * rows_per_block;
     const int m_end = (m_beg + rows_per_block < M) ? m_beg + rows_per_block : M;
-    const bool nok = n < N;  // N is even
-    float acc0[RT], acc1[RT];
+    const bool nok = n < N;  // N % 8 == 0
+    float acc[8][RT];
 #pragma unroll
-    for (int j = 0; j < RT; ++j) { acc0[j] = 0.f; acc1[j] = 0.f; }
+    for (int e = 0; e < 8; ++e)
+#pragma unroll
+        for (int j = 0; j < RT; ++j) acc[e][j] = 0.f;
     constexpr int UN = 8;
-    for (int mb = m_beg + w; mb < m_end; mb += 4 * UN) {
-        half2v a[UN];
+    for (int mb = m_beg; mb < m_end; mb += UN) {
+        half8 a[UN];
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
-            const int m = mb + 4 * u;
-            half2v z = {0, 0};
-            a[u] = z;
+            const int m = mb + u;
+            a[u] = zero8();
             if (nok && m < m_end) {
                 const int ar = a_rows > 0 ? m % a_rows : m;
-                a[u] = *reinterpret_cast<const half2v*>(A + (size_t)ar * lda + n);
+                a[u] = ld8(A + (size_t)ar * lda + n);
             }
         }
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
-            const int m = mb + 4 * u;
+            const int m = mb + u;
             if (m < m_end) {
-                const float a0 = (float)a[u][0], a1 = (float)a[u][1];
                 const float* tr = T + (size_t)m * ldt + toff;
 #pragma unroll
                 for (int j = 0; j < RT; ++j)
-                    if (j < R) { const float tv = tr[j]; acc0[j] += a0 * tv; acc1[j] += a1 * tv; }
+                    if (j < R) {
+                        const float tv = tr[j];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) acc[e][j] += (float)a[u][e] * tv;
+                    }
             }
         }
     }
-    if (w > 0) {
+    if (nok) {
+        float* out = part + ((size_t)blockIdx.y * N + n) * RT;
 #pragma unroll
-        for (int j = 0; j < RT; ++j) {
-            red[(((w - 1) * 64 + l) * 2 + 0) * RT + j] = acc0[j];
-            red[(((w - 1) * 64 + l) * 2 + 1) * RT + j] = acc1[j];
-        }
+        for (int e = 0; e < 8; ++e)
+#pragma unroll
+            for (int j = 0; j < RT; ++j) out[e * RT + j] = acc[e][j];
     }
-    __syncthreads();
-    if (w == 0 && nok) {
-#pragma unroll
-        for (int j = 0; j < RT; ++j)
-            if (j < R) {
-                float s0 = acc0[j], s1 = acc1[j];
-#pragma unroll
-                for (int ww = 0; ww < 3; ++ww) {
-                    s0 += red[((ww * 64 + l) * 2 + 0) * RT + j];
-                    s1 += red[((ww * 64 + l) * 2 + 1) * RT + j];
-                }
-                atomicAdd(G + (size_t)n * gs_n + (size_t)j * gs_j, scale * s0);
-                atomicAdd(G + (size_t)(n + 1) * gs_n + (size_t)j * gs_j, scale * s1);
-            }
-    }
+}
+
+__global__ __launch_bounds__(256) void lora_wgrad_finish_kernel(const float* __restrict__ part, float* __restrict__ G,
+                                                                int nblk, int N, int RT, int R, int gs_n, int gs_j,
+                                                                float scale) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N * RT) return;
+    const int n = i / RT, j = i - n * RT;
+    if (j >= R) return;
+    float s = 0.f;
+    for (int b = 0; b < nblk; ++b) s += part[(size_t)b * N * RT + i];
+    float* o = G + (size_t)n * gs_n + (size_t)j * gs_j;
+    *o += scale * s;
 }
 
 }  // namespace
 
 extern "C" int clora_lora_down_f16(const clora_half* X, int ldx, const float* D, int ldd, float* T, int ldt, int toff,
                                    int M, int K, int R, int accumulate, int x_rows, void* stream) {
-    if (!X || !D || !T || M <= 0 || K <= 0 || R <= 0 || (K & 7) || (ldx & 7)) return CLORA_ERR_ARG;
+    if (!X || !D || !T || M <= 0 || K <= 0 || R <= 0 || (K & 7) || (ldx & 7) || (ldd & 3) ||
+        ((uintptr_t)D & 15))
+        return CLORA_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
-    const half_t* Xh = (const half_t*)X;
     for (int r0 = 0; r0 < R; r0 += 16) {  // ranks > 16 (danbooru-sketch control_rank 256) take several passes over X
-        const float* Dp = D + (size_t)r0 * ldd;
-        const int Rp = (R - r0 < 16) ? R - r0 : 16, to = toff + r0;
-        const dim3 grid(clora_cdiv(M, 256));
-        if (Rp <= 4) hipLaunchKernelGGL((lora_down_kernel<4>), grid, dim3(256), 0, s, Xh, Dp, T, ldx, ldd, ldt, to, M, K, Rp, accumulate, x_rows);
-        else if (Rp <= 8) hipLaunchKernelGGL((lora_down_kernel<8>), grid, dim3(256), 0, s, Xh, Dp, T, ldx, ldd, ldt, to, M, K, Rp, accumulate, x_rows);
-        else hipLaunchKernelGGL((lora_down_kernel<16>), grid, dim3(256), 0, s, Xh, Dp, T, ldx, ldd, ldt, to, M, K, Rp, accumulate, x_rows);
+        const int Rp = (R - r0 < 16) ? R - r0 : 16;
+        hipLaunchKernelGGL(lora_down_kernel, dim3(clora_cdiv(M, 64)), dim3(256), 0, s, (const half_t*)X,
+                           D + (size_t)r0 * ldd, T, ldx, ldd, ldt, toff + r0, M, K, Rp, accumulate, x_rows);
     }
     return clora_check_launch();
 }
@@ -199,20 +197,32 @@ extern "C" int clora_lora_up_f16(const clora_half* base, int ldb, const float* T
     return clora_check_launch();
 }
 
+extern "C" size_t clora_lora_wgrad_workspace_bytes(int M, int N, int R) {
+    int rpb = 32;
+    while ((long)clora_cdiv(N, 512) * clora_cdiv(M, rpb) > 2048) rpb *= 2;
+    const int rt = R <= 4 ? 4 : (R <= 8 ? 8 : 16);
+    return (size_t)clora_cdiv(M, rpb) * N * rt * sizeof(float);
+}
+
 extern "C" int clora_lora_wgrad_f16(const clora_half* A, int lda, const float* T, int ldt, int toff, float* G, int gs_n,
-                                    int gs_j, int M, int N, int R, float scale, int a_rows, void* stream) {
-    if (!A || !T || !G || M <= 0 || N <= 0 || R <= 0 || (N & 7) || (lda & 1)) return CLORA_ERR_ARG;
+                                    int gs_j, int M, int N, int R, float scale, int a_rows, void* workspace,
+                                    size_t workspace_bytes, void* stream) {
+    if (!A || !T || !G || M <= 0 || N <= 0 || R <= 0 || (N & 7) || (lda & 7)) return CLORA_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
-    const half_t* Ah = (const half_t*)A;
-    int rpb = 128;
-    while (rpb < 1024 && (long)clora_cdiv(N, 128) * clora_cdiv(M, rpb) > 1024) rpb *= 2;
+    int rpb = 32;
+    while ((long)clora_cdiv(N, 512) * clora_cdiv(M, rpb) > 2048) rpb *= 2;
+    const int nblk = clora_cdiv(M, rpb);
     for (int r0 = 0; r0 < R; r0 += 16) {
-        float* Gp = G + (size_t)r0 * gs_j;
         const int Rp = (R - r0 < 16) ? R - r0 : 16, to = toff + r0;
-        const dim3 grid(clora_cdiv(N, 128), clora_cdiv(M, rpb));
-        if (Rp <= 4) hipLaunchKernelGGL((lora_wgrad_kernel<4>), grid, dim3(256), 0, s, Ah, T, Gp, lda, ldt, to, gs_n, gs_j, M, N, Rp, a_rows, rpb, scale);
-        else if (Rp <= 8) hipLaunchKernelGGL((lora_wgrad_kernel<8>), grid, dim3(256), 0, s, Ah, T, Gp, lda, ldt, to, gs_n, gs_j, M, N, Rp, a_rows, rpb, scale);
-        else hipLaunchKernelGGL((lora_wgrad_kernel<16>), grid, dim3(256), 0, s, Ah, T, Gp, lda, ldt, to, gs_n, gs_j, M, N, Rp, a_rows, rpb, scale);
+        const int rt = Rp <= 4 ? 4 : (Rp <= 8 ? 8 : 16);
+        if (!workspace || workspace_bytes < (size_t)nblk * N * rt * sizeof(float)) return CLORA_ERR_WORKSPACE;
+        float* part = (float*)workspace;
+        const dim3 grid(clora_cdiv(N, 512), nblk);
+        if (rt == 4) hipLaunchKernelGGL((lora_wgrad_kernel<4>), grid, dim3(64), 0, s, (const half_t*)A, T, part, lda, ldt, to, M, N, Rp, a_rows, rpb);
+        else if (rt == 8) hipLaunchKernelGGL((lora_wgrad_kernel<8>), grid, dim3(64), 0, s, (const half_t*)A, T, part, lda, ldt, to, M, N, Rp, a_rows, rpb);
+        else hipLaunchKernelGGL((lora_wgrad_kernel<16>), grid, dim3(64), 0, s, (const half_t*)A, T, part, lda, ldt, to, M, N, Rp, a_rows, rpb);
+        hipLaunchKernelGGL(lora_wgrad_finish_kernel, dim3(clora_cdiv(N * rt, 256)), dim3(256), 0, s, part,
+                           G + (size_t)r0 * gs_j, nblk, N, rt, Rp, gs_n, gs_j, scale);
     }
     return clora_check_launch();
 }

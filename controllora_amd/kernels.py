@@ -220,7 +220,7 @@ def lora_down(X, D, T, toff, M, K, accumulate=False, x_rows=0, ldx=None):
     """T[:, toff:toff+R] (+)= X . D^T ; X [rows, K] fp16 (row pitch ldx), D [R, K] fp32, T [M, ldt] fp32."""
     assert D.dtype == f32 and D.stride(1) == 1 and T.dtype == f32 and T.is_contiguous()
     _call("clora_lora_down_f16", ptr(X, f16), ldx if ldx is not None else X.stride(0), ptr(D), D.stride(0), ptr(T),
-          T.shape[1], toff, M, K, D.shape[0], int(accumulate), x_rows)
+          T.shape[1], toff, M, K, D.shape[0], int(accumulate), x_rows, nbytes=2.0 * M * K)
     return T
 
 
@@ -235,8 +235,9 @@ def lora_up(base, T, toff, U, M, N, scale, out=None):
 def lora_wgrad(A, T, toff, G, gs_n, gs_j, M, N, R, scale=1.0, a_rows=0, lda=None):
     """G[n*gs_n + j*gs_j] += scale * sum_m A[m,n] T[m,toff+j]"""
     assert G.dtype == f32 and T.dtype == f32
+    ws = workspace(capi.lib().cdll.clora_lora_wgrad_workspace_bytes(M, N, R), A.device)
     _call("clora_lora_wgrad_f16", ptr(A, f16), lda if lda is not None else A.stride(0), ptr(T), T.shape[1], toff, ptr(G),
-          gs_n, gs_j, M, N, R, float(scale), a_rows)
+          gs_n, gs_j, M, N, R, float(scale), a_rows, ptr(ws), ws.numel(), nbytes=2.0 * M * N)
     return G
 
 
