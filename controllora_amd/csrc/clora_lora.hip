@@ -8,7 +8,7 @@
 //                                        share X write disjoint column ranges of one T buffer
 //   up   : acc += s * T . U^T            inside the projection GEMM epilogue (clora_gemm.hip)
 //   up (explicit) for the control term   hidden + s*to_control(ctrl)     (this file)
-//   wgrad: dU = s * dY^T . T,  dD = dT^T . X    skinny reductions over M, two-stage and deterministic (this file)
+//   wgrad: dU = s * dY^T . T,  dD = dT^T . X    skinny reductions over M (LDS fold + one fp32 atomic per element)
 #include "clora_common.h"
 #include "../../include/clora.h"
 
@@ -103,17 +103,22 @@ __global__ __launch_bounds__(256) void lora_up_kernel(UpArgs p) {
 }
 
 // G[n*gs_n + j*gs_j] += scale * sum_m A[m, n] * T[m, toff + j]      (adapter weight gradients)
-// Pure HBM stream over A.  One WAVE per block: lane owns 8 columns (16-byte loads, a wave spans 512 columns),
-// 8 rows in flight; the T row is wave-uniform (scalar loads); each block writes its partial [N, RT] slab to the
-// workspace and a second kernel folds the slabs in a fixed order -- no atomics, bit-reproducible gradients.
+// Pure HBM stream over A: lane owns 8 columns (16-byte loads, a wave spans 512 columns), every wave keeps 8
+// rows in flight, the T row is wave-uniform (scalar loads).  The 4 waves of a block are folded with LDS atomics
+// and the block adds its [<=512 x R] slab to G with one fp32 atomic per element.
 template <int RT>
-__global__ __launch_bounds__(64) void lora_wgrad_kernel(const half_t* __restrict__ A, const float* __restrict__ T,
-                                                        float* __restrict__ part, int lda, int ldt, int toff, int M, int N,
-                                                        int R, int a_rows, int rows_per_block) {
-    const int l = threadIdx.x;
+__global__ __launch_bounds__(256) void lora_wgrad_kernel(const half_t* __restrict__ A, const float* __restrict__ T,
+                                                         float* __restrict__ G, int lda, int ldt, int toff, int gs_n,
+                                                         int gs_j, int M, int N, int R, int a_rows, int rows_per_block,
+                                                         float scale) {
+    __shared__ float red[64 * 8 * RT];
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l = threadIdx.x & 63;
+    for (int i = threadIdx.x; i < 64 * 8 * RT; i += 256) red[i] = 0.f;
     const int n = (blockIdx.x * 64 + l) * 8;
-    const int m_beg = blockIdx.y * rows_per_block;
-    const int m_end = (m_beg + rows_per_block < M) ? m_beg + rows_per_block : M;
+    const int rpw = rows_per_block / 4;
+    const int m_beg = blockIdx.y * rows_per_block + w * rpw;
+    int m_end = m_beg + rpw;
+    if (m_end > M) m_end = M;
     const bool nok = n < N;  // N % 8 == 0
     float acc[8][RT];
 #pragma unroll
@@ -147,26 +152,20 @@ __global__ __launch_bounds__(64) void lora_wgrad_kernel(const half_t* __restrict
             }
         }
     }
+    __syncthreads();
     if (nok) {
-        float* out = part + ((size_t)blockIdx.y * N + n) * RT;
 #pragma unroll
         for (int e = 0; e < 8; ++e)
 #pragma unroll
-            for (int j = 0; j < RT; ++j) out[e * RT + j] = acc[e][j];
+            for (int j = 0; j < RT; ++j)
+                if (j < R) atomicAdd(&red[(l * 8 + e) * RT + j], acc[e][j]);
     }
-}
-
-__global__ __launch_bounds__(256) void lora_wgrad_finish_kernel(const float* __restrict__ part, float* __restrict__ G,
-                                                                int nblk, int N, int RT, int R, int gs_n, int gs_j,
-                                                                float scale) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= N * RT) return;
-    const int n = i / RT, j = i - n * RT;
-    if (j >= R) return;
-    float s = 0.f;
-    for (int b = 0; b < nblk; ++b) s += part[(size_t)b * N * RT + i];
-    float* o = G + (size_t)n * gs_n + (size_t)j * gs_j;
-    *o += scale * s;
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * 8 * RT; i += 256) {
+        const int col = i / RT, j = i - col * RT;
+        const int nn = blockIdx.x * 512 + col;
+        if (nn < N && j < R) atomicAdd(G + (size_t)nn * gs_n + (size_t)j * gs_j, scale * red[i]);
+    }
 }
 
 }  // namespace
@@ -197,32 +196,19 @@ extern "C" int clora_lora_up_f16(const clora_half* base, int ldb, const float* T
     return clora_check_launch();
 }
 
-extern "C" size_t clora_lora_wgrad_workspace_bytes(int M, int N, int R) {
-    int rpb = 32;
-    while ((long)clora_cdiv(N, 512) * clora_cdiv(M, rpb) > 2048) rpb *= 2;
-    const int rt = R <= 4 ? 4 : (R <= 8 ? 8 : 16);
-    return (size_t)clora_cdiv(M, rpb) * N * rt * sizeof(float);
-}
-
 extern "C" int clora_lora_wgrad_f16(const clora_half* A, int lda, const float* T, int ldt, int toff, float* G, int gs_n,
-                                    int gs_j, int M, int N, int R, float scale, int a_rows, void* workspace,
-                                    size_t workspace_bytes, void* stream) {
+                                    int gs_j, int M, int N, int R, float scale, int a_rows, void* stream) {
     if (!A || !T || !G || M <= 0 || N <= 0 || R <= 0 || (N & 7) || (lda & 7)) return CLORA_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
-    int rpb = 32;
-    while ((long)clora_cdiv(N, 512) * clora_cdiv(M, rpb) > 2048) rpb *= 2;
-    const int nblk = clora_cdiv(M, rpb);
+    int rpb = 32;   // 4 waves x 8 rows; grow until the grid is at most ~512 blocks
+    while ((long)clora_cdiv(N, 512) * clora_cdiv(M, rpb) > 512) rpb *= 2;
     for (int r0 = 0; r0 < R; r0 += 16) {
         const int Rp = (R - r0 < 16) ? R - r0 : 16, to = toff + r0;
-        const int rt = Rp <= 4 ? 4 : (Rp <= 8 ? 8 : 16);
-        if (!workspace || workspace_bytes < (size_t)nblk * N * rt * sizeof(float)) return CLORA_ERR_WORKSPACE;
-        float* part = (float*)workspace;
-        const dim3 grid(clora_cdiv(N, 512), nblk);
-        if (rt == 4) hipLaunchKernelGGL((lora_wgrad_kernel<4>), grid, dim3(64), 0, s, (const half_t*)A, T, part, lda, ldt, to, M, N, Rp, a_rows, rpb);
-        else if (rt == 8) hipLaunchKernelGGL((lora_wgrad_kernel<8>), grid, dim3(64), 0, s, (const half_t*)A, T, part, lda, ldt, to, M, N, Rp, a_rows, rpb);
-        else hipLaunchKernelGGL((lora_wgrad_kernel<16>), grid, dim3(64), 0, s, (const half_t*)A, T, part, lda, ldt, to, M, N, Rp, a_rows, rpb);
-        hipLaunchKernelGGL(lora_wgrad_finish_kernel, dim3(clora_cdiv(N * rt, 256)), dim3(256), 0, s, part,
-                           G + (size_t)r0 * gs_j, nblk, N, rt, Rp, gs_n, gs_j, scale);
+        float* Gp = G + (size_t)r0 * gs_j;
+        const dim3 grid(clora_cdiv(N, 512), clora_cdiv(M, rpb));
+        if (Rp <= 4) hipLaunchKernelGGL((lora_wgrad_kernel<4>), grid, dim3(256), 0, s, (const half_t*)A, T, Gp, lda, ldt, to, gs_n, gs_j, M, N, Rp, a_rows, rpb, scale);
+        else if (Rp <= 8) hipLaunchKernelGGL((lora_wgrad_kernel<8>), grid, dim3(256), 0, s, (const half_t*)A, T, Gp, lda, ldt, to, gs_n, gs_j, M, N, Rp, a_rows, rpb, scale);
+        else hipLaunchKernelGGL((lora_wgrad_kernel<16>), grid, dim3(256), 0, s, (const half_t*)A, T, Gp, lda, ldt, to, gs_n, gs_j, M, N, Rp, a_rows, rpb, scale);
     }
     return clora_check_launch();
 }
