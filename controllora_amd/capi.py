@@ -35,14 +35,14 @@ class Epilogue(C.Structure):
     """mirror of clora_epilogue_t"""
     _fields_ = [("bias", C.c_void_p), ("rowadd", C.c_void_p), ("rows_per_batch", C.c_int), ("ld_rowadd", C.c_int),
                 ("residual", C.c_void_p), ("ldr", C.c_int), ("lora_t", C.c_void_p), ("ldt", C.c_int),
-                ("lora_u", C.c_void_p), ("lora_r", C.c_int), ("lora_seg", C.c_int), ("lora_scale", C.c_float)]
+                ("lora_u", C.c_void_p), ("ldu", C.c_int), ("lora_u_tr", C.c_int), ("lora_r", C.c_int), ("lora_seg", C.c_int), ("lora_scale", C.c_float)]
 
 
 _P, _I, _Z, _F = C.c_void_p, C.c_int, C.c_size_t, C.c_float
 _PROTOS = {
     "clora_gemm_f16": [_P, _I, _P, _P, _I, _I, _I, _I, C.POINTER(ConvDesc), C.POINTER(Epilogue), _I, _P, _Z, _P],
     "clora_gemm_f16_ex": [_P, _I, _P, _P, _I, _I, _I, _I, C.POINTER(ConvDesc), C.POINTER(Epilogue), _I, _I, _P, _Z, _P],
-    "clora_conv_wgrad_f16": [_P, _I, _P, _I, _P, _I, _I, _I, C.POINTER(ConvDesc), _P],
+    "clora_conv_wgrad_f16": [_P, _I, _P, _I, _P, _P, _I, _I, _I, C.POINTER(ConvDesc), _P],
     "clora_attn_fwd_f16": [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _F, _P],
     "clora_attn_bwd_f16": [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _F, _P, _Z, _P],
     "clora_groupnorm_fwd_f16": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P, _Z, _P],
@@ -51,8 +51,8 @@ _PROTOS = {
     "clora_layernorm_bwd_f16": [_P, _P, _P, _P, _I, _I, _F, _P],
     "clora_geglu_fwd_f16": [_P, _P, _I, _I, _P],
     "clora_geglu_bwd_f16": [_P, _P, _P, _I, _I, _P],
-    "clora_lora_down_f16": [_P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P],
-    "clora_lora_up_f16": [_P, _I, _P, _I, _I, _P, _I, _P, _I, _I, _I, _I, _F, _P],
+    "clora_lora_down_f16": [_P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P],
+    "clora_lora_up_f16": [_P, _I, _P, _I, _I, _P, _I, _I, _P, _I, _I, _I, _I, _F, _P],
     "clora_lora_wgrad_f16": [_P, _I, _P, _I, _I, _P, _I, _I, _I, _I, _I, _F, _I, _P],
     "clora_add_f16": [_P, _P, _P, _Z, _P],
     "clora_silu_f16": [_P, _P, _Z, _P],

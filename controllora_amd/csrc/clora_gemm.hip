@@ -36,9 +36,14 @@ __device__ __forceinline__ float epi_pre(float acc, int m, int n, const clora_ep
     if (e.lora_t) {
         const int r = e.lora_r;
         const float* t = e.lora_t + (size_t)m * e.ldt + (n / e.lora_seg) * r;
-        const float* u = e.lora_u + (size_t)n * r;
         float s = 0.f;
-        for (int j = 0; j < r; ++j) s += t[j] * u[j];
+        if (e.lora_u_tr) {
+            const float* u = e.lora_u + n;
+            for (int j = 0; j < r; ++j) s += t[j] * u[(size_t)j * e.ldu];
+        } else {
+            const float* u = e.lora_u + (size_t)n * e.ldu;
+            for (int j = 0; j < r; ++j) s += t[j] * u[j];
+        }
         acc += e.lora_scale * s;
     }
     return acc;
@@ -255,6 +260,7 @@ struct WgradArgs {
     const half_t* dY;
     const half_t* X;
     float* dW;
+    float* db;   // optional bias gradient: handled as one extra all-ones input column k == K
     int ldy, ldx, M, N, K;
     int m_per_block;
     int tiles_n, tiles_k;
@@ -280,6 +286,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
     int tap = 0, ci = kcol, ky = 0, kx = 0;
     if (conv) { tap = kcol / p.conv.Cin; ci = kcol - tap * p.conv.Cin; ky = tap / p.conv.ksize; kx = tap - ky * p.conv.ksize; }
     const bool kcol_ok = kcol < p.K;
+    const bool bias_col = p.db != nullptr && kcol == p.K;   // K % 8 == 0: the ones column starts a chunk
     const bool ncol_ok = (n0 + cc) < p.N;
 
     const int w = t >> 6, l = t & 63, g = l >> 4, li = l & 15;
@@ -295,6 +302,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
         half8 va = zero8(), vb = zero8();
         if (m < mend) {
             if (ncol_ok) va = ld8(p.dY + (size_t)m * p.ldy + n0 + cc);
+            if (bias_col) vb[0] = (half_t)1.0f;
             if (kcol_ok) {
                 if (!conv) {
                     vb = ld8(p.X + (size_t)m * p.ldx + kcol);
@@ -337,6 +345,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
                 const int n = n0 + wm * 32 + i * 16 + 4 * g + r;
                 const int kk = k0 + wn * 32 + j * 16 + li;
                 if (n < p.N && kk < p.K) atomicAdd(p.dW + (size_t)n * p.K + kk, acc[i][j][r]);
+                else if (n < p.N && kk == p.K && p.db) atomicAdd(p.db + n, acc[i][j][r]);
             }
 }
 
@@ -439,11 +448,11 @@ extern "C" int clora_gemm_f16(const clora_half* A, int lda, const clora_half* B,
     return clora_gemm_f16_ex(A, lda, B, C, ldc, M, N, K, conv, epi, split_k, 0, workspace, workspace_bytes, stream);
 }
 
-extern "C" int clora_conv_wgrad_f16(const clora_half* dY, int ldy, const clora_half* X, int ldx, float* dW, int M,
-                                    int N, int K, const clora_conv_t* conv, void* stream) {
+extern "C" int clora_conv_wgrad_f16(const clora_half* dY, int ldy, const clora_half* X, int ldx, float* dW, float* db,
+                                    int M, int N, int K, const clora_conv_t* conv, void* stream) {
     if (!dY || !X || !dW || M <= 0 || N <= 0 || K <= 0 || (K & 7) || (N & 7) || (ldy & 7)) return CLORA_ERR_ARG;
     WgradArgs a;
-    a.dY = (const half_t*)dY; a.X = (const half_t*)X; a.dW = dW;
+    a.dY = (const half_t*)dY; a.X = (const half_t*)X; a.dW = dW; a.db = db;
     a.ldy = ldy; a.ldx = ldx; a.M = M; a.N = N; a.K = K;
     if (conv && conv->enabled) {
         a.conv = *conv;
@@ -454,7 +463,7 @@ extern "C" int clora_conv_wgrad_f16(const clora_half* dY, int ldy, const clora_h
         if (ldx & 7) return CLORA_ERR_ARG;
     }
     a.tiles_n = clora_cdiv(N, 64);
-    a.tiles_k = clora_cdiv(K, 64);
+    a.tiles_k = clora_cdiv(K + (db ? 8 : 0), 64);
     const int tiles = a.tiles_n * a.tiles_k;
     int chunks = clora_cdiv(2048, tiles);              // aim for ~2048 blocks
     int mpb = clora_cdiv(clora_cdiv(M, chunks), 32) * 32;

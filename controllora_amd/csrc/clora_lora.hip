@@ -21,14 +21,15 @@ namespace {
 // over X with 1024 independent waves at the 64x64 level.
 __global__ __launch_bounds__(256) void lora_down_kernel(const half_t* __restrict__ X, const float* __restrict__ D,
                                                         float* __restrict__ T, int ldx, int ldd, int ldt, int toff, int M,
-                                                        int K, int R, int accumulate, int x_rows) {
+                                                        int K, int R, int accumulate, int x_rows, int d_kmajor,
+                                                        float dscale) {
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63, g = l >> 4, li = l & 15;
     const int m0 = (blockIdx.x * 4 + w) * 16;
     const int m = m0 + li;
     const bool mok = m < M;
     const size_t xoff = (size_t)(mok ? (x_rows > 0 ? m % x_rows : m) : 0) * ldx;
     const bool jok = li < R;
-    const float* drow = D + (size_t)(jok ? li : 0) * ldd;
+    const float* drow = D + (d_kmajor ? (size_t)(jok ? li : 0) : (size_t)(jok ? li : 0) * ldd);
     floatx4 acc = zero4f();
     for (int k0 = 0; k0 < K; k0 += 32) {
         const int k = k0 + g * 8;
@@ -36,8 +37,15 @@ __global__ __launch_bounds__(256) void lora_down_kernel(const half_t* __restrict
         if (k < K) {                       // K % 8 == 0: a chunk is all-valid or all-out
             if (mok) a = ld8(X + xoff + k);
             if (jok) {
-                const floatx4 d0 = *reinterpret_cast<const floatx4*>(drow + k);
-                const floatx4 d1 = *reinterpret_cast<const floatx4*>(drow + k + 4);
+                floatx4 d0, d1;
+                if (d_kmajor) {        // D[j][k] stored at D[k*ldd + j]  (an up-projection matrix [N, r] used as U^T)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { d0[e] = drow[(size_t)(k + e) * ldd]; d1[e] = drow[(size_t)(k + 4 + e) * ldd]; }
+                } else {
+                    d0 = *reinterpret_cast<const floatx4*>(drow + k);
+                    d1 = *reinterpret_cast<const floatx4*>(drow + k + 4);
+                }
+                d0 *= dscale; d1 *= dscale;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const half_t h0 = (half_t)d0[e], h1 = (half_t)d1[e];
@@ -67,7 +75,7 @@ struct UpArgs {
     const float* T;
     const float* U;
     half_t* Y;
-    int ldb, ldt, toff, ldu, ldy, M, N, R;
+    int ldb, ldt, toff, ldu, ldy, M, N, R, u_tr;
     float scale;
 };
 
@@ -84,7 +92,7 @@ __global__ __launch_bounds__(256) void lora_up_kernel(UpArgs p) {
         for (int j = 0; j < p.R; ++j) {
             const float tv = tr[j];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) acc[e] += tv * p.U[(size_t)(n + e) * p.ldu + j];
+            for (int e = 0; e < 8; ++e) acc[e] += tv * (p.u_tr ? p.U[(size_t)j * p.ldu + n + e] : p.U[(size_t)(n + e) * p.ldu + j]);
         }
         half8 o;
         if (p.base) {
@@ -171,25 +179,28 @@ __global__ __launch_bounds__(256) void lora_wgrad_kernel(const half_t* __restric
 }  // namespace
 
 extern "C" int clora_lora_down_f16(const clora_half* X, int ldx, const float* D, int ldd, float* T, int ldt, int toff,
-                                   int M, int K, int R, int accumulate, int x_rows, void* stream) {
-    if (!X || !D || !T || M <= 0 || K <= 0 || R <= 0 || (K & 7) || (ldx & 7) || (ldd & 3) ||
-        ((uintptr_t)D & 15))
-        return CLORA_ERR_ARG;
+                                   int M, int K, int R, int accumulate, int x_rows, int d_kmajor, float d_scale,
+                                   void* stream) {
+    if (!X || !D || !T || M <= 0 || K <= 0 || R <= 0 || (K & 7) || (ldx & 7)) return CLORA_ERR_ARG;
+    if (!d_kmajor && ((ldd & 3) || ((uintptr_t)D & 15))) return CLORA_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     for (int r0 = 0; r0 < R; r0 += 16) {  // ranks > 16 (danbooru-sketch control_rank 256) take several passes over X
         const int Rp = (R - r0 < 16) ? R - r0 : 16;
         hipLaunchKernelGGL(lora_down_kernel, dim3(clora_cdiv(M, 64)), dim3(256), 0, s, (const half_t*)X,
-                           D + (size_t)r0 * ldd, T, ldx, ldd, ldt, toff + r0, M, K, Rp, accumulate, x_rows);
+                           d_kmajor ? D + r0 : D + (size_t)r0 * ldd, T, ldx, ldd, ldt, toff + r0, M, K, Rp, accumulate,
+                           x_rows, d_kmajor, d_scale);
     }
     return clora_check_launch();
 }
 
 extern "C" int clora_lora_up_f16(const clora_half* base, int ldb, const float* T, int ldt, int toff, const float* U,
-                                 int ldu, clora_half* Y, int ldy, int M, int N, int R, float scale, void* stream) {
+                                 int ldu, int u_transposed, clora_half* Y, int ldy, int M, int N, int R, float scale,
+                                 void* stream) {
     if (!T || !U || !Y || M <= 0 || N <= 0 || R <= 0 || (N & 7) || (ldy & 7) || (base && (ldb & 7))) return CLORA_ERR_ARG;
     UpArgs a;
     a.base = (const half_t*)base; a.T = T; a.U = U; a.Y = (half_t*)Y;
     a.ldb = ldb; a.ldt = ldt; a.toff = toff; a.ldu = ldu; a.ldy = ldy; a.M = M; a.N = N; a.R = R; a.scale = scale;
+    a.u_tr = u_transposed;
     size_t blocks = ((size_t)M * (N / 8) + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(lora_up_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);

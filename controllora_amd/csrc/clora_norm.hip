@@ -245,17 +245,27 @@ __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(GnArgs p) {
     }
 }
 
-// ---- backward, trainable affine: dgamma[c] = sum_{b,chunk} a2, dbeta[c] = sum a1  (fixed order)
+// ---- backward, trainable affine: dgamma[c] = sum_{b,chunk} a2, dbeta[c] = sum a1  (fixed order: 8 interleaved
+// partial sums per channel folded through LDS; one block = 32 channels)
 __global__ __launch_bounds__(256) void gn_bwd_params_kernel(GnArgs p) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= p.C) return;
+    __shared__ float red[256 * 2];
+    const int t = threadIdx.x, cl = t & 31, part = t >> 5;
+    const int c = blockIdx.x * 32 + cl;
     float sa = 0.f, sb = 0.f;
-    for (int i = 0; i < p.B * p.nchunk; ++i) {
-        const float* pp = p.chpart + ((size_t)i * p.C + c) * 2;
-        sa += pp[0]; sb += pp[1];
+    if (c < p.C) {
+        const int n = p.B * p.nchunk;
+        for (int i = part; i < n; i += 8) {
+            const float* pp = p.chpart + ((size_t)i * p.C + c) * 2;
+            sa += pp[0]; sb += pp[1];
+        }
     }
-    p.dbeta[c] = sa;
-    p.dgamma[c] = sb;
+    red[t * 2] = sa; red[t * 2 + 1] = sb;
+    __syncthreads();
+    if (part == 0 && c < p.C) {
+        for (int q = 1; q < 8; ++q) { sa += red[(q * 32 + cl) * 2]; sb += red[(q * 32 + cl) * 2 + 1]; }
+        p.dbeta[c] = sa;
+        p.dgamma[c] = sb;
+    }
 }
 
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(GnArgs p) {
@@ -434,7 +444,7 @@ extern "C" int clora_groupnorm_bwd_f16(const clora_half* x, const clora_half* dy
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(gn_bwd_partial_kernel, dim3(a.nchunk, B), dim3(256), 0, s, a);
     hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(B), dim3(256), 0, s, a);
-    if (dgamma) hipLaunchKernelGGL(gn_bwd_params_kernel, dim3(clora_cdiv(C, 256)), dim3(256), 0, s, a);
+    if (dgamma) hipLaunchKernelGGL(gn_bwd_params_kernel, dim3(clora_cdiv(C, 32)), dim3(256), 0, s, a);
     hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(ew_blocks((size_t)B * HW * (C / 8))), dim3(256), 0, s, a);
     return clora_check_launch();
 }

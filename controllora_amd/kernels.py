@@ -96,7 +96,8 @@ GEMM_WS_BYTES = 256 << 20   # split-K slab budget handed to the library's launch
 
 def gemm(A: torch.Tensor, Bw: torch.Tensor, M: int, N: int, K: int, *, lda: Optional[int] = None,
          conv: Optional[ConvDesc] = None, bias=None, rowadd=None, rows_per_batch=0, residual=None,
-         lora_t=None, lora_u=None, lora_seg=0, lora_scale=1.0, out: Optional[torch.Tensor] = None,
+         lora_t=None, lora_u=None, lora_seg=0, lora_scale=1.0, lora_u_tr=False, lora_r=None,
+         out: Optional[torch.Tensor] = None,
          split_k: int = 0, tile_cfg: int = 0) -> torch.Tensor:
     """C[M,N] = A . Bw^T with the fused epilogue of clora_epilogue_t."""
     assert A.dtype == f16 and Bw.dtype == f16 and Bw.shape == (N, K) and Bw.is_contiguous()
@@ -114,8 +115,9 @@ def gemm(A: torch.Tensor, Bw: torch.Tensor, M: int, N: int, K: int, *, lda: Opti
         assert residual.dtype == f16 and residual.stride(-1) == 1
         e.residual, e.ldr = ptr(residual), (residual.stride(0) if residual.dim() == 2 else N)
     if lora_t is not None:
-        assert lora_t.dtype == f32 and lora_u.dtype == f32 and lora_t.is_contiguous() and lora_u.is_contiguous()
-        e.lora_t, e.ldt, e.lora_u, e.lora_r = ptr(lora_t), lora_t.shape[-1], ptr(lora_u), lora_u.shape[-1]
+        assert lora_t.dtype == f32 and lora_u.dtype == f32 and lora_t.stride(1) == 1 and lora_u.stride(1) == 1
+        e.lora_t, e.ldt, e.lora_u, e.ldu, e.lora_u_tr = ptr(lora_t), lora_t.stride(0), ptr(lora_u), lora_u.stride(0), int(lora_u_tr)
+        e.lora_r = lora_r if lora_r is not None else (lora_u.shape[0] if lora_u_tr else lora_u.shape[1])
         e.lora_seg, e.lora_scale = (lora_seg or N), float(lora_scale)
     ws = workspace(GEMM_WS_BYTES if split_k == 0 else max(split_k, 1) * M * N * 4, A.device) if split_k != 1 else None
     _call("clora_gemm_f16_ex", ptr(A), lda if lda is not None else K, ptr(Bw), ptr(C_), ldc, M, N, K,
@@ -126,11 +128,13 @@ def gemm(A: torch.Tensor, Bw: torch.Tensor, M: int, N: int, K: int, *, lda: Opti
 
 
 def conv_wgrad(dY: torch.Tensor, X: torch.Tensor, M: int, N: int, K: int, conv: Optional[ConvDesc],
-               ldx: Optional[int] = None) -> torch.Tensor:
-    dW = torch.zeros((N, K), dtype=f32, device=dY.device)
-    _call("clora_conv_wgrad_f16", ptr(dY, f16), N, ptr(X, f16), ldx if ldx is not None else K, ptr(dW), M, N, K,
-          C.byref(conv) if conv is not None else None)
-    return dW
+               ldx: Optional[int] = None, with_bias: bool = False):
+    """dW [N, K] (and the bias gradient [N] when with_bias) of a trainable conv / linear, one pass over dY and X."""
+    buf = torch.zeros(N * K + (N if with_bias else 0), dtype=f32, device=dY.device)
+    dW, db = buf[:N * K].view(N, K), (buf[N * K:] if with_bias else None)
+    _call("clora_conv_wgrad_f16", ptr(dY, f16), N, ptr(X, f16), ldx if ldx is not None else K, ptr(dW), ptr(db), M, N, K,
+          C.byref(conv) if conv is not None else None, flops=2.0 * M * N * K)
+    return (dW, db) if with_bias else dW
 
 
 # ------------------------------------------------------------------ attention
@@ -216,26 +220,31 @@ def geglu_bwd(h, dy):
 
 
 # ------------------------------------------------------------------ adapters
-def lora_down(X, D, T, toff, M, K, accumulate=False, x_rows=0, ldx=None):
-    """T[:, toff:toff+R] (+)= X . D^T ; X [rows, K] fp16 (row pitch ldx), D [R, K] fp32, T [M, ldt] fp32."""
-    assert D.dtype == f32 and D.stride(1) == 1 and T.dtype == f32 and T.is_contiguous()
+def lora_down(X, D, T, toff, M, K, accumulate=False, x_rows=0, ldx=None, kmajor=False, R=None, d_scale=1.0):
+    """T[:, toff:toff+R] (+)= X . (d_scale * D)^T ; X [rows, K] fp16 (row pitch ldx), T [M, ldt] fp32.
+    D is [R, K] fp32, or with kmajor=True an up-projection matrix [K, R] used as its own transpose."""
+    assert D.dtype == f32 and D.stride(1) == 1 and T.dtype == f32 and T.stride(1) == 1
+    rank = R if R is not None else (D.shape[1] if kmajor else D.shape[0])
     _call("clora_lora_down_f16", ptr(X, f16), ldx if ldx is not None else X.stride(0), ptr(D), D.stride(0), ptr(T),
-          T.shape[1], toff, M, K, D.shape[0], int(accumulate), x_rows, nbytes=2.0 * M * K)
+          T.stride(0), toff, M, K, rank, int(accumulate), x_rows, int(kmajor), float(d_scale), nbytes=2.0 * M * K)
     return T
 
 
-def lora_up(base, T, toff, U, M, N, scale, out=None):
-    assert U.dtype == f32 and U.is_contiguous() and T.dtype == f32
+def lora_up(base, T, toff, U, M, N, scale, out=None, u_tr=False):
+    """Y = base + fp16(scale * fp16(T[:, toff:toff+R] . U^T)); U is [N, R], or with u_tr a down matrix [R, N]."""
+    assert U.dtype == f32 and U.stride(1) == 1 and T.dtype == f32
     y = out if out is not None else torch.empty((M, N), dtype=f16, device=T.device)
     _call("clora_lora_up_f16", ptr(base, f16) if base is not None else None, base.stride(0) if base is not None else 0,
-          ptr(T), T.shape[1], toff, ptr(U), U.shape[1], ptr(y), y.stride(0), M, N, U.shape[1], float(scale))
+          ptr(T), T.stride(0), toff, ptr(U), U.stride(0), int(u_tr), ptr(y), y.stride(0), M, N,
+          U.shape[0] if u_tr else U.shape[1], float(scale),
+          nbytes=2.0 * M * N * (2 if base is not None else 1))
     return y
 
 
 def lora_wgrad(A, T, toff, G, gs_n, gs_j, M, N, R, scale=1.0, a_rows=0, lda=None):
     """G[n*gs_n + j*gs_j] += scale * sum_m A[m,n] T[m,toff+j]"""
     assert G.dtype == f32 and T.dtype == f32
-    _call("clora_lora_wgrad_f16", ptr(A, f16), lda if lda is not None else A.stride(0), ptr(T), T.shape[1], toff, ptr(G),
+    _call("clora_lora_wgrad_f16", ptr(A, f16), lda if lda is not None else A.stride(0), ptr(T), T.stride(0), toff, ptr(G),
           gs_n, gs_j, M, N, R, float(scale), a_rows, nbytes=2.0 * M * N)
     return G
 

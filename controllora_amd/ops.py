@@ -252,83 +252,106 @@ def attention_cross(q, kv, B, H, N, Nk, D, scale):
 
 
 # ------------------------------------------------------------------------------------------------ adapters
+def _grad_buffer(p: torch.Tensor) -> torch.Tensor:
+    """Adapter weight gradients are accumulated by the kernels straight into ``param.grad`` (fp32 atomics;
+    with ControlLoRATrainer that is a view of the flat all-reduce buffer) instead of being returned to
+    autograd: no zero-filled temporaries, no AccumulateGrad add per parameter."""
+    if p.grad is None:
+        p.grad = torch.zeros_like(p)
+    return p.grad
+
+
 class _LoraProjFn(torch.autograd.Function):
     """y = x W^T (+b) (+residual) + scale_s * up_s(down_s(xa_s)) on column segment s.
 
     One frozen GEMM over x with the rank-r updates applied in its epilogue.
-    ``segs[s]`` is None (no adapter on that segment) or (xa_index, scale) where xa_index selects the adapter
-    input among ``xas`` (0 = x itself).  Tensor arguments are flattened as
-    (x, residual, *xas[1:], D_0, U_0, D_1, U_1, ...) for autograd."""
+    ``meta[s]`` is None (no adapter on that segment) or (xa_index, scale); xa_index selects the adapter input
+    among ``xas`` (0 = x itself).  Tensor arguments are (x, residual, *xas[1:], D_0, U_0, D_1, U_1, ...)."""
 
     @staticmethod
-    def forward(ctx, pack: LinearPack, segs, n_xa, x, residual, *rest):
+    def forward(ctx, pack: LinearPack, meta, n_xa, x, residual, *rest):
         xas = [x] + list(rest[:n_xa - 1])
         params = rest[n_xa - 1:]
-        S = len(segs)
+        S = len(meta)
         seg_w = pack.N // S
         M = x.shape[0]
-        r = max([params[2 * i].shape[0] for i in range(len(params) // 2)] + [1])
-        T = torch.zeros((M, S * r), dtype=f32, device=x.device)
-        U = torch.zeros((pack.N, r), dtype=f32, device=x.device)
-        pi = 0
-        meta = []
-        for s, sg in enumerate(segs):
-            if sg is None:
-                meta.append(None)
+        ranks = [params[2 * i].shape[0] for i in range(len(params) // 2)]
+        r = max(ranks + [1])
+        full = all(m is not None for m in meta) and all(rk == r for rk in ranks)
+        T = (torch.empty if full else torch.zeros)((M, S * r), dtype=f32, device=x.device)
+        pieces, pi, info = [], 0, []
+        for s, m in enumerate(meta):
+            if m is None:
+                pieces.append(torch.zeros((seg_w, r), dtype=f32, device=x.device))
+                info.append(None)
                 continue
-            xi, sc = sg
+            xi, sc = m
             D, Uw = params[2 * pi], params[2 * pi + 1]
             pi += 1
             rs = D.shape[0]
-            K.lora_down(xas[xi], D, T, s * r, M, D.shape[1])
-            U[s * seg_w:(s + 1) * seg_w, :rs] = Uw * sc
-            meta.append((xi, sc, rs))
+            K.lora_down(xas[xi], D.detach(), T, s * r, M, D.shape[1])
+            u = Uw.detach() if sc == 1.0 else Uw.detach() * sc
+            if rs != r:
+                u = torch.cat([u, u.new_zeros(seg_w, r - rs)], 1)
+            pieces.append(u)
+            info.append((xi, sc, rs))
+        U = pieces[0] if S == 1 else torch.cat(pieces, 0)
         y = K.gemm(x, pack.w, M, pack.N, pack.K, bias=pack.bias, residual=residual, lora_t=T, lora_u=U,
                    lora_seg=seg_w, lora_scale=1.0)
-        ctx.pack, ctx.meta, ctx.n_xa, ctx.r, ctx.has_res = pack, meta, n_xa, r, residual is not None
-        ctx.save_for_backward(T, *xas, *params)
+        ctx.pack, ctx.info, ctx.n_xa, ctx.r, ctx.has_res = pack, info, n_xa, r, residual is not None
+        ctx.params = params                       # the Parameter objects themselves (leaf tensors)
+        ctx.save_for_backward(T, *xas)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         dy = dy.contiguous()
-        pack, meta, n_xa, r = ctx.pack, ctx.meta, ctx.n_xa, ctx.r
+        pack, info, n_xa, r, params = ctx.pack, ctx.info, ctx.n_xa, ctx.r, ctx.params
         saved = ctx.saved_tensors
-        T, xas, params = saved[0], saved[1:1 + n_xa], saved[1 + n_xa:]
-        S = len(meta)
+        T, xas = saved[0], saved[1:1 + n_xa]
+        S = len(info)
         seg_w = pack.N // S
         M = dy.shape[0]
-        dev = dy.device
-        dT = torch.zeros((M, S * r), dtype=f32, device=dev)
-        # rank-r part of dx for adapters fed by x itself goes into the dgrad GEMM epilogue
-        Dx = torch.zeros((pack.K, S * r), dtype=f32, device=dev)
-        grads_params: List[Optional[torch.Tensor]] = []
+        dT = (torch.empty if all(i is not None and i[2] == r for i in info) else torch.zeros)((M, S * r), dtype=f32, device=dy.device)
         d_xas: List[Optional[torch.Tensor]] = [None] * n_xa
+        own = []                                  # (segment, D) of adapters fed by x itself -> dgrad GEMM epilogue
         pi = 0
-        for s, m in enumerate(meta):
+        for s, m in enumerate(info):
             if m is None:
                 continue
             xi, sc, rs = m
             D, Uw = params[2 * pi], params[2 * pi + 1]
             pi += 1
             dys = dy[:, s * seg_w:(s + 1) * seg_w]
-            # dT_s = sc * dy_s . U_s   (a "down" projection of dy with U^T as the matrix)
-            K.lora_down(dys, (Uw * sc).t().contiguous(), dT, s * r, M, seg_w, ldx=pack.N)
-            dU = torch.zeros_like(Uw)
-            K.lora_wgrad(dys, T, s * r, dU, Uw.shape[1], 1, M, seg_w, rs, scale=sc, lda=pack.N)
-            dD = torch.zeros_like(D)
-            K.lora_wgrad(xas[xi], dT, s * r, dD, 1, D.shape[1], M, D.shape[1], rs, scale=1.0)
-            grads_params += [dD, dU]
+            # dT_s = sc * dy_s . U_s : a "down" projection of dy with U (k-major) as the matrix
+            K.lora_down(dys, Uw.detach(), dT, s * r, M, seg_w, ldx=pack.N, kmajor=True, R=rs, d_scale=sc)
+            if Uw.requires_grad:
+                K.lora_wgrad(dys, T, s * r, _grad_buffer(Uw), Uw.shape[1], 1, M, seg_w, rs, scale=sc, lda=pack.N)
+            if D.requires_grad:
+                K.lora_wgrad(xas[xi], dT, s * r, _grad_buffer(D), 1, D.shape[1], M, D.shape[1], rs, scale=1.0)
             if xi == 0:
-                Dx[:, s * r:s * r + rs] = D.t()
+                own.append((s, D))
             elif ctx.needs_input_grad[4 + xi]:
-                g = K.lora_up(None, dT, s * r, D.t().contiguous(), M, D.shape[1], 1.0)
+                g = K.lora_up(None, dT, s * r, D.detach(), M, D.shape[1], 1.0, u_tr=True)
                 d_xas[xi] = g if d_xas[xi] is None else K.add(d_xas[xi], g)
         dx = None
         if ctx.needs_input_grad[3]:
-            dx = K.gemm(dy, pack.wt, M, pack.K, pack.N, lora_t=dT, lora_u=Dx, lora_seg=pack.K, lora_scale=1.0)
+            if not own:
+                dx = K.gemm(dy, pack.wt, M, pack.K, pack.N)
+            else:
+                segs = [s for s, _ in own]
+                contiguous = segs == list(range(segs[0], segs[0] + len(segs))) and all(D.shape[0] == r for _, D in own)
+                if contiguous:                                   # rank-r part of dx rides in the GEMM epilogue
+                    Dcat = own[0][1].detach() if len(own) == 1 else torch.cat([D.detach() for _, D in own], 0)
+                    dx = K.gemm(dy, pack.wt, M, pack.K, pack.N, lora_t=dT[:, segs[0] * r:], lora_u=Dcat,
+                                lora_seg=pack.K, lora_u_tr=True, lora_r=Dcat.shape[0])
+                else:
+                    Dx = torch.zeros((S * r, pack.K), dtype=f32, device=dy.device)
+                    for s, D in own:
+                        Dx[s * r:s * r + D.shape[0]] = D.detach()
+                    dx = K.gemm(dy, pack.wt, M, pack.K, pack.N, lora_t=dT, lora_u=Dx, lora_seg=pack.K, lora_u_tr=True)
         dres = dy if ctx.has_res and ctx.needs_input_grad[4] else None
-        return (None, None, None, dx, dres, *d_xas[1:], *grads_params)
+        return (None, None, None, dx, dres, *d_xas[1:], *([None] * len(params)))
 
 
 def lora_proj(x, pack: LinearPack, segs: Sequence[Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor, float]]],
@@ -362,44 +385,50 @@ class _ControlAddFn(torch.autograd.Function):
         R = D.shape[0]
         T = torch.empty((M, R), dtype=f32, device=h.device)
         xr = Mc if Mc != M else 0
+        Dd, Ud = D.detach(), U.detach()
         if concat:
-            K.lora_down(h, D, T, 0, M, C_)                          # D[:, :C] acts on h (row pitch ldd = C + Cc)
-            K.lora_down(ctrl, D[:, C_:], T, 0, M, Cc, accumulate=True, x_rows=xr)
+            K.lora_down(h, Dd, T, 0, M, C_)                          # D[:, :C] acts on h (row pitch ldd = C + Cc)
+            K.lora_down(ctrl, Dd[:, C_:], T, 0, M, Cc, accumulate=True, x_rows=xr)
         else:
-            K.lora_down(ctrl, D, T, 0, M, Cc, x_rows=xr)
-        y = K.lora_up(h, T, 0, U, M, C_, scale)
-        ctx.save_for_backward(h, ctrl, D, U, T)
+            K.lora_down(ctrl, Dd, T, 0, M, Cc, x_rows=xr)
+        y = K.lora_up(h, T, 0, Ud, M, C_, scale)
+        ctx.save_for_backward(h, ctrl, T)
+        ctx.params = (D, U)
         ctx.cfg = (scale, concat, xr)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         dy = dy.contiguous()
-        h, ctrl, D, U, T = ctx.saved_tensors
+        h, ctrl, T = ctx.saved_tensors
+        D, U = ctx.params
         scale, concat, xr = ctx.cfg
         M, C_ = h.shape
         Mc, Cc = ctrl.shape
         R = D.shape[0]
+        Dd, Ud = D.detach(), U.detach()
         dT = torch.empty((M, R), dtype=f32, device=dy.device)
-        K.lora_down(dy, (U * scale).t().contiguous(), dT, 0, M, C_)
-        dU = torch.zeros_like(U)
-        K.lora_wgrad(dy, T, 0, dU, R, 1, M, C_, R, scale=scale)
-        dD = torch.zeros_like(D)
+        K.lora_down(dy, Ud, dT, 0, M, C_, kmajor=True, R=R, d_scale=scale)
+        if U.requires_grad:
+            K.lora_wgrad(dy, T, 0, _grad_buffer(U), R, 1, M, C_, R, scale=scale)
         dh = dy
         dctrl = None
         if concat:
-            K.lora_wgrad(h, dT, 0, dD, 1, D.shape[1], M, C_, R)
-            K.lora_wgrad(ctrl, dT, 0, dD[:, C_:], 1, D.shape[1], M, Cc, R, a_rows=xr)
-            dh = K.lora_up(dy, dT, 0, D[:, :C_].t().contiguous(), M, C_, 1.0)
-            Dc_t = D[:, C_:].t().contiguous()
+            if D.requires_grad:
+                gD = _grad_buffer(D)
+                K.lora_wgrad(h, dT, 0, gD, 1, D.shape[1], M, C_, R)
+                K.lora_wgrad(ctrl, dT, 0, gD[:, C_:], 1, D.shape[1], M, Cc, R, a_rows=xr)
+            dh = K.lora_up(dy, dT, 0, Dd[:, :C_], M, C_, 1.0, u_tr=True)
+            Dc = Dd[:, C_:]
         else:
-            K.lora_wgrad(ctrl, dT, 0, dD, 1, D.shape[1], M, Cc, R, a_rows=xr)
-            Dc_t = D.t().contiguous()
+            if D.requires_grad:
+                K.lora_wgrad(ctrl, dT, 0, _grad_buffer(D), 1, D.shape[1], M, Cc, R, a_rows=xr)
+            Dc = Dd
         if ctx.needs_input_grad[1]:
-            dctrl = K.lora_up(None, dT, 0, Dc_t, M, Cc, 1.0)
+            dctrl = K.lora_up(None, dT, 0, Dc, M, Cc, 1.0, u_tr=True)
             if xr:
                 dctrl = dctrl.reshape(M // Mc, Mc, Cc).float().sum(0).to(f16)
-        return dh, dctrl, dD, dU, None, None
+        return dh, dctrl, None, None, None, None
 
 
 def control_add(h, ctrl, D, U, scale, concat):
@@ -443,13 +472,13 @@ class _TrainConvFn(torch.autograd.Function):
                 wd[:Ci] = weight.detach().permute(1, 2, 3, 0)
                 cdd = K.conv_dgrad_desc(Ho, Wo, Co, H, W, 3, stride, 1, asym_pad)
                 dx = K.gemm(dy, wd.reshape(Cip, 9 * Co), B * H * W, Cip, 9 * Co, conv=cdd)
-            dWp = K.conv_wgrad(dy, x, M, Co, 9 * Cip, cd)
+            dWp, db = K.conv_wgrad(dy, x, M, Co, 9 * Cip, cd, with_bias=True)
             dW = dWp.reshape(Co, 3, 3, Cip)[:, :, :, :Ci].permute(0, 3, 1, 2).contiguous()
         else:
             if need_dx:
                 dx = K.gemm(dy, weight.detach().reshape(Co, Ci).t().contiguous().to(f16), M, Ci, Co)
-            dW = K.conv_wgrad(dy, x, M, Co, Ci, None).reshape(Co, Ci, 1, 1)
-        db = K.colsum(dy, M, Co)
+            dWp, db = K.conv_wgrad(dy, x, M, Co, Ci, None, with_bias=True)
+            dW = dWp.reshape(Co, Ci, 1, 1)
         return dx, dW, db, None, None, None, None, None, None
 
 

@@ -56,7 +56,9 @@ typedef struct {
     int ldr;
     const float* lora_t;        /* [M, ldt] or NULL : X . D^T (fp32, from clora_lora_down) */
     int ldt;
-    const float* lora_u;        /* [N, lora_r] : adapter up weights */
+    const float* lora_u;        /* adapter up weights u(n,j): lora_u[n*ldu + j], or lora_u[j*ldu + n] when lora_u_tr */
+    int ldu;
+    int lora_u_tr;
     int lora_r;
     int lora_seg;
     float lora_scale;
@@ -77,10 +79,11 @@ int clora_gemm_f16_ex(const clora_half* A, int lda, const clora_half* B, clora_h
                       int M, int N, int K, const clora_conv_t* conv, const clora_epilogue_t* epi,
                       int split_k, int tile_cfg, void* workspace, size_t workspace_bytes, void* stream);
 
-/* dW[N, K] += dY[M,N]^T . gather(X)[M,K]   (fp32 atomics; caller zeroes dW).
+/* dW[N, K] += dY[M,N]^T . gather(X)[M,K] and (db != NULL) db[N] += column sums of dY  (fp32 atomics; caller
+ * zeroes dW / db).
  * Weight gradient of the trainable hint-encoder convolutions (reference models.py:470,529,594-597,684:
  * autograd of F.conv2d).  `conv` as in the forward of that layer (NULL = 1x1 / linear). */
-int clora_conv_wgrad_f16(const clora_half* dY, int ldy, const clora_half* X, int ldx, float* dW,
+int clora_conv_wgrad_f16(const clora_half* dY, int ldy, const clora_half* X, int ldx, float* dW, float* db,
                          int M, int N, int K, const clora_conv_t* conv, void* stream);
 
 /* ---- attention core: O = softmax(Q K^T * scale) V per (batch, head), flash-style (never
@@ -122,13 +125,15 @@ int clora_geglu_bwd_f16(const clora_half* h, const clora_half* dy, clora_half* d
 
 /* ---- rank-r adapter pieces (upstream LoRALinearLayer; reference models.py:89-97,185-188,316-323).
  * T[m, toff+j] (+)= sum_k X[bmap(m), k] * D[j, k]   (fp32 math like the reference's x.float() @ down.T)
- * x_batch_rows > 0 : X holds one batch element of x_batch_rows rows that is broadcast over M (control batch 1). */
+ * x_rows > 0 : X holds one batch element of x_rows rows that is broadcast over M (control batch 1).
+ * d_kmajor  : D[j][k] is stored at D[k*ldd + j] (an up matrix [N, r] acting as U^T in the backward pass).
+ * d_scale   : D is multiplied by d_scale on the fly (the LoRA `scale`). */
 int clora_lora_down_f16(const clora_half* X, int ldx, const float* D, int ldd, float* T, int ldt, int toff,
-                        int M, int K, int R, int accumulate, int x_rows, void* stream);
+                        int M, int K, int R, int accumulate, int x_rows, int d_kmajor, float d_scale, void* stream);
 /* Y[m,n] = (base ? base[m,n] : 0) + fp16(scale * fp16(sum_j T[m,toff+j] U[n,j]))  -- the explicit
  * "hidden + to_control(control)" of models.py:214-218,237-238 and the V2 pre/post adds (:369,:415). */
 int clora_lora_up_f16(const clora_half* base, int ldb, const float* T, int ldt, int toff, const float* U, int ldu,
-                      clora_half* Y, int ldy, int M, int N, int R, float scale, void* stream);
+                      int u_transposed, clora_half* Y, int ldy, int M, int N, int R, float scale, void* stream);
 /* G[n*gs_n + j*gs_j] += scale * sum_m A[m, n] * T[m, toff+j]  (adapter weight gradients; fp32 atomics). */
 int clora_lora_wgrad_f16(const clora_half* A, int lda, const float* T, int ldt, int toff, float* G, int gs_n, int gs_j,
                          int M, int N, int R, float scale, int a_rows, void* stream);

@@ -72,10 +72,10 @@ def case_conv(dev, Bn, H, W, Ci, Co, stride=1, pad=1, ups=False, asym=False, see
         pooled = K.pool2x2_sum(dx.reshape(Bn, Hi * Wi, Ci), Bn, H, W, Ci)
         ref = F.avg_pool2d(xin.grad, 2) * 4
         assert rel(pooled, ref.permute(0, 2, 3, 1).reshape(Bn, H * W, Ci)) < 1e-3
-    dW = K.conv_wgrad(dyn, xn, M, Co, 9 * Ci, cd)
+    dW, db = K.conv_wgrad(dyn, xn, M, Co, 9 * Ci, cd, with_bias=True)
     assert rel(dW, w32.grad.permute(0, 2, 3, 1).reshape(Co, 9 * Ci)) < 1e-4
-    db = K.colsum(dyn.reshape(M, Co), M, Co)
     assert rel(db, dy.float().sum((0, 2, 3))) < 1e-4
+    assert rel(K.colsum(dyn.reshape(M, Co), M, Co), dy.float().sum((0, 2, 3))) < 1e-4
 
 
 def _attn_ref(q, k, v, H, scale):
