@@ -28,6 +28,19 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 #define CLORA_ERR_LAUNCH (-2)
 #define CLORA_ERR_WORKSPACE (-3)
 
+// ---- asynchronous global -> LDS copies (LDS-DMA, `global_load_lds_dwordx4`) and the counted waits that let
+// them stay in flight across a workgroup barrier.  Measured semantics on gfx950 (tools/probes/glds_probe.hip):
+// the LDS destination is the FIRST lane's pointer + lane*16 (wave-uniform base), the global source is per lane.
+// (tests/hipemu/hipemu.h provides host stand-ins for these three when the sources are built for the CPU emulator)
+#ifndef CLORA_ASYNC_PRIMS
+#define CLORA_ASYNC_PRIMS
+#define CLORA_GLDS16(gptr, lptr)                                                                      \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),            \
+                                     (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
+#define CLORA_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+#define CLORA_RAW_BARRIER() __builtin_amdgcn_s_barrier()
+#endif
+
 __device__ __forceinline__ floatx4 mfma16(half8 a, half8 b, floatx4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }

@@ -224,6 +224,181 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// v2 main loop: operands go global -> LDS by LDS-DMA (no staging VGPRs, no ds_write pass) into a 3-stage ring;
+// the copy of tile kt+2 is issued right after the barrier of iteration kt and only has to land two
+// iterations later (counted s_waitcnt vmcnt, raw s_barrier: one barrier per k-step, loads stay in flight
+// across it).  LDS rows are 64 B (one BK=32 row) unpadded -- the DMA writes lane-linearly -- and bank
+// conflicts are removed by an XOR swizzle applied on the SOURCE side: the lane that fills 16-byte slot `pos`
+// of row r fetches logical k-chunk  pos ^ ((r >> 2) & 3); fragment reads apply the same involution.
+// Out-of-range / padding chunks are fetched from a 16-byte zero page.
+__device__ __attribute__((aligned(16))) const unsigned g_clora_zero16[4] = {0u, 0u, 0u, 0u};
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void gemm_dma_kernel(GemmArgs p) {
+    constexpr int BK = 32, NST = 3;
+    constexpr int FM = BM / WM / 16, FN = BN / WN / 16;
+    constexpr int A_IN = BM / 64, B_IN = BN / 64;          // DMA wave-instructions per stage per wave
+    constexpr int STAGE = (BM + BN) * BK;                   // halves
+    constexpr int C_LD = BN + 8;
+    constexpr int SMEM = (NST * STAGE > BM * C_LD) ? NST * STAGE : BM * C_LD;
+    __shared__ __attribute__((aligned(16))) half_t smem[SMEM];
+
+    const int t = threadIdx.x;
+    const int tile_m = blockIdx.x / p.tiles_n, tile_n = blockIdx.x % p.tiles_n;
+    const int split = blockIdx.y;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int kbeg = split * p.k_per_split;
+    const int kend = (kbeg + p.k_per_split < p.K) ? kbeg + p.k_per_split : p.K;
+    const int nk = (kend - kbeg + BK - 1) / BK;
+
+    const int w = t >> 6, l = t & 63, g = l >> 4, li = l & 15;
+    const bool conv = p.conv.enabled != 0;
+    const half_t* zero_page = reinterpret_cast<const half_t*>(g_clora_zero16);
+
+    // ---- loader: wave w, instruction i fills rows (w*IN + i)*16 .. +16 of the tile; lane -> (row l/4, slot l%4)
+    const int lrow = l >> 2, pos = l & 3;
+    const int kc = pos ^ ((lrow >> 2) & 3);                 // logical k-chunk this lane fetches (same for all its rows)
+    bool a_ok[A_IN];
+    size_t a_base[A_IN];
+    int a_ty[A_IN], a_tx[A_IN];
+#pragma unroll
+    for (int i = 0; i < A_IN; ++i) {
+        const int m = m0 + (w * A_IN + i) * 16 + lrow;
+        a_ok[i] = m < p.M;
+        a_base[i] = 0; a_ty[i] = 0; a_tx[i] = 0;
+        if (a_ok[i]) {
+            if (!conv) {
+                a_base[i] = (size_t)m * p.lda;
+            } else {
+                const int hw = p.conv.Hout * p.conv.Wout;
+                const int b = m / hw, rem = m - b * hw;
+                const int yo = rem / p.conv.Wout, xo = rem - yo * p.conv.Wout;
+                a_base[i] = (size_t)b * p.conv.Hin * p.conv.Win;
+                a_ty[i] = yo * p.conv.mul + p.conv.off;
+                a_tx[i] = xo * p.conv.mul + p.conv.off;
+            }
+        }
+    }
+    bool b_ok[B_IN];
+    size_t b_base[B_IN];
+#pragma unroll
+    for (int i = 0; i < B_IN; ++i) {
+        const int n = n0 + (w * B_IN + i) * 16 + lrow;
+        b_ok[i] = n < p.N;
+        b_base[i] = (size_t)n * p.K;
+    }
+    int k = kbeg + kc * 8;
+    int tap = 0, ci = k;
+    if (conv) { tap = k / p.conv.Cin; ci = k - tap * p.conv.Cin; }
+
+    auto issue_stage = [&](int buf) {
+        half_t* As = smem + buf * STAGE;
+        half_t* Bs = As + BM * BK;
+        const bool kok = k < kend;
+        int ky = 0, kx = 0;
+        if (conv) { ky = tap / p.conv.ksize; kx = tap - ky * p.conv.ksize; }
+#pragma unroll
+        for (int i = 0; i < A_IN; ++i) {
+            const half_t* src = zero_page;
+            if (a_ok[i] && kok) {
+                if (!conv) {
+                    src = p.A + a_base[i] + k;
+                } else {
+                    const int ty = a_ty[i] + ky * p.conv.kmul, tx = a_tx[i] + kx * p.conv.kmul;
+                    bool ok = ty >= 0 && ty < p.conv.lim_h && tx >= 0 && tx < p.conv.lim_w;
+                    if (p.conv.need_even) ok = ok && (((ty | tx) & 1) == 0);
+                    if (ok)
+                        src = p.A + (a_base[i] + (size_t)(ty >> p.conv.shift) * p.conv.Win + (tx >> p.conv.shift)) * p.conv.Cin + ci;
+                }
+            }
+            CLORA_GLDS16(src, As + (w * A_IN + i) * 16 * BK);
+        }
+#pragma unroll
+        for (int i = 0; i < B_IN; ++i) {
+            const half_t* src = (b_ok[i] && kok) ? p.B + b_base[i] + k : zero_page;
+            CLORA_GLDS16(src, Bs + (w * B_IN + i) * 16 * BK);
+        }
+        k += BK;
+        if (conv) {
+            ci += BK;
+            while (ci >= p.conv.Cin) { ci -= p.conv.Cin; ++tap; }
+        }
+    };
+
+    const int wm = w / WN, wn = w % WN;
+    const int fsw = ((g ^ (li >> 2)) & 3) * 8;               // swizzled slot of logical chunk g for rows == li (mod 16)
+    floatx4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = zero4f();
+
+    if (nk > 0) issue_stage(0);
+    if (nk > 1) issue_stage(1);
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) CLORA_WAIT_VMCNT(A_IN + B_IN); else CLORA_WAIT_VMCNT(0);
+        CLORA_RAW_BARRIER();
+        if (kt + 2 < nk) issue_stage((kt + 2) % NST);
+        const half_t* As = smem + (kt % NST) * STAGE;
+        const half_t* Bs = As + BM * BK;
+        half8 af[FM], bf[FN];
+#pragma unroll
+        for (int i = 0; i < FM; ++i) af[i] = ld8(As + (wm * FM * 16 + i * 16 + li) * BK + fsw);
+#pragma unroll
+        for (int j = 0; j < FN; ++j) bf[j] = ld8(Bs + (wn * FN * 16 + j * 16 + li) * BK + fsw);
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) acc[i][j] = mfma16(af[i], bf[j], acc[i][j]);
+    }
+
+    if (p.partial) {
+        float* slab = p.partial + (size_t)split * p.M * p.N;
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = m0 + wm * FM * 16 + i * 16 + 4 * g + r;
+                    const int n = n0 + wn * FN * 16 + j * 16 + li;
+                    if (m < p.M && n < p.N) slab[(size_t)m * p.N + n] = acc[i][j][r];
+                }
+        return;
+    }
+    __syncthreads();                                           // every wave is done reading the last stage
+    half_t* Cs = smem;
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ml = wm * FM * 16 + i * 16 + 4 * g + r;
+                const int nl = wn * FN * 16 + j * 16 + li;
+                const int m = m0 + ml, n = n0 + nl;
+                float v = acc[i][j][r];
+                if (m < p.M && n < p.N) v = epi_pre(v, m, n, p.epi);
+                Cs[ml * C_LD + nl] = (half_t)v;
+            }
+    __syncthreads();
+    constexpr int CPR = BN / 8;
+    for (int c = t; c < BM * CPR; c += 256) {
+        const int ml = c / CPR, nc = c - ml * CPR;
+        const int m = m0 + ml, n = n0 + nc * 8;
+        if (m < p.M && n < p.N) {
+            half8 v = ld8(Cs + ml * C_LD + nc * 8);
+            if (p.epi.residual) {
+                const half8 rr = ld8((const half_t*)p.epi.residual + (size_t)m * p.epi.ldr + n);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)rr[e]);
+            }
+            st8(p.C + (size_t)m * p.ldc + n, v);
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void splitk_finish_kernel(GemmArgs p, int splits) {
     const size_t chunks = (size_t)p.M * (p.N / 8);
     for (size_t c = (size_t)blockIdx.x * 256 + threadIdx.x; c < chunks; c += (size_t)gridDim.x * 256) {
@@ -350,10 +525,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
 }
 
 template <int BM, int BN, int WM, int WN>
-int launch_gemm(GemmArgs& a, int splits, hipStream_t s) {
+int launch_gemm(GemmArgs& a, int splits, hipStream_t s, bool dma) {
     a.tiles_n = clora_cdiv(a.N, BN);
     const int tiles_m = clora_cdiv(a.M, BM);
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN>), dim3(tiles_m * a.tiles_n, splits), dim3(256), 0, s, a);
+    if (dma) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, WM, WN>), dim3(tiles_m * a.tiles_n, splits), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN>), dim3(tiles_m * a.tiles_n, splits), dim3(256), 0, s, a);
     return clora_check_launch();
 }
 
@@ -361,15 +537,15 @@ int launch_gemm(GemmArgs& a, int splits, hipStream_t s) {
 
 // ---- launch planning --------------------------------------------------------------------------------
 // Tile shape and split-K come from a latency model calibrated with tools/kbench.py --sweep on MI355X
-// (profiles/kbench_r01.json): with the single-stage register prefetch of this kernel one BK=32 step costs a
-// roughly constant t_k (global-load latency bound) per resident block, and a CU keeps `conc` blocks of a
-// given tile shape in flight, so
+// (profiles/r01_kbench_sweep.json): one BK=32 step costs a roughly constant t_k per resident block (the
+// LDS-DMA ring keeps two stages in flight, the rest of the global-load latency is exposed), and a CU keeps
+// `conc` blocks of a given tile shape in flight (LDS: 3 x 48 KB, 4 x 36 KB, 6 x 24 KB), so
 //     time = ceil(blocks / (256 * conc)) * (k_steps * t_k + t_fix)  +  split-K reduction traffic.
 // Predictions are within ~15% of the sweep for the 15 UNet shapes; the model prefers split-K whenever
 // M*N alone gives fewer than ~3 blocks per CU (the 16x16 / 8x8 UNet levels are weight-streaming problems).
 namespace {
 struct TileCfg { int bm, bn, conc; double t_k; };
-const TileCfg kTiles[3] = {{128, 128, 3, 0.95e-6}, {128, 64, 5, 0.92e-6}, {64, 64, 7, 0.62e-6}};
+const TileCfg kTiles[3] = {{128, 128, 3, 0.85e-6}, {128, 64, 4, 0.82e-6}, {64, 64, 6, 0.52e-6}};
 
 void plan_gemm(int M, int N, int K, int max_split, int& tile, int& splits) {
     const int ksteps = clora_cdiv(K, 32);
@@ -420,6 +596,8 @@ extern "C" int clora_gemm_f16_ex(const clora_half* A, int lda, const clora_half*
         const int ksteps = clora_cdiv(K, 32);
         splits = split_k > ksteps ? ksteps : split_k;
     }
+    bool dma = true;                       // tile_cfg 11..13 = the register-staged v1 main loop (A/B comparisons)
+    if (tile_cfg >= 11 && tile_cfg <= 13) { dma = false; tile_cfg -= 10; }
     if (tile_cfg >= 1 && tile_cfg <= 3) tile = tile_cfg - 1;
     a.k_per_split = clora_cdiv(clora_cdiv(K, 32), splits) * 32;
     splits = clora_cdiv(K, a.k_per_split);
@@ -428,9 +606,9 @@ extern "C" int clora_gemm_f16_ex(const clora_half* A, int lda, const clora_half*
         a.partial = (float*)workspace;
     }
     int rc;
-    if (tile == 0) rc = launch_gemm<128, 128, 2, 2>(a, splits, s);
-    else if (tile == 1) rc = launch_gemm<128, 64, 4, 1>(a, splits, s);
-    else rc = launch_gemm<64, 64, 2, 2>(a, splits, s);
+    if (tile == 0) rc = launch_gemm<128, 128, 2, 2>(a, splits, s, dma);
+    else if (tile == 1) rc = launch_gemm<128, 64, 4, 1>(a, splits, s, dma);
+    else rc = launch_gemm<64, 64, 2, 2>(a, splits, s, dma);
     if (rc != CLORA_OK) return rc;
     if (splits > 1) {
         const size_t chunks = (size_t)M * (N / 8);

@@ -211,8 +211,8 @@ extern "C" int clora_lora_wgrad_f16(const clora_half* A, int lda, const float* T
                                     int gs_j, int M, int N, int R, float scale, int a_rows, void* stream) {
     if (!A || !T || !G || M <= 0 || N <= 0 || R <= 0 || (N & 7) || (lda & 7)) return CLORA_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
-    int rpb = 32;   // 4 waves x 8 rows; grow until the grid is at most ~512 blocks
-    while ((long)clora_cdiv(N, 512) * clora_cdiv(M, rpb) > 512) rpb *= 2;
+    int rpb = 32;   // 4 waves x 8 rows; grow until the grid is at most ~192 blocks (one fp32 atomic per element per block)
+    while ((long)clora_cdiv(N, 512) * clora_cdiv(M, rpb) > 192) rpb *= 2;
     for (int r0 = 0; r0 < R; r0 += 16) {
         const int Rp = (R - r0 < 16) ? R - r0 : 16, to = toff + r0;
         float* Gp = G + (size_t)r0 * gs_j;

@@ -114,20 +114,27 @@ __global__ __launch_bounds__(256) void gn_fwd_finalize_kernel(GnArgs p) {
     __shared__ float mr[64 * 2];
     const int t = threadIdx.x, b = blockIdx.x;
     const int cpg = p.C / p.G;
-    if (t < p.G) {
+    // 4 threads per group fold the chunk partials (interleaved, fixed order), then one of them finishes
+    {
+        const int g = t >> 2, part = t & 3;
         float s = 0.f, q = 0.f;
-        for (int c = 0; c < p.nchunk; ++c) {
-            const float* pp = p.partial + (((size_t)b * p.nchunk + c) * p.G + t) * 2;
-            s += pp[0]; q += pp[1];
+        if (g < p.G)
+            for (int c = part; c < p.nchunk; c += 4) {
+                const float* pp = p.partial + (((size_t)b * p.nchunk + c) * p.G + g) * 2;
+                s += pp[0]; q += pp[1];
+            }
+        s += __shfl_xor(s, 1); q += __shfl_xor(q, 1);
+        s += __shfl_xor(s, 2); q += __shfl_xor(q, 2);
+        if (g < p.G && part == 0) {
+            const float n = (float)p.HW * (float)cpg;
+            const float mean = s / n;
+            float var = q / n - mean * mean;
+            var = var < 0.f ? 0.f : var;
+            const float rstd = rsqrtf(var + p.eps);
+            mr[g * 2] = mean; mr[g * 2 + 1] = rstd;
+            p.stats[((size_t)b * p.G + g) * 2] = mean;
+            p.stats[((size_t)b * p.G + g) * 2 + 1] = rstd;
         }
-        const float n = (float)p.HW * (float)cpg;
-        const float mean = s / n;
-        float var = q / n - mean * mean;
-        var = var < 0.f ? 0.f : var;
-        const float rstd = rsqrtf(var + p.eps);
-        mr[t * 2] = mean; mr[t * 2 + 1] = rstd;
-        p.stats[((size_t)b * p.G + t) * 2] = mean;
-        p.stats[((size_t)b * p.G + t) * 2 + 1] = rstd;
     }
     __syncthreads();
     float* scale = p.table + (size_t)b * p.C;
@@ -220,14 +227,20 @@ __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(GnArgs p) {
     __shared__ float gs[64 * 2];
     const int t = threadIdx.x, b = blockIdx.x;
     const int cpg = p.C / p.G;
-    if (t < p.G) {
+    {
+        const int g = t >> 2, part = t & 3;
         float s = 0.f, q = 0.f;
-        for (int c = 0; c < p.nchunk; ++c) {
-            const float* pp = p.partial + (((size_t)b * p.nchunk + c) * p.G + t) * 2;
-            s += pp[0]; q += pp[1];
+        if (g < p.G)
+            for (int c = part; c < p.nchunk; c += 4) {
+                const float* pp = p.partial + (((size_t)b * p.nchunk + c) * p.G + g) * 2;
+                s += pp[0]; q += pp[1];
+            }
+        s += __shfl_xor(s, 1); q += __shfl_xor(q, 1);
+        s += __shfl_xor(s, 2); q += __shfl_xor(q, 2);
+        if (g < p.G && part == 0) {
+            const float n = (float)p.HW * (float)cpg;
+            gs[g * 2] = s / n; gs[g * 2 + 1] = q / n;
         }
-        const float n = (float)p.HW * (float)cpg;
-        gs[t * 2] = s / n; gs[t * 2 + 1] = q / n;
     }
     __syncthreads();
     const size_t plane = (size_t)p.B * p.C;

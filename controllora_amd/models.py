@@ -420,12 +420,14 @@ class ControlLoRA(nn.Module):
             c = h
             if not isinstance(pre, nn.Identity):
                 c, _, _ = pre(h, B, H, W)
-            # NCHW-shaped *view* of the NHWC tensor: API parity with the reference at zero cost
+            # The processors get the [B, HW, C] token tensor directly (the reference's process_control_states accepts
+            # 3-D control states as they are, models.py:203): gradients from the 10 sites of a level then accumulate
+            # as contiguous fp16 adds.  The RETURNED tuple keeps the reference's NCHW shape as a zero-copy view.
+            for p in procs:
+                p.inject_control_states(c)
             ctrl = c.reshape(B, H, W, -1).permute(0, 3, 1, 2)
             if orig_dtype != f16:
                 ctrl = ctrl.to(orig_dtype)
-            for p in procs:
-                p.inject_control_states(ctrl)
             outs.append(ctrl)
         if not return_dict:
             return tuple(outs)

@@ -29,6 +29,8 @@ hipemu_switch:
 namespace hipemu {
 
 struct Wave {
+    const void* gsrc[64];
+    void* ldst[64];
     int live = 0, count = 0;
     uint64_t gen = 0;
     uint32_t in32[64], out32[64];
@@ -113,6 +115,19 @@ uint32_t wave_shfl(uint32_t v, int a, int mode) {
         }
     });
     return w->out32[l];
+}
+
+void glds16(const void* gptr, void* lptr) {
+    Wave* w = cur->wave;
+    int l = cur->lane;
+    w->gsrc[l] = gptr; w->ldst[l] = lptr;
+    collective([](Wave* w) {
+        int first = 0;
+        while (first < 64 && !w->present[first]) ++first;
+        char* base = (char*)w->ldst[first];
+        for (int i = 0; i < 64; ++i)
+            if (w->present[i]) memcpy(base + 16 * i, w->gsrc[i], 16);
+    });
 }
 
 hipemu_floatx4 mfma_16x16x32_f16(hipemu_half8 a, hipemu_half8 b, hipemu_floatx4 c) {

@@ -80,6 +80,14 @@ static inline hipemu_floatx4 __builtin_amdgcn_mfma_f32_16x16x32_f16(hipemu_half8
 }
 
 static inline int __builtin_amdgcn_readfirstlane(int x) { return x; }
+
+// host stand-ins for the asynchronous-copy primitives of clora_common.h: the copy happens immediately (the
+// emulator has no memory latency), destination = first lane's LDS pointer + lane*16 like the hardware.
+namespace hipemu { void glds16(const void* gptr, void* lptr); }
+#define CLORA_ASYNC_PRIMS
+#define CLORA_GLDS16(gptr, lptr) hipemu::glds16((const void*)(gptr), (void*)(lptr))
+#define CLORA_WAIT_VMCNT(n) ((void)0)
+#define CLORA_RAW_BARRIER() hipemu::sync_threads()
 static inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }
 static inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v; return o; }
 static inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }

@@ -49,7 +49,7 @@ def _sweep_or_auto(name, fn, flops, nbytes):
     s = timeit(lambda: fn(0, 0))
     report(f"{name} auto", s, flops, nbytes)
     if SWEEP:
-        for tile in (1, 2, 3):
+        for tile in (1, 2, 3, 11, 12, 13):
             for split in (1, 2, 4, 8):
                 try:
                     s = timeit(lambda: fn(split, tile), iters=8, warm=2)
