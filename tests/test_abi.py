@@ -1,0 +1,43 @@
+"""CPU test: the gfx950 library built by __graft_entry__.build() loads and exports every symbol that
+include/clora.h declares (no compute calls -- there is no GPU here), and the product binding refuses to
+run without it / on CPU tensors (no silent fallback)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    src = open(os.path.join(ROOT, "include", "clora.h")).read()
+    return sorted(set(re.findall(r"\b(clora_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from controllora_amd import build
+    lib = build.build(verbose=False)
+    cdll = ctypes.CDLL(lib)
+    syms = _declared_symbols()
+    assert len(syms) >= 25
+    missing = [s for s in syms if not hasattr(cdll, s)]
+    assert not missing, missing
+    assert cdll.clora_abi_version() == 1
+
+
+def test_binding_covers_the_header():
+    from controllora_amd import capi
+    declared = set(_declared_symbols()) - {"clora_build_info", "clora_gemm_f16"}
+    assert declared <= set(capi._PROTOS), declared - set(capi._PROTOS)
+
+
+def test_no_cpu_fallback():
+    from controllora_amd import capi, kernels as K
+    with pytest.raises(capi.CloraError):
+        capi.Lib(os.path.join(ROOT, "controllora_amd", "_build", "does_not_exist.so"))
+    if not torch.cuda.is_available():
+        x = torch.zeros(8, 8, dtype=torch.float16)
+        with pytest.raises(capi.CloraError):          # product library + CPU tensors -> loud error, not a fallback
+            K.silu(x)
