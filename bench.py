@@ -109,6 +109,8 @@ def main():
     ap.add_argument("--res", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-ddim", action="store_true", help="skip the secondary inference measurement")
+    ap.add_argument("--ddim-batch", type=int, default=16)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -174,6 +176,27 @@ def main():
                     "whole_step_frac_of_mfma_peak": round(
                         images_per_s / world * HOT_PATH_TFLOP_PER_IMAGE_512 * (args.res / 512) ** 2 / MFMA_PEAK_TFLOPS, 4)}
 
+    # secondary line of BASELINE.json's metric: 50-step DDIM latency, 512^2, 16 images, CFG 9.0 (UNet batch 32),
+    # control batch 1 (the inference call pattern of apps/gradio_canny2image.py:66-92); replicas only, rank 0, N=1
+    ddim = None
+    if world == 1 and rank == 0 and not args.no_ddim:
+        from controllora_amd.pipeline import ddim_sample
+        nb = args.ddim_batch
+        g = torch.Generator(device=dev).manual_seed(1)
+        cond = torch.randn(nb, 77, 768, device=dev, generator=g).half()
+        uncond = torch.randn(nb, 77, 768, device=dev, generator=g).half()
+        lat0 = torch.randn(nb, 4, args.res // 8, args.res // 8, device=dev, generator=g).half()
+        ddim_sample(unet, clora, batch["guide"][:1], cond, uncond, steps=2, latents=lat0)      # warm-up
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        out = ddim_sample(unet, clora, batch["guide"][:1], cond, uncond, steps=50, guidance_scale=9.0, latents=lat0)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t1
+        ddim = {"metric": f"50-step DDIM latency {args.res}^2 bs{nb} (CFG 9.0, UNet batch {2 * nb}, control batch 1)",
+                "latency_s": round(dt, 3), "images_per_s": round(nb / dt, 3), "finite": bool(torch.isfinite(out.float()).all())}
+        del out, cond, uncond, lat0
+        torch.cuda.empty_cache()
+
     cpu = None
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
         cpu = cpu_baseline()
@@ -190,7 +213,7 @@ def main():
                        "global_batch": args.batch * world, "parallelism": f"dp{world}",
                        "allreduce_bytes": trainer.flat.numel * 4},
             "loss": round(loss, 5), "steps_skipped_by_scaler": skipped,
-            "roofline": roofline, "cpu_baseline": cpu}))
+            "roofline": roofline, "ddim50": ddim, "cpu_baseline": cpu}))
     if world > 1:
         torch.distributed.destroy_process_group()
 

@@ -79,38 +79,122 @@ __device__ __forceinline__ half8 frag_from_acc(floatx4 lo, floatx4 hi) {
     return r;
 }
 
+// register-staged tile loads: issue the global loads of tile t+1 before the MFMAs of tile t, write them to LDS
+// after the barrier that ends tile t (cdna_hip_programming.md T14)
+template <int ROWS, int DP>
+struct TileRegs {
+    static constexpr int N = (ROWS * (DP / 8) + 255) / 256;
+    half8 v[N];
+};
+template <int ROWS, int DP, bool ROW_FAST>
+__device__ __forceinline__ void tile_load(TileRegs<ROWS, DP>& r, const half_t* src, int ld, int rows_valid, int D, int t) {
+    constexpr int CPR = DP / 8;
+#pragma unroll
+    for (int i = 0; i < TileRegs<ROWS, DP>::N; ++i) {
+        const int c = t + 256 * i;
+        const int row = ROW_FAST ? c % ROWS : c / CPR;
+        const int col = (ROW_FAST ? c / ROWS : c - (c / CPR) * CPR) * 8;
+        half8 v = zero8();
+        if (c < ROWS * CPR && row < rows_valid && col < D) v = ld8(src + (size_t)row * ld + col);
+        r.v[i] = v;
+    }
+}
+template <int ROWS, int DP, int LD>
+__device__ __forceinline__ void tile_store_rows(const TileRegs<ROWS, DP>& r, half_t* dst, int t) {
+    constexpr int CPR = DP / 8;
+#pragma unroll
+    for (int i = 0; i < TileRegs<ROWS, DP>::N; ++i) {
+        const int c = t + 256 * i;
+        if (c < ROWS * CPR) { const int row = c / CPR, col = (c - row * CPR) * 8; st8(dst + row * LD + col, r.v[i]); }
+    }
+}
+template <int ROWS, int DP, int LDT>
+__device__ __forceinline__ void tile_store_cols(const TileRegs<ROWS, DP>& r, half_t* dst, int t) {
+    constexpr int CPR = DP / 8;
+#pragma unroll
+    for (int i = 0; i < TileRegs<ROWS, DP>::N; ++i) {
+        const int c = t + 256 * i;
+        if (c < ROWS * CPR) {
+            const int row = c % ROWS, col = (c / ROWS) * 8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dst[(col + e) * LDT + row] = r.v[i][e];
+        }
+    }
+}
+
+// stores for tiles that were loaded with the ROW_FAST mapping (lane walks the rows)
+template <int ROWS, int DP, int LD>
+__device__ __forceinline__ void tile_store_rows_rf(const TileRegs<ROWS, DP>& r, half_t* dst, int t) {
+    constexpr int CPR = DP / 8;
+#pragma unroll
+    for (int i = 0; i < TileRegs<ROWS, DP>::N; ++i) {
+        const int c = t + 256 * i;
+        if (c < ROWS * CPR) { const int row = c % ROWS, col = (c / ROWS) * 8; st8(dst + row * LD + col, r.v[i]); }
+    }
+}
+template <int ROWS, int DP, int DROWS, int LDT>
+__device__ __forceinline__ void tile_store_cols_n(const TileRegs<ROWS, DP>& r, half_t* dst, int t) {
+    constexpr int CPR = DP / 8;
+#pragma unroll
+    for (int i = 0; i < TileRegs<ROWS, DP>::N; ++i) {
+        const int c = t + 256 * i;
+        const int row = c % ROWS, col = (c / ROWS) * 8;
+        if (c < ROWS * CPR && col < DROWS) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dst[(col + e) * LDT + row] = r.v[i][e];
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------ forward
 template <int DP, int DT>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
-    constexpr int BKV = 64, LDK = DP + 8, LDV = BKV + 8, KS = DP / 32;
-    __shared__ __attribute__((aligned(16))) half_t smem[BKV * LDK + DT * 16 * LDV];
+    constexpr int BKV = 64, LDK = DP + 8, LDV = BKV + 8, KS = DP / 32, DV = DT * 16;
+    __shared__ __attribute__((aligned(16))) half_t smem[BKV * LDK + DV * LDV];
     half_t* Ks = smem;
     half_t* Vt = smem + BKV * LDK;
     const int t = threadIdx.x, w = t >> 6, l = t & 63, g = l >> 4, li = l & 15;
     const int b = blockIdx.y / p.H, h = blockIdx.y % p.H;
     const int q0 = blockIdx.x * 128 + w * 32;
     const int D = p.D;
+    const float c = p.scale * kLog2e;
 
-    half8 qf[2][KS];
+    half8 qf[2][KS];       // Q pre-multiplied by scale*log2(e): scores come out of the MFMA ready for exp2
 #pragma unroll
     for (int qg = 0; qg < 2; ++qg)
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const int q = q0 + qg * 16 + li, d = ks * 32 + g * 8;
-            qf[qg][ks] = (q < p.Nq && d < D) ? ld8(p.q + ((size_t)b * p.Nq + q) * p.ldq + h * D + d) : zero8();
+            half8 v = (q < p.Nq && d < D) ? ld8(p.q + ((size_t)b * p.Nq + q) * p.ldq + h * D + d) : zero8();
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] * c);
+            qf[qg][ks] = v;
         }
     floatx4 oacc[DT][2];
 #pragma unroll
     for (int i = 0; i < DT; ++i) { oacc[i][0] = zero4f(); oacc[i][1] = zero4f(); }
     float mrun[2] = {kNegBig, kNegBig}, lrun[2] = {0.f, 0.f};
-    const float c = p.scale * kLog2e;
 
+    const half_t* kbase = p.k + (size_t)b * p.Nk * p.ldk + h * D;
+    const half_t* vbase = p.v + (size_t)b * p.Nk * p.ldv + h * D;
+    TileRegs<BKV, DP> rk;
+    TileRegs<BKV, DV> rv;
+    {
+        const int rows0 = p.Nk < BKV ? p.Nk : BKV;
+        tile_load<BKV, DP, false>(rk, kbase, p.ldk, rows0, D, t);
+        tile_load<BKV, DV, true>(rv, vbase, p.ldv, rows0, D, t);
+    }
     for (int kv0 = 0; kv0 < p.Nk; kv0 += BKV) {
         const int rows = (p.Nk - kv0 < BKV) ? p.Nk - kv0 : BKV;
+        __syncthreads();                                   // previous tile fully consumed
+        tile_store_rows<BKV, DP, LDK>(rk, Ks, t);
+        tile_store_cols<BKV, DV, LDV>(rv, Vt, t);
         __syncthreads();
-        stage_rows<BKV, DP, LDK>(Ks, p.k + ((size_t)b * p.Nk + kv0) * p.ldk + h * D, p.ldk, rows, D, t);
-        stage_cols<BKV, DT * 16, LDV>(Vt, p.v + ((size_t)b * p.Nk + kv0) * p.ldv + h * D, p.ldv, rows, D, t);
-        __syncthreads();
+        if (kv0 + BKV < p.Nk) {                            // prefetch the next tile while this one is processed
+            const int nrows = (p.Nk - kv0 - BKV < BKV) ? p.Nk - kv0 - BKV : BKV;
+            tile_load<BKV, DP, false>(rk, kbase + (size_t)(kv0 + BKV) * p.ldk, p.ldk, nrows, D, t);
+            tile_load<BKV, DV, true>(rv, vbase + (size_t)(kv0 + BKV) * p.ldv, p.ldv, nrows, D, t);
+        }
 
         floatx4 s[4][2];
 #pragma unroll
@@ -123,18 +207,20 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
                 s[kt][0] = mfma16(a, qf[0][ks], s[kt][0]);
                 s[kt][1] = mfma16(a, qf[1][ks], s[kt][1]);
             }
+        if (rows < BKV) {                                  // ragged last tile only: mask the missing keys
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (kt * 16 + 4 * g + r >= rows) { s[kt][0][r] = kNegBig; s[kt][1][r] = kNegBig; }
+        }
 #pragma unroll
         for (int qg = 0; qg < 2; ++qg) {
             float mx = kNegBig;
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const bool ok = (kt * 16 + 4 * g + r) < rows;
-                    const float v = ok ? s[kt][qg][r] * c : kNegBig;
-                    s[kt][qg][r] = v;
-                    mx = fmaxf(mx, v);
-                }
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][qg][r]);
             mx = fmaxf(mx, __shfl_xor(mx, 16));
             mx = fmaxf(mx, __shfl_xor(mx, 32));
             const float mnew = fmaxf(mrun[qg], mx);
@@ -237,19 +323,37 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
         Lq[qg] = (q < p.Nq) ? p.lse_in[si] * kLog2e : 1.0e30f;
         Dq[qg] = (q < p.Nq) ? p.delta[si] : 0.f;
     }
+    const float c = p.scale * kLog2e;
+#pragma unroll
+    for (int qg = 0; qg < 2; ++qg)          // scores leave the MFMA already multiplied by scale*log2(e)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) qf[qg][ks][e] = (half_t)((float)qf[qg][ks][e] * c);
     floatx4 acc[DT][2];
 #pragma unroll
     for (int i = 0; i < DT; ++i) { acc[i][0] = zero4f(); acc[i][1] = zero4f(); }
-    const float c = p.scale * kLog2e;
 
+    const half_t* kbase = p.k + (size_t)b * p.Nk * p.ldk + h * D;
+    const half_t* vbase = p.v + (size_t)b * p.Nk * p.ldv + h * D;
+    TileRegs<BKV, DP> rk, rv;
+    {
+        const int rows0 = p.Nk < BKV ? p.Nk : BKV;
+        tile_load<BKV, DP, true>(rk, kbase, p.ldk, rows0, D, t);
+        tile_load<BKV, DP, false>(rv, vbase, p.ldv, rows0, D, t);
+    }
     for (int kv0 = 0; kv0 < p.Nk; kv0 += BKV) {
         const int rows = (p.Nk - kv0 < BKV) ? p.Nk - kv0 : BKV;
-        const half_t* kg = p.k + ((size_t)b * p.Nk + kv0) * p.ldk + h * D;
         __syncthreads();
-        stage_rows<BKV, DP, LDK>(Ks, kg, p.ldk, rows, D, t);
-        stage_rows<BKV, DP, LDK>(Vs, p.v + ((size_t)b * p.Nk + kv0) * p.ldv + h * D, p.ldv, rows, D, t);
-        stage_cols<BKV, DT * 16, LDT>(Kt, kg, p.ldk, rows, D, t);
+        tile_store_rows_rf<BKV, DP, LDK>(rk, Ks, t);           // K once in registers -> row-major AND transposed tiles
+        tile_store_cols_n<BKV, DP, DT * 16, LDT>(rk, Kt, t);
+        tile_store_rows<BKV, DP, LDK>(rv, Vs, t);
         __syncthreads();
+        if (kv0 + BKV < p.Nk) {
+            const int nrows = (p.Nk - kv0 - BKV < BKV) ? p.Nk - kv0 - BKV : BKV;
+            tile_load<BKV, DP, true>(rk, kbase + (size_t)(kv0 + BKV) * p.ldk, p.ldk, nrows, D, t);
+            tile_load<BKV, DP, false>(rv, vbase + (size_t)(kv0 + BKV) * p.ldv, p.ldv, nrows, D, t);
+        }
 
         floatx4 s[KT][2], dp[KT][2];
 #pragma unroll
@@ -272,7 +376,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const bool ok = (kt * 16 + 4 * g + r) < rows;
-                    const float pv = ok ? exp2f(s[kt][qg][r] * c - Lq[qg]) : 0.f;
+                    const float pv = ok ? exp2f(s[kt][qg][r] - Lq[qg]) : 0.f;
                     s[kt][qg][r] = pv * (dp[kt][qg][r] - Dq[qg]);  // dS^T
                 }
 #pragma unroll
@@ -344,10 +448,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs p) {
         const half_t* qg_ = p.q + ((size_t)b * p.Nq + qq) * p.ldq + h * D;
         const half_t* dog = p.dO + ((size_t)b * p.Nq + qq) * p.lddo + h * D;
         __syncthreads();
-        stage_rows<BQT, DP, LDK>(Qs, qg_, p.ldq, rows, D, t);
-        stage_rows<BQT, DP, LDK>(dOs, dog, p.lddo, rows, D, t);
-        stage_cols<BQT, DT * 16, LDT>(Qt, qg_, p.ldq, rows, D, t);
-        stage_cols<BQT, DT * 16, LDT>(dOt, dog, p.lddo, rows, D, t);
+        {
+            TileRegs<BQT, DP> rq, rdo;                       // each operand is fetched once and stored twice
+            tile_load<BQT, DP, true>(rq, qg_, p.ldq, rows, D, t);
+            tile_load<BQT, DP, true>(rdo, dog, p.lddo, rows, D, t);
+            tile_store_rows_rf<BQT, DP, LDK>(rq, Qs, t);
+            tile_store_cols_n<BQT, DP, DT * 16, LDT>(rq, Qt, t);
+            tile_store_rows_rf<BQT, DP, LDK>(rdo, dOs, t);
+            tile_store_cols_n<BQT, DP, DT * 16, LDT>(rdo, dOt, t);
+        }
         if (t < BQT) {
             const size_t si = ((size_t)b * p.H + h) * p.Nq + qq + t;
             Ls[t] = (t < rows) ? p.lse_in[si] * kLog2e : 1.0e30f;

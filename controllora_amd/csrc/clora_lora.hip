@@ -8,7 +8,7 @@
 //                                        share X write disjoint column ranges of one T buffer
 //   up   : acc += s * T . U^T            inside the projection GEMM epilogue (clora_gemm.hip)
 //   up (explicit) for the control term   hidden + s*to_control(ctrl)     (this file)
-//   wgrad: dU = s * dY^T . T,  dD = dT^T . X    skinny reductions over M (LDS fold + one fp32 atomic per element)
+//   wgrad: dU = s * dY^T . T,  dD = dT^T . X    skinny reductions over M (one wave per workgroup, fp32 atomics)
 #include "clora_common.h"
 #include "../../include/clora.h"
 
@@ -111,21 +111,18 @@ __global__ __launch_bounds__(256) void lora_up_kernel(UpArgs p) {
 }
 
 // G[n*gs_n + j*gs_j] += scale * sum_m A[m, n] * T[m, toff + j]      (adapter weight gradients)
-// Pure HBM stream over A: lane owns 8 columns (16-byte loads, a wave spans 512 columns), every wave keeps 8
-// rows in flight, the T row is wave-uniform (scalar loads).  The 4 waves of a block are folded with LDS atomics
-// and the block adds its [<=512 x R] slab to G with one fp32 atomic per element.
+// Pure HBM stream over A.  One WAVE per workgroup (no LDS, no barriers): lane owns 8 columns (16-byte loads, a
+// wave spans 512 columns) and keeps 16 rows in flight; the T rows are wave-uniform (batched scalar loads);
+// every wave adds its [<=512 x R] partial to G with fp32 atomics (lanes own distinct columns: conflict-free).
 template <int RT>
-__global__ __launch_bounds__(256) void lora_wgrad_kernel(const half_t* __restrict__ A, const float* __restrict__ T,
-                                                         float* __restrict__ G, int lda, int ldt, int toff, int gs_n,
-                                                         int gs_j, int M, int N, int R, int a_rows, int rows_per_block,
-                                                         float scale) {
-    __shared__ float red[64 * 8 * RT];
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l = threadIdx.x & 63;
-    for (int i = threadIdx.x; i < 64 * 8 * RT; i += 256) red[i] = 0.f;
+__global__ __launch_bounds__(64) void lora_wgrad_kernel(const half_t* __restrict__ A, const float* __restrict__ T,
+                                                        float* __restrict__ G, int lda, int ldt, int toff, int gs_n,
+                                                        int gs_j, int M, int N, int R, int a_rows, int rows_per_wave,
+                                                        float scale) {
+    const int l = threadIdx.x;
     const int n = (blockIdx.x * 64 + l) * 8;
-    const int rpw = rows_per_block / 4;
-    const int m_beg = blockIdx.y * rows_per_block + w * rpw;
-    int m_end = m_beg + rpw;
+    const int m_beg = blockIdx.y * rows_per_wave;
+    int m_end = m_beg + rows_per_wave;
     if (m_end > M) m_end = M;
     const bool nok = n < N;  // N % 8 == 0
     float acc[8][RT];
@@ -133,9 +130,11 @@ __global__ __launch_bounds__(256) void lora_wgrad_kernel(const half_t* __restric
     for (int e = 0; e < 8; ++e)
 #pragma unroll
         for (int j = 0; j < RT; ++j) acc[e][j] = 0.f;
-    constexpr int UN = 8;
+    constexpr int UN = (RT <= 8) ? 16 : 8;     // rows in flight
     for (int mb = m_beg; mb < m_end; mb += UN) {
         half8 a[UN];
+        float tv[UN][RT];
+        // issue every load of the batch first (16-byte vector loads of A, scalar loads of the wave-uniform T rows) ...
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             const int m = mb + u;
@@ -147,32 +146,25 @@ __global__ __launch_bounds__(256) void lora_wgrad_kernel(const half_t* __restric
         }
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
-            const int m = mb + u;
-            if (m < m_end) {
-                const float* tr = T + (size_t)m * ldt + toff;
+            const int m = (mb + u < m_end) ? mb + u : m_end - 1;
+            const float* tr = T + (size_t)m * ldt + toff;
 #pragma unroll
-                for (int j = 0; j < RT; ++j)
-                    if (j < R) {
-                        const float tv = tr[j];
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) acc[e][j] += (float)a[u][e] * tv;
-                    }
-            }
+            for (int j = 0; j < RT; ++j) tv[u][j] = (j < R && mb + u < m_end) ? tr[j] : 0.f;
         }
+        // ... then consume
+#pragma unroll
+        for (int u = 0; u < UN; ++u)
+#pragma unroll
+            for (int j = 0; j < RT; ++j)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e][j] += (float)a[u][e] * tv[u][j];
     }
-    __syncthreads();
     if (nok) {
 #pragma unroll
         for (int e = 0; e < 8; ++e)
 #pragma unroll
             for (int j = 0; j < RT; ++j)
-                if (j < R) atomicAdd(&red[(l * 8 + e) * RT + j], acc[e][j]);
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < 64 * 8 * RT; i += 256) {
-        const int col = i / RT, j = i - col * RT;
-        const int nn = blockIdx.x * 512 + col;
-        if (nn < N && j < R) atomicAdd(G + (size_t)nn * gs_n + (size_t)j * gs_j, scale * red[i]);
+                if (j < R) atomicAdd(G + (size_t)(n + e) * gs_n + (size_t)j * gs_j, scale * acc[e][j]);
     }
 }
 
@@ -211,15 +203,15 @@ extern "C" int clora_lora_wgrad_f16(const clora_half* A, int lda, const float* T
                                     int gs_j, int M, int N, int R, float scale, int a_rows, void* stream) {
     if (!A || !T || !G || M <= 0 || N <= 0 || R <= 0 || (N & 7) || (lda & 7)) return CLORA_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
-    int rpb = 32;   // 4 waves x 8 rows; grow until the grid is at most ~192 blocks (one fp32 atomic per element per block)
-    while ((long)clora_cdiv(N, 512) * clora_cdiv(M, rpb) > 192) rpb *= 2;
+    int rpb = 16;   // rows per wave: at least one 16-row batch, at most ~512 waves (one fp32 atomic per element per wave)
+    while ((long)clora_cdiv(N, 512) * clora_cdiv(M, rpb) > 512) rpb *= 2;
     for (int r0 = 0; r0 < R; r0 += 16) {
         const int Rp = (R - r0 < 16) ? R - r0 : 16, to = toff + r0;
         float* Gp = G + (size_t)r0 * gs_j;
         const dim3 grid(clora_cdiv(N, 512), clora_cdiv(M, rpb));
-        if (Rp <= 4) hipLaunchKernelGGL((lora_wgrad_kernel<4>), grid, dim3(256), 0, s, (const half_t*)A, T, Gp, lda, ldt, to, gs_n, gs_j, M, N, Rp, a_rows, rpb, scale);
-        else if (Rp <= 8) hipLaunchKernelGGL((lora_wgrad_kernel<8>), grid, dim3(256), 0, s, (const half_t*)A, T, Gp, lda, ldt, to, gs_n, gs_j, M, N, Rp, a_rows, rpb, scale);
-        else hipLaunchKernelGGL((lora_wgrad_kernel<16>), grid, dim3(256), 0, s, (const half_t*)A, T, Gp, lda, ldt, to, gs_n, gs_j, M, N, Rp, a_rows, rpb, scale);
+        if (Rp <= 4) hipLaunchKernelGGL((lora_wgrad_kernel<4>), grid, dim3(64), 0, s, (const half_t*)A, T, Gp, lda, ldt, to, gs_n, gs_j, M, N, Rp, a_rows, rpb, scale);
+        else if (Rp <= 8) hipLaunchKernelGGL((lora_wgrad_kernel<8>), grid, dim3(64), 0, s, (const half_t*)A, T, Gp, lda, ldt, to, gs_n, gs_j, M, N, Rp, a_rows, rpb, scale);
+        else hipLaunchKernelGGL((lora_wgrad_kernel<16>), grid, dim3(64), 0, s, (const half_t*)A, T, Gp, lda, ldt, to, gs_n, gs_j, M, N, Rp, a_rows, rpb, scale);
     }
     return clora_check_launch();
 }
