@@ -53,7 +53,7 @@ _PROTOS = {
     "clora_geglu_bwd_f16": [_P, _P, _P, _I, _I, _P],
     "clora_lora_down_f16": [_P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P],
     "clora_lora_up_f16": [_P, _I, _P, _I, _I, _P, _I, _I, _P, _I, _I, _I, _I, _F, _P],
-    "clora_lora_wgrad_f16": [_P, _I, _P, _I, _I, _P, _I, _I, _I, _I, _I, _F, _I, _P],
+    "clora_lora_wgrad_f16": [_P, _I, _P, _I, _I, _P, _I, _I, _I, _I, _I, _F, _I, _P, _Z, _P],
     "clora_add_f16": [_P, _P, _P, _Z, _P],
     "clora_silu_f16": [_P, _P, _Z, _P],
     "clora_silu_bwd_f16": [_P, _P, _P, _Z, _P],
@@ -68,6 +68,7 @@ _PROTOS = {
     "clora_adamw_flat_f32": [_P, _P, _P, _P, _Z, _P, _F, _F, _F, _F, _F, _P],
     "clora_abi_version": [],
     "clora_groupnorm_workspace_bytes": [_I, _I, _I, _I, _I, _I],
+    "clora_lora_wgrad_workspace_bytes": [_I, _I, _I],
 }
 
 
@@ -88,6 +89,7 @@ class Lib:
             fn.restype = C.c_int
         self.cdll.clora_build_info.restype = C.c_char_p
         self.cdll.clora_groupnorm_workspace_bytes.restype = C.c_size_t
+        self.cdll.clora_lora_wgrad_workspace_bytes.restype = C.c_size_t
 
     def call(self, name: str, *args) -> None:
         rc = getattr(self.cdll, name)(*args)

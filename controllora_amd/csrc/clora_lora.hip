@@ -8,7 +8,7 @@
 //                                        share X write disjoint column ranges of one T buffer
 //   up   : acc += s * T . U^T            inside the projection GEMM epilogue (clora_gemm.hip)
 //   up (explicit) for the control term   hidden + s*to_control(ctrl)     (this file)
-//   wgrad: dU = s * dY^T . T,  dD = dT^T . X    skinny reductions over M (one wave per workgroup, fp32 atomics)
+//   wgrad: dU = s * dY^T . T,  dD = dT^T . X    skinny reductions over M, two deterministic stages, no atomics
 #include "clora_common.h"
 #include "../../include/clora.h"
 
@@ -111,18 +111,22 @@ __global__ __launch_bounds__(256) void lora_up_kernel(UpArgs p) {
 }
 
 // G[n*gs_n + j*gs_j] += scale * sum_m A[m, n] * T[m, toff + j]      (adapter weight gradients)
-// Pure HBM stream over A.  One WAVE per workgroup (no LDS, no barriers): lane owns 8 columns (16-byte loads, a
-// wave spans 512 columns) and keeps 16 rows in flight; the T rows are wave-uniform (batched scalar loads);
-// every wave adds its [<=512 x R] partial to G with fp32 atomics (lanes own distinct columns: conflict-free).
+// Pure HBM stream over A, reduced in two deterministic stages (same-address fp32 atomics serialise at ~0.2 us
+// each on this chip -- measured -- so they are avoided entirely):
+//   stage 1: block = 4 waves x rows_per_block/4 rows; lane owns 8 columns (16-byte loads, a wave spans 512
+//            columns), 16 rows in flight, wave-uniform T rows by batched scalar loads; the 4 waves fold through
+//            LDS and the block writes its [N x RT] slab to the workspace;
+//   stage 2: 64 outputs x 4 slab-lanes per block fold the slabs in a fixed order and add into G.
 template <int RT>
-__global__ __launch_bounds__(64) void lora_wgrad_kernel(const half_t* __restrict__ A, const float* __restrict__ T,
-                                                        float* __restrict__ G, int lda, int ldt, int toff, int gs_n,
-                                                        int gs_j, int M, int N, int R, int a_rows, int rows_per_wave,
-                                                        float scale) {
-    const int l = threadIdx.x;
+__global__ __launch_bounds__(256) void lora_wgrad_kernel(const half_t* __restrict__ A, const float* __restrict__ T,
+                                                         float* __restrict__ part, int lda, int ldt, int toff, int M,
+                                                         int N, int R, int a_rows, int rows_per_block) {
+    __shared__ float red[3 * 64 * 8 * RT / ((RT > 8) ? 2 : 1)];
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l = threadIdx.x & 63;
     const int n = (blockIdx.x * 64 + l) * 8;
-    const int m_beg = blockIdx.y * rows_per_wave;
-    int m_end = m_beg + rows_per_wave;
+    const int rpw = rows_per_block / 4;
+    const int m_beg = blockIdx.y * rows_per_block + w * rpw;
+    int m_end = m_beg + rpw;
     if (m_end > M) m_end = M;
     const bool nok = n < N;  // N % 8 == 0
     float acc[8][RT];
@@ -130,11 +134,10 @@ __global__ __launch_bounds__(64) void lora_wgrad_kernel(const half_t* __restrict
     for (int e = 0; e < 8; ++e)
 #pragma unroll
         for (int j = 0; j < RT; ++j) acc[e][j] = 0.f;
-    constexpr int UN = (RT <= 8) ? 16 : 8;     // rows in flight
+    constexpr int UN = (RT <= 8) ? 16 : 8;     // rows in flight per wave
     for (int mb = m_beg; mb < m_end; mb += UN) {
         half8 a[UN];
         float tv[UN][RT];
-        // issue every load of the batch first (16-byte vector loads of A, scalar loads of the wave-uniform T rows) ...
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             const int m = mb + u;
@@ -149,9 +152,8 @@ __global__ __launch_bounds__(64) void lora_wgrad_kernel(const half_t* __restrict
             const int m = (mb + u < m_end) ? mb + u : m_end - 1;
             const float* tr = T + (size_t)m * ldt + toff;
 #pragma unroll
-            for (int j = 0; j < RT; ++j) tv[u][j] = (j < R && mb + u < m_end) ? tr[j] : 0.f;
+            for (int j = 0; j < RT; ++j) tv[u][j] = (j < R && mb + u < m_end && m_end > m_beg) ? tr[j] : 0.f;
         }
-        // ... then consume
 #pragma unroll
         for (int u = 0; u < UN; ++u)
 #pragma unroll
@@ -159,12 +161,62 @@ __global__ __launch_bounds__(64) void lora_wgrad_kernel(const half_t* __restrict
 #pragma unroll
                 for (int e = 0; e < 8; ++e) acc[e][j] += (float)a[u][e] * tv[u][j];
     }
-    if (nok) {
+    // fold the 4 waves (fixed order) -- in two halves of the 8 columns when RT = 16 to stay inside 48 KB of LDS
+    constexpr int HALF = (RT > 8) ? 2 : 1, EC = 8 / HALF;
+    float* out = part + ((size_t)blockIdx.y * N + n) * RT;
 #pragma unroll
-        for (int e = 0; e < 8; ++e)
+    for (int hh = 0; hh < HALF; ++hh) {
+        if (hh) __syncthreads();
+        if (w > 0) {
 #pragma unroll
-            for (int j = 0; j < RT; ++j)
-                if (j < R) atomicAdd(G + (size_t)(n + e) * gs_n + (size_t)j * gs_j, scale * acc[e][j]);
+            for (int e = 0; e < EC; ++e)
+#pragma unroll
+                for (int j = 0; j < RT; ++j) red[(((w - 1) * 64 + l) * EC + e) * RT + j] = acc[hh * EC + e][j];
+        }
+        __syncthreads();
+        if (w == 0 && nok) {
+#pragma unroll
+            for (int e = 0; e < EC; ++e)
+#pragma unroll
+                for (int j = 0; j < RT; ++j) {
+                    float sacc = acc[hh * EC + e][j];
+#pragma unroll
+                    for (int ww = 0; ww < 3; ++ww) sacc += red[((ww * 64 + l) * EC + e) * RT + j];
+                    out[(hh * EC + e) * RT + j] = sacc;
+                }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void lora_wgrad_finish_kernel(const float* __restrict__ part, float* __restrict__ G,
+                                                                int nblk, int N, int RT, int R, int gs_n, int gs_j,
+                                                                float scale) {
+    __shared__ float red[256];
+    const int t = threadIdx.x, o = t & 63, q = t >> 6;
+    const int i = blockIdx.x * 64 + o;
+    const int total = N * RT;
+    float s = 0.f;
+    if (i < total) {
+        const size_t stride = (size_t)total;
+        int b = q;
+        for (; b + 28 < nblk; b += 32) {        // 8 independent loads in flight
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(b + 4 * u) * stride + i];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; b < nblk; b += 4) s += part[(size_t)b * stride + i];
+    }
+    red[t] = s;
+    __syncthreads();
+    if (q == 0 && i < total) {
+        const int n = i / RT, j = i - n * RT;
+        if (j < R) {
+            s = red[o] + red[64 + o] + red[128 + o] + red[192 + o];
+            float* dst = G + (size_t)n * gs_n + (size_t)j * gs_j;
+            *dst += scale * s;
+        }
     }
 }
 
@@ -199,19 +251,37 @@ extern "C" int clora_lora_up_f16(const clora_half* base, int ldb, const float* T
     return clora_check_launch();
 }
 
+namespace {
+int wgrad_rows_per_block(int M, int N) {
+    int rpb = 64;   // 4 waves x one 16-row batch; grow until the grid is at most ~256 blocks
+    while ((long)clora_cdiv(N, 512) * clora_cdiv(M, rpb) > 256) rpb *= 2;
+    return rpb;
+}
+}  // namespace
+
+extern "C" size_t clora_lora_wgrad_workspace_bytes(int M, int N, int R) {
+    const int rt = R <= 4 ? 4 : (R <= 8 ? 8 : 16);
+    return (size_t)clora_cdiv(M, wgrad_rows_per_block(M, N)) * N * rt * sizeof(float);
+}
+
 extern "C" int clora_lora_wgrad_f16(const clora_half* A, int lda, const float* T, int ldt, int toff, float* G, int gs_n,
-                                    int gs_j, int M, int N, int R, float scale, int a_rows, void* stream) {
+                                    int gs_j, int M, int N, int R, float scale, int a_rows, void* workspace,
+                                    size_t workspace_bytes, void* stream) {
     if (!A || !T || !G || M <= 0 || N <= 0 || R <= 0 || (N & 7) || (lda & 7)) return CLORA_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
-    int rpb = 16;   // rows per wave: at least one 16-row batch, at most ~512 waves (one fp32 atomic per element per wave)
-    while ((long)clora_cdiv(N, 512) * clora_cdiv(M, rpb) > 512) rpb *= 2;
+    const int rpb = wgrad_rows_per_block(M, N);
+    const int nblk = clora_cdiv(M, rpb);
     for (int r0 = 0; r0 < R; r0 += 16) {
         const int Rp = (R - r0 < 16) ? R - r0 : 16, to = toff + r0;
-        float* Gp = G + (size_t)r0 * gs_j;
-        const dim3 grid(clora_cdiv(N, 512), clora_cdiv(M, rpb));
-        if (Rp <= 4) hipLaunchKernelGGL((lora_wgrad_kernel<4>), grid, dim3(64), 0, s, (const half_t*)A, T, Gp, lda, ldt, to, gs_n, gs_j, M, N, Rp, a_rows, rpb, scale);
-        else if (Rp <= 8) hipLaunchKernelGGL((lora_wgrad_kernel<8>), grid, dim3(64), 0, s, (const half_t*)A, T, Gp, lda, ldt, to, gs_n, gs_j, M, N, Rp, a_rows, rpb, scale);
-        else hipLaunchKernelGGL((lora_wgrad_kernel<16>), grid, dim3(64), 0, s, (const half_t*)A, T, Gp, lda, ldt, to, gs_n, gs_j, M, N, Rp, a_rows, rpb, scale);
+        const int rt = Rp <= 4 ? 4 : (Rp <= 8 ? 8 : 16);
+        if (!workspace || workspace_bytes < (size_t)nblk * N * rt * sizeof(float)) return CLORA_ERR_WORKSPACE;
+        float* part = (float*)workspace;
+        const dim3 grid(clora_cdiv(N, 512), nblk);
+        if (rt == 4) hipLaunchKernelGGL((lora_wgrad_kernel<4>), grid, dim3(256), 0, s, (const half_t*)A, T, part, lda, ldt, to, M, N, Rp, a_rows, rpb);
+        else if (rt == 8) hipLaunchKernelGGL((lora_wgrad_kernel<8>), grid, dim3(256), 0, s, (const half_t*)A, T, part, lda, ldt, to, M, N, Rp, a_rows, rpb);
+        else hipLaunchKernelGGL((lora_wgrad_kernel<16>), grid, dim3(256), 0, s, (const half_t*)A, T, part, lda, ldt, to, M, N, Rp, a_rows, rpb);
+        hipLaunchKernelGGL(lora_wgrad_finish_kernel, dim3(clora_cdiv(N * rt, 64)), dim3(256), 0, s, part,
+                           G + (size_t)r0 * gs_j, nblk, N, rt, Rp, gs_n, gs_j, scale);
     }
     return clora_check_launch();
 }

@@ -244,8 +244,9 @@ def lora_up(base, T, toff, U, M, N, scale, out=None, u_tr=False):
 def lora_wgrad(A, T, toff, G, gs_n, gs_j, M, N, R, scale=1.0, a_rows=0, lda=None):
     """G[n*gs_n + j*gs_j] += scale * sum_m A[m,n] T[m,toff+j]"""
     assert G.dtype == f32 and T.dtype == f32
+    ws = workspace(capi.lib().cdll.clora_lora_wgrad_workspace_bytes(M, N, R), A.device)
     _call("clora_lora_wgrad_f16", ptr(A, f16), lda if lda is not None else A.stride(0), ptr(T), T.stride(0), toff, ptr(G),
-          gs_n, gs_j, M, N, R, float(scale), a_rows, nbytes=2.0 * M * N)
+          gs_n, gs_j, M, N, R, float(scale), a_rows, ptr(ws), ws.numel(), nbytes=2.0 * M * N)
     return G
 
 

@@ -134,9 +134,12 @@ int clora_lora_down_f16(const clora_half* X, int ldx, const float* D, int ldd, f
  * "hidden + to_control(control)" of models.py:214-218,237-238 and the V2 pre/post adds (:369,:415). */
 int clora_lora_up_f16(const clora_half* base, int ldb, const float* T, int ldt, int toff, const float* U, int ldu,
                       int u_transposed, clora_half* Y, int ldy, int M, int N, int R, float scale, void* stream);
-/* G[n*gs_n + j*gs_j] += scale * sum_m A[m, n] * T[m, toff+j]  (adapter weight gradients; fp32 atomics). */
+/* G[n*gs_n + j*gs_j] += scale * sum_m A[m, n] * T[m, toff+j]  (adapter weight gradients; two-stage
+ * deterministic reduction through `workspace` of clora_lora_wgrad_workspace_bytes(M, N, R) bytes, no atomics). */
+size_t clora_lora_wgrad_workspace_bytes(int M, int N, int R);
 int clora_lora_wgrad_f16(const clora_half* A, int lda, const float* T, int ldt, int toff, float* G, int gs_n, int gs_j,
-                         int M, int N, int R, float scale, int a_rows, void* stream);
+                         int M, int N, int R, float scale, int a_rows, void* workspace, size_t workspace_bytes,
+                         void* stream);
 
 /* ---- small elementwise / data-movement kernels on the path */
 int clora_add_f16(const clora_half* a, const clora_half* b, clora_half* y, size_t n, void* stream);
