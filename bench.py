@@ -110,6 +110,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-ddim", action="store_true", help="skip the secondary inference measurement")
+    ap.add_argument("--no-graph", action="store_true", help="issue the step eagerly instead of replaying hipGraphs")
     ap.add_argument("--ddim-batch", type=int, default=16)
     args = ap.parse_args()
 
@@ -133,8 +134,15 @@ def main():
     batch = synthetic_batch(args.batch, args.res, dev, 42 + rank)         # data-parallel: different samples per rank
     noisy = DDPMScheduler().add_noise(batch["latents"], batch["noise"], batch["timesteps"]).half()
 
-    def step():
+    def eager_step():
         trainer.step(noisy, batch["timesteps"], batch["ehs"], batch["guide"], batch["noise"])
+
+    graphed = not args.no_graph
+    if graphed:
+        trainer.capture(noisy, batch["timesteps"], batch["ehs"], batch["guide"], batch["noise"])
+        step = trainer.step_graphed          # same kernels, same work: the launches are replayed from hipGraphs
+    else:
+        step = eager_step
 
     for _ in range(args.warmup):
         step()
@@ -160,7 +168,7 @@ def main():
     roofline = None
     if not args.no_roofline and rank == 0:
         K.PROFILER = K.KernelProfiler()
-        step()
+        eager_step()
         agg = K.PROFILER.summary()
         K.PROFILER = None
         total_ms = sum(a["ms"] for a in agg.values())
@@ -210,7 +218,7 @@ def main():
             "config": {"workload": f"configs/fill50k.json on SD-1.5 topology (seeded random weights), {args.res}x{args.res}, "
                                    f"bs={args.batch}/GPU, fp16; hot path = hint encoder + UNet fwd/bwd + adapter AdamW; "
                                    f"latents/text embeddings synthetic (VAE/CLIP outside the hot path)",
-                       "global_batch": args.batch * world, "parallelism": f"dp{world}",
+                       "global_batch": args.batch * world, "parallelism": f"dp{world}", "hipgraph": graphed,
                        "allreduce_bytes": trainer.flat.numel * 4},
             "loss": round(loss, 5), "steps_skipped_by_scaler": skipped,
             "roofline": roofline, "ddim50": ddim, "cpu_baseline": cpu}))

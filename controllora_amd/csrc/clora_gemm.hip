@@ -29,7 +29,7 @@ struct GemmArgs {
     clora_epilogue_t epi;
 };
 
-// everything of the epilogue that happens BEFORE the fp16 rounding
+// everything of the epilogue that happens BEFORE the fp16 rounding (scalar form: split-K finish, v1 kernel)
 __device__ __forceinline__ float epi_pre(float acc, int m, int n, const clora_epilogue_t& e) {
     if (e.bias) acc += e.bias[n];
     if (e.rowadd) acc += (float)((const half_t*)e.rowadd)[(size_t)(m / e.rows_per_batch) * e.ld_rowadd + n];
@@ -47,6 +47,57 @@ __device__ __forceinline__ float epi_pre(float acc, int m, int n, const clora_ep
         acc += e.lora_scale * s;
     }
     return acc;
+}
+
+// Row-chunk form: 8 consecutive columns n..n+7 of row m (n % 8 == 0, lora_seg % 16 == 0 so the chunk belongs to
+// one adapter).  Bias, U and the rank-r row of T are fetched with float4 loads -- instead of 2r scalar loads
+// per output element.  Used by the LDS-staged epilogue of the DMA kernel and by the split-K finish kernel.
+__device__ __forceinline__ void epi_chunk8(float (&v)[8], int m, int n, const clora_epilogue_t& e) {
+    if (e.bias) {
+        const floatx4 b0 = *reinterpret_cast<const floatx4*>(e.bias + n), b1 = *reinterpret_cast<const floatx4*>(e.bias + n + 4);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { v[q] += b0[q]; v[4 + q] += b1[q]; }
+    }
+    if (e.rowadd) {
+        const half8 ra = ld8((const half_t*)e.rowadd + (size_t)(m / e.rows_per_batch) * e.ld_rowadd + n);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] += (float)ra[q];
+    }
+    if (e.lora_t) {
+        const int R = e.lora_r;
+        const int toff = (n / e.lora_seg) * R;
+        const float* tp = e.lora_t + (size_t)m * e.ldt + toff;
+        const bool tvec = ((e.ldt | toff) & 3) == 0;
+        for (int j0 = 0; j0 < R; j0 += 4) {
+            floatx4 t = zero4f();
+            if (j0 + 4 <= R && tvec) t = *reinterpret_cast<const floatx4*>(tp + j0);
+            else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) if (j0 + q < R) t[q] = tp[j0 + q];
+            }
+            t *= e.lora_scale;
+            if (e.lora_u_tr) {                       // u(n, j) = U[j*ldu + n]: contiguous along n
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (j0 + q < R) {
+                        const float* up = e.lora_u + (size_t)(j0 + q) * e.ldu + n;
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) v[c] += t[q] * up[c];
+                    }
+            } else if (j0 + 4 <= R && (e.ldu & 3) == 0) {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const floatx4 u = *reinterpret_cast<const floatx4*>(e.lora_u + (size_t)(n + c) * e.ldu + j0);
+                    v[c] += t[0] * u[0] + t[1] * u[1] + t[2] * u[2] + t[3] * u[3];
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < 8; ++c)
+                    for (int q = 0; q < 4; ++q)
+                        if (j0 + q < R) v[c] += t[q] * e.lora_u[(size_t)(n + c) * e.ldu + j0 + q];
+            }
+        }
+    }
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -234,8 +285,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
 // Out-of-range / padding chunks are fetched from a 16-byte zero page.
 __device__ __attribute__((aligned(16))) const unsigned g_clora_zero16[4] = {0u, 0u, 0u, 0u};
 
+// blocks per CU the LDS ring allows (48 / 36 / 24 KB): the register allocator is told to leave room for them
+template <int BM, int BN> struct DmaOcc { static constexpr int v = (BM * BN >= 128 * 128) ? 3 : ((BM * BN >= 128 * 64) ? 4 : 6); };
+
 template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256) void gemm_dma_kernel(GemmArgs p) {
+__global__ __launch_bounds__(256, (DmaOcc<BM, BN>::v)) void gemm_dma_kernel(GemmArgs p) {
     constexpr int BK = 32, NST = 3;
     constexpr int FM = BM / WM / 16, FN = BN / WN / 16;
     constexpr int A_IN = BM / 64, B_IN = BN / 64;          // DMA wave-instructions per stage per wave
@@ -367,34 +421,45 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(GemmArgs p) {
                 }
         return;
     }
-    __syncthreads();                                           // every wave is done reading the last stage
-    half_t* Cs = smem;
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int ml = wm * FM * 16 + i * 16 + 4 * g + r;
-                const int nl = wn * FN * 16 + j * 16 + li;
-                const int m = m0 + ml, n = n0 + nl;
-                float v = acc[i][j][r];
-                if (m < p.M && n < p.N) v = epi_pre(v, m, n, p.epi);
-                Cs[ml * C_LD + nl] = (half_t)v;
-            }
-    __syncthreads();
+    // ---- epilogue: fp32 accumulators -> LDS (64 rows per pass) -> per row-chunk: bias / time-embedding / rank-r
+    // adapter update (float4 operand loads) -> fp16 -> + residual -> 16-byte coalesced stores.  Doing the fused
+    // math AFTER the LDS hop keeps it out of the main loop's register budget (3 blocks per CU).
+    constexpr int PR = 64, F_LD = BN + 4, NPASS = BM / PR;
+    static_assert(PR * F_LD * 2 <= SMEM, "fp32 staging must fit in the ring buffer");
+    float* Cf = reinterpret_cast<float*>(smem);
     constexpr int CPR = BN / 8;
-    for (int c = t; c < BM * CPR; c += 256) {
-        const int ml = c / CPR, nc = c - ml * CPR;
-        const int m = m0 + ml, n = n0 + nc * 8;
-        if (m < p.M && n < p.N) {
-            half8 v = ld8(Cs + ml * C_LD + nc * 8);
-            if (p.epi.residual) {
-                const half8 rr = ld8((const half_t*)p.epi.residual + (size_t)m * p.epi.ldr + n);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)rr[e]);
+    for (int ph = 0; ph < NPASS; ++ph) {
+        __syncthreads();                                       // ring (or previous pass) fully consumed
+        const int wrow0 = wm * FM * 16;                        // first tile row of this wave
+        if (wrow0 >= ph * PR && wrow0 < (ph + 1) * PR) {
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        Cf[(wrow0 - ph * PR + i * 16 + 4 * g + r) * F_LD + wn * FN * 16 + j * 16 + li] = acc[i][j][r];
+        }
+        __syncthreads();
+        for (int c = t; c < PR * CPR; c += 256) {
+            const int ml = c / CPR, nc = c - ml * CPR;
+            const int m = m0 + ph * PR + ml, n = n0 + nc * 8;
+            if (m < p.M && n < p.N) {
+                const floatx4 f0 = *reinterpret_cast<const floatx4*>(Cf + ml * F_LD + nc * 8);
+                const floatx4 f1 = *reinterpret_cast<const floatx4*>(Cf + ml * F_LD + nc * 8 + 4);
+                float v[8] = {f0[0], f0[1], f0[2], f0[3], f1[0], f1[1], f1[2], f1[3]};
+                epi_chunk8(v, m, n, p.epi);
+                half8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (half_t)v[e];
+                if (p.epi.residual) {
+                    const half8 rr = ld8((const half_t*)p.epi.residual + (size_t)m * p.epi.ldr + n);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = (half_t)((float)o[e] + (float)rr[e]);
+                }
+                st8(p.C + (size_t)m * p.ldc + n, o);
             }
-            st8(p.C + (size_t)m * p.ldc + n, v);
         }
     }
 }
@@ -414,9 +479,10 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(GemmArgs p, int spli
 #pragma unroll
             for (int e = 0; e < 4; ++e) { s[e] += a[e]; s[4 + e] += b[e]; }
         }
+        epi_chunk8(s, m, n, p.epi);
         half8 v;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = (half_t)epi_pre(s[e], m, n + e, p.epi);
+        for (int e = 0; e < 8; ++e) v[e] = (half_t)s[e];
         if (p.epi.residual) {
             const half8 rr = ld8((const half_t*)p.epi.residual + (size_t)m * p.epi.ldr + n);
 #pragma unroll
@@ -584,7 +650,7 @@ extern "C" int clora_gemm_f16_ex(const clora_half* A, int lda, const clora_half*
         if (lda & 7) return CLORA_ERR_ARG;
     }
     if (epi) a.epi = *epi; else a.epi = clora_epilogue_t();
-    if (a.epi.lora_t && (a.epi.lora_r <= 0 || a.epi.lora_seg <= 0)) return CLORA_ERR_ARG;
+    if (a.epi.lora_t && (a.epi.lora_r <= 0 || a.epi.lora_seg <= 0 || (a.epi.lora_seg & 15))) return CLORA_ERR_ARG;
     if (a.epi.rowadd && a.epi.rows_per_batch <= 0) return CLORA_ERR_ARG;
     if (a.epi.residual && (a.epi.ldr & 7)) return CLORA_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;

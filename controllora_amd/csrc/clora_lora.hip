@@ -17,8 +17,10 @@ namespace {
 // T[m, toff+j] (+)= sum_k X[m,k] * D[j,k] on the matrix cores with fp32-equivalent accuracy:
 // D (fp32) is split on the fly into hi + lo fp16 halves (|D - hi - lo| <= 2^-22 |D|), X is exact fp16, products
 // are exact in the fp32 accumulator -- two v_mfma_f32_16x16x32_f16 per k-step.  One wave = 16 rows, fragments
-// are loaded straight from global (16 B per lane, 64-B row segments), no LDS: the kernel is a pure stream
-// over X with 1024 independent waves at the 64x64 level.
+// are loaded straight from global (16 B per lane, 64-B row segments), no LDS, no barriers.  The k loop is
+// processed four k-steps at a time with ALL loads of the group issued before the first use: the kernel is a
+// pure stream and would otherwise pay one full memory latency per k-step.
+// d_kmajor: D[j][k] lives at D[k*ldd + j] (an up matrix [K, r] acting as U^T in the backward pass).
 __global__ __launch_bounds__(256) void lora_down_kernel(const half_t* __restrict__ X, const float* __restrict__ D,
                                                         float* __restrict__ T, int ldx, int ldd, int ldt, int toff, int M,
                                                         int K, int R, int accumulate, int x_rows, int d_kmajor,
@@ -29,33 +31,45 @@ __global__ __launch_bounds__(256) void lora_down_kernel(const half_t* __restrict
     const bool mok = m < M;
     const size_t xoff = (size_t)(mok ? (x_rows > 0 ? m % x_rows : m) : 0) * ldx;
     const bool jok = li < R;
-    const float* drow = D + (d_kmajor ? (size_t)(jok ? li : 0) : (size_t)(jok ? li : 0) * ldd);
+    const int jj = jok ? li : 0;
     floatx4 acc = zero4f();
-    for (int k0 = 0; k0 < K; k0 += 32) {
-        const int k = k0 + g * 8;
-        half8 a = zero8(), bh = zero8(), bl = zero8();
-        if (k < K) {                       // K % 8 == 0: a chunk is all-valid or all-out
-            if (mok) a = ld8(X + xoff + k);
-            if (jok) {
-                floatx4 d0, d1;
-                if (d_kmajor) {        // D[j][k] stored at D[k*ldd + j]  (an up-projection matrix [N, r] used as U^T)
+    constexpr int G = 4;                                   // k-steps in flight
+    for (int k0 = 0; k0 < K; k0 += 32 * G) {
+        half8 a[G];
+        floatx4 d0[G], d1[G];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { d0[e] = drow[(size_t)(k + e) * ldd]; d1[e] = drow[(size_t)(k + 4 + e) * ldd]; }
-                } else {
-                    d0 = *reinterpret_cast<const floatx4*>(drow + k);
-                    d1 = *reinterpret_cast<const floatx4*>(drow + k + 4);
-                }
-                d0 *= dscale; d1 *= dscale;
+        for (int u = 0; u < G; ++u) {                      // issue every load of the group ...
+            const int k = k0 + u * 32 + g * 8;
+            a[u] = zero8(); d0[u] = zero4f(); d1[u] = zero4f();
+            if (k < K) {                                   // K % 8 == 0: a chunk is all-valid or all-out
+                if (mok) a[u] = ld8(X + xoff + k);
+                if (jok) {
+                    if (d_kmajor) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const half_t h0 = (half_t)d0[e], h1 = (half_t)d1[e];
-                    bh[e] = h0; bh[4 + e] = h1;
-                    bl[e] = (half_t)(d0[e] - (float)h0); bl[4 + e] = (half_t)(d1[e] - (float)h1);
+                        for (int e = 0; e < 4; ++e) {
+                            d0[u][e] = D[(size_t)(k + e) * ldd + jj];
+                            d1[u][e] = D[(size_t)(k + 4 + e) * ldd + jj];
+                        }
+                    } else {
+                        d0[u] = *reinterpret_cast<const floatx4*>(D + (size_t)jj * ldd + k);
+                        d1[u] = *reinterpret_cast<const floatx4*>(D + (size_t)jj * ldd + k + 4);
+                    }
                 }
             }
         }
-        acc = mfma16(a, bh, acc);
-        acc = mfma16(a, bl, acc);
+#pragma unroll
+        for (int u = 0; u < G; ++u) {                      // ... then split D into hi/lo halves and multiply
+            half8 bh, bl;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float f0 = d0[u][e] * dscale, f1 = d1[u][e] * dscale;
+                const half_t h0 = (half_t)f0, h1 = (half_t)f1;
+                bh[e] = h0; bh[4 + e] = h1;
+                bl[e] = (half_t)(f0 - (float)h0); bl[4 + e] = (half_t)(f1 - (float)h1);
+            }
+            acc = mfma16(a[u], bh, acc);
+            acc = mfma16(a[u], bl, acc);
+        }
     }
     // C layout: lane holds T[m0 + 4g + r][toff + li]
     if (jok) {
@@ -89,10 +103,27 @@ __global__ __launch_bounds__(256) void lora_up_kernel(UpArgs p) {
         float acc[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-        for (int j = 0; j < p.R; ++j) {
-            const float tv = tr[j];
+        if (p.u_tr && (p.ldu & 3) == 0) {                 // U^T rows are contiguous along n: two float4 per rank index
+            for (int j = 0; j < p.R; ++j) {
+                const float tv = tr[j];
+                const floatx4 u0 = *reinterpret_cast<const floatx4*>(p.U + (size_t)j * p.ldu + n);
+                const floatx4 u1 = *reinterpret_cast<const floatx4*>(p.U + (size_t)j * p.ldu + n + 4);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) acc[e] += tv * (p.u_tr ? p.U[(size_t)j * p.ldu + n + e] : p.U[(size_t)(n + e) * p.ldu + j]);
+                for (int e = 0; e < 4; ++e) { acc[e] += tv * u0[e]; acc[4 + e] += tv * u1[e]; }
+            }
+        } else if (!p.u_tr && p.R == 4 && p.ldu == 4 && ((p.ldt | p.toff) & 3) == 0) {   // the common rank-4 case
+            const floatx4 t4 = *reinterpret_cast<const floatx4*>(tr);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const floatx4 u = *reinterpret_cast<const floatx4*>(p.U + (size_t)(n + e) * 4);
+                acc[e] += t4[0] * u[0] + t4[1] * u[1] + t4[2] * u[2] + t4[3] * u[3];
+            }
+        } else {
+            for (int j = 0; j < p.R; ++j) {
+                const float tv = tr[j];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += tv * (p.u_tr ? p.U[(size_t)j * p.ldu + n + e] : p.U[(size_t)(n + e) * p.ldu + j]);
+            }
         }
         half8 o;
         if (p.base) {

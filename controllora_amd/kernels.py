@@ -20,7 +20,8 @@ class KernelProfiler:
     """Optional per-launch timing with HIP events recorded on the launch stream (bench.py's roofline leg).
     Off by default; never active inside a timed region."""
 
-    def __init__(self):
+    def __init__(self, detail=False):
+        self.detail = detail       # per-shape records (tools / debugging)
         self.records = []          # (entry point, start event, end event, algorithmic flops, algorithmic bytes)
 
     def summary(self):
@@ -38,7 +39,7 @@ class KernelProfiler:
 PROFILER: Optional[KernelProfiler] = None
 
 
-def _call(name, *args, flops=0.0, nbytes=0.0):
+def _call(name, *args, flops=0.0, nbytes=0.0, tag=None):
     if PROFILER is None:
         capi.lib().call(name, *args, capi.stream())
         return
@@ -46,7 +47,7 @@ def _call(name, *args, flops=0.0, nbytes=0.0):
     e0.record()
     capi.lib().call(name, *args, capi.stream())
     e1.record()
-    PROFILER.records.append((name, e0, e1, float(flops), float(nbytes)))
+    PROFILER.records.append((name if not (tag and PROFILER.detail) else f"{name}[{tag}]", e0, e1, float(flops), float(nbytes)))
 
 
 def _c2(t: torch.Tensor) -> torch.Tensor:
@@ -123,7 +124,8 @@ def gemm(A: torch.Tensor, Bw: torch.Tensor, M: int, N: int, K: int, *, lda: Opti
     _call("clora_gemm_f16_ex", ptr(A), lda if lda is not None else K, ptr(Bw), ptr(C_), ldc, M, N, K,
           C.byref(conv) if conv is not None else None, C.byref(e), split_k, tile_cfg,
           ptr(ws) if ws is not None else None, ws.numel() if ws is not None else 0,
-          flops=2.0 * M * N * K, nbytes=2.0 * (A.numel() + N * K + M * N))
+          flops=2.0 * M * N * K, nbytes=2.0 * (A.numel() + N * K + M * N),
+          tag=f"{M}x{N}x{K}{'conv' if conv is not None else ''}")
     return C_
 
 

@@ -83,6 +83,10 @@ class ControlLoRATrainer:
         if self.world > 1:
             torch.distributed.all_reduce(g, group=self.pg)           # RCCL over xGMI: one flat 24 MB buffer
             g.mul_(1.0 / self.world)
+        self._optimizer_kernels()
+
+    def _optimizer_kernels(self):
+        g = self.flat.grad
         K.grad_sumsq(g, self.state)
         K.optim_prep(self.state, self.hp["max_norm"], self.hp["beta1"], self.hp["beta2"], self.hp["dynamic"], 2.0, 0.5,
                      self.hp["interval"])
@@ -93,6 +97,40 @@ class ControlLoRATrainer:
         pred = self.forward_backward(noisy_latents, timesteps, encoder_hidden_states, guide, target)
         self.optimizer_step()
         return pred
+
+    # -- hipGraph capture -------------------------------------------------------------------------------------
+    def capture(self, noisy_latents, timesteps, encoder_hidden_states, guide, target, warmup=2):
+        """Capture the step into hipGraphs (the step issues ~2500 small launches; replaying a graph removes
+        the Python / launch overhead that otherwise bounds it).  Shapes become static: ``step_graphed`` copies a
+        new batch into the captured input buffers and replays.  With data parallelism the all-reduce stays an
+        eager RCCL call between the forward/backward graph and the optimizer graph."""
+        self._static = [t.clone() for t in (noisy_latents, timesteps, encoder_hidden_states, guide, target)]
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):                       # warm-up on a side stream (allocator / lazy packs settle)
+            for _ in range(warmup):
+                self.forward_backward(*self._static)
+                self.optimizer_step()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        self._g_fb = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._g_fb):
+            self._static_pred = self.forward_backward(*self._static)
+        self._g_opt = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._g_opt, pool=self._g_fb.pool()):
+            self._optimizer_kernels()
+        return self
+
+    def step_graphed(self, noisy_latents=None, timesteps=None, encoder_hidden_states=None, guide=None, target=None):
+        for dst, src in zip(self._static, (noisy_latents, timesteps, encoder_hidden_states, guide, target)):
+            if src is not None and src.data_ptr() != dst.data_ptr():
+                dst.copy_(src, non_blocking=True)
+        self._g_fb.replay()
+        if self.world > 1:
+            torch.distributed.all_reduce(self.flat.grad, group=self.pg)
+            self.flat.grad.mul_(1.0 / self.world)
+        self._g_opt.replay()
+        return self._static_pred
 
     # -- host-visible scalars (each forces a sync; call outside the timed region)
     def loss(self, numel) -> float:

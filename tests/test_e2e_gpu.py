@@ -62,3 +62,32 @@ def test_ddim_inference_loop_runs():
     lat = ddim_sample(unet, clora, inp["guide"][:1].half(), inp["ehs"][:1].half(), inp["ehs"][1:2].half(),
                       steps=4, guidance_scale=9.0, latents=inp["latents"][:1].half())
     assert lat.shape == (1, 4, 16, 16) and torch.isfinite(lat.float()).all()
+
+
+def test_graph_replay_matches_eager_step():
+    """The hipGraph-captured step (bench default) must do exactly the work of the eager step."""
+    out = []
+    for graphed in (False, True):
+        torch.manual_seed(0)
+        unet, params, clora = E.build_product_case("v1", "cuda")
+        from controllora_amd.train import ControlLoRATrainer
+        from oracle import cases, unet_ref
+        inp = {k: v.cuda() for k, v in cases.seeded_inputs().items()}
+        noisy = unet_ref.DDPMSchedule().add_noise(inp["latents"].cpu(), inp["noise"].cpu(), inp["timesteps"].cpu()).cuda().half()
+        tr = ControlLoRATrainer(unet, params, init_scale=128.0, dynamic_scale=False)
+        args = (noisy, inp["timesteps"], inp["ehs"].half(), inp["guide"].half(), inp["noise"].half())
+        start = tr.flat.data.clone()
+        if graphed:
+            tr.capture(*args, warmup=1)          # warm-up steps move the parameters: restore them
+            tr.flat.data.copy_(start); tr.flat.exp_avg.zero_(); tr.flat.exp_avg_sq.zero_(); tr.state[2] = 0
+            for _ in range(2):
+                tr.step_graphed(*args)
+        else:
+            for _ in range(2):
+                tr.step(*args)
+        torch.cuda.synchronize()
+        out.append((tr.flat.data.clone(), tr.loss(noisy.numel()), float(tr.state[2])))
+    (p0, l0, s0), (p1, l1, s1) = out
+    assert s0 == s1 == 2.0
+    assert abs(l0 - l1) < 1e-5 * max(1.0, abs(l0))
+    assert float((p0 - p1).norm() / p0.norm()) < 1e-5
