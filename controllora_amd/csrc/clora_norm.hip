@@ -3,8 +3,10 @@
 // HBM-bound kernels: every pass reads/writes whole 16-byte channel chunks of
 // full rows, so global traffic is coalesced regardless of how channels split into groups
 // (C/32 = 10 channels per group at C=320 is not a multiple of the 8-channel load width).
-//   GroupNorm forward : partial (sum, sumsq per (b, row-chunk, group)) -> finalize (mean, rstd) -> apply
-//   GroupNorm backward: partial (s1 = sum dy*gamma, s2 = sum dy*gamma*xhat) -> finalize -> apply
+//   GroupNorm forward : partial (sum, sumsq per (b, row-chunk, group), deterministic block reduce) -> apply
+//                       (each block re-folds the partials of its batch element and keeps its per-channel
+//                       scale/shift in registers: two launches, no atomics, no coefficient table)
+//   GroupNorm backward: partial (s1 = sum dy*gamma, s2 = sum dy*gamma*xhat) -> apply (dx = k1*dy' + k2*x + k3)
 //   LayerNorm         : one wave per row, the row lives in registers (two-pass variance), no workspace.
 #include "clora_common.h"
 #include "../../include/clora.h"
@@ -258,6 +260,122 @@ __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(GnArgs p) {
     }
 }
 
+// ---- fused finalize + apply (forward): every block re-folds the chunk partials of its batch element (a few KB
+// from L2) into group statistics, derives the per-channel scale/shift of ITS OWN columns into registers and
+// streams its rows: no coefficient table, no separate finalize launch.
+__device__ __forceinline__ void gn_fold_groups(const GnArgs& p, int b, int t, float* out2, float inv_n) {
+    const int g = t >> 2, part = t & 3;
+    float s = 0.f, q = 0.f;
+    if (g < p.G)
+        for (int c = part; c < p.nchunk; c += 4) {
+            const float* pp = p.partial + (((size_t)b * p.nchunk + c) * p.G + g) * 2;
+            s += pp[0]; q += pp[1];
+        }
+    s += __shfl_xor(s, 1); q += __shfl_xor(q, 1);
+    s += __shfl_xor(s, 2); q += __shfl_xor(q, 2);
+    if (g < p.G && part == 0) { out2[g * 2] = s * inv_n; out2[g * 2 + 1] = q * inv_n; }
+}
+
+__global__ __launch_bounds__(256) void gn_fwd_apply2_kernel(GnArgs p) {
+    __shared__ float mr[64 * 2];
+    const int t = threadIdx.x, b = blockIdx.y, chunk = blockIdx.x;
+    const int CH = p.C / 8, cpg = p.C / p.G;
+    gn_fold_groups(p, b, t, mr, 1.0f / ((float)p.HW * (float)cpg));
+    __syncthreads();
+    if (t < p.G) {                                  // (E[x], E[x^2]) -> (mean, rstd)
+        const float mean = mr[t * 2];
+        float var = mr[t * 2 + 1] - mean * mean;
+        var = var < 0.f ? 0.f : var;
+        const float rstd = rsqrtf(var + p.eps);
+        mr[t * 2 + 1] = rstd;
+        if (chunk == 0) { p.stats[((size_t)b * p.G + t) * 2] = mean; p.stats[((size_t)b * p.G + t) * 2 + 1] = rstd; }
+    }
+    __syncthreads();
+    int rl, nrl, c0, cstep; bool active;
+    gn_thread_map(t, CH, rl, nrl, c0, cstep, active);
+    float sc[kMaxCols][8], sh[kMaxCols][8];
+#pragma unroll
+    for (int j = 0; j < kMaxCols; ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int cc = c0 + j * cstep;
+            const int ch = (cc < CH ? cc : 0) * 8 + e, g = ch / cpg;
+            sc[j][e] = mr[g * 2 + 1] * p.gamma[ch];
+            sh[j][e] = p.beta[ch] - mr[g * 2] * sc[j][e];
+        }
+    if (!active) return;
+    const int r_beg = chunk * p.rows_per_chunk;
+    const int r_end = (r_beg + p.rows_per_chunk < p.HW) ? r_beg + p.rows_per_chunk : p.HW;
+#pragma unroll 4
+    for (int r = r_beg + rl; r < r_end; r += nrl) {
+        const size_t off = ((size_t)b * p.HW + r) * p.C;
+#pragma unroll
+        for (int j = 0; j < kMaxCols; ++j) {
+            const int cc = c0 + j * cstep;
+            if (cc < CH && (j == 0 || cstep == 256)) {
+                const half8 v = ld8(p.x + off + cc * 8);
+                half8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float yv = (float)v[e] * sc[j][e] + sh[j][e];
+                    if (p.fuse_silu) yv = silu_f(yv);
+                    o[e] = (half_t)yv;
+                }
+                st8(p.y + off + cc * 8, o);
+            }
+        }
+    }
+}
+
+// ---- fused finalize + apply (backward): dx = k1*dyp + k2*x + k3 with per-channel coefficients in registers
+__global__ __launch_bounds__(256) void gn_bwd_apply2_kernel(GnArgs p) {
+    __shared__ float gs[64 * 2];
+    const int t = threadIdx.x, b = blockIdx.y, chunk = blockIdx.x;
+    const int CH = p.C / 8, cpg = p.C / p.G;
+    gn_fold_groups(p, b, t, gs, 1.0f / ((float)p.HW * (float)cpg));
+    __syncthreads();
+    int rl, nrl, c0, cstep; bool active;
+    gn_thread_map(t, CH, rl, nrl, c0, cstep, active);
+    float sc[kMaxCols][8], sh[kMaxCols][8], k1[kMaxCols][8], k2[kMaxCols][8], k3[kMaxCols][8];
+#pragma unroll
+    for (int j = 0; j < kMaxCols; ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int cc = c0 + j * cstep;
+            const int ch = (cc < CH ? cc : 0) * 8 + e, g = ch / cpg;
+            const float mean = p.stats[((size_t)b * p.G + g) * 2], rstd = p.stats[((size_t)b * p.G + g) * 2 + 1];
+            const float s_ = rstd * p.gamma[ch];
+            sc[j][e] = s_;
+            sh[j][e] = p.beta[ch] - mean * s_;
+            k1[j][e] = s_;
+            k2[j][e] = -rstd * rstd * gs[g * 2 + 1];
+            k3[j][e] = -k2[j][e] * mean - rstd * gs[g * 2];
+        }
+    if (!active) return;
+    const int r_beg = chunk * p.rows_per_chunk;
+    const int r_end = (r_beg + p.rows_per_chunk < p.HW) ? r_beg + p.rows_per_chunk : p.HW;
+#pragma unroll 2
+    for (int r = r_beg + rl; r < r_end; r += nrl) {
+        const size_t off = ((size_t)b * p.HW + r) * p.C;
+#pragma unroll
+        for (int j = 0; j < kMaxCols; ++j) {
+            const int cc = c0 + j * cstep;
+            if (cc < CH && (j == 0 || cstep == 256)) {
+                const half8 xv = ld8(p.x + off + cc * 8), gv = ld8(p.dy + off + cc * 8);
+                half8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float xf = (float)xv[e];
+                    float d = (float)gv[e];
+                    if (p.fuse_silu) d *= dsilu_f(xf * sc[j][e] + sh[j][e]);
+                    o[e] = (half_t)(k1[j][e] * d + k2[j][e] * xf + k3[j][e]);
+                }
+                st8(p.y + off + cc * 8, o);
+            }
+        }
+    }
+}
+
 // ---- backward, trainable affine: dgamma[c] = sum_{b,chunk} a2, dbeta[c] = sum a1  (fixed order: 8 interleaved
 // partial sums per channel folded through LDS; one block = 32 channels)
 __global__ __launch_bounds__(256) void gn_bwd_params_kernel(GnArgs p) {
@@ -438,8 +556,7 @@ extern "C" int clora_groupnorm_fwd_f16(const clora_half* x, clora_half* y, const
     if (rc != CLORA_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(gn_fwd_partial_kernel, dim3(a.nchunk, B), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(gn_fwd_finalize_kernel, dim3(B), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(gn_fwd_apply_kernel, dim3(ew_blocks((size_t)B * HW * (C / 8))), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(gn_fwd_apply2_kernel, dim3(a.nchunk, B), dim3(256), 0, s, a);
     return clora_check_launch();
 }
 
@@ -456,9 +573,8 @@ extern "C" int clora_groupnorm_bwd_f16(const clora_half* x, const clora_half* dy
     if (rc != CLORA_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(gn_bwd_partial_kernel, dim3(a.nchunk, B), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(B), dim3(256), 0, s, a);
     if (dgamma) hipLaunchKernelGGL(gn_bwd_params_kernel, dim3(clora_cdiv(C, 32)), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(ew_blocks((size_t)B * HW * (C / 8))), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(gn_bwd_apply2_kernel, dim3(a.nchunk, B), dim3(256), 0, s, a);
     return clora_check_launch();
 }
 

@@ -261,6 +261,24 @@ def _grad_buffer(p: torch.Tensor) -> torch.Tensor:
     return p.grad
 
 
+def _stack_rows(ts):
+    """Row-concatenate [n_i, r] fp32 matrices.  ControlLoRATrainer lays the adapter weights of a processor out
+    back to back in its flat parameter buffer, so the concatenation is usually a zero-copy strided view."""
+    if len(ts) == 1:
+        return ts[0]
+    t0 = ts[0]
+    ptr, ok = t0.data_ptr(), True
+    for t in ts:
+        if not (t.is_contiguous() and t.dim() == 2 and t.shape[1] == t0.shape[1] and t.dtype == t0.dtype and t.data_ptr() == ptr
+                and t.untyped_storage().data_ptr() == t0.untyped_storage().data_ptr()):
+            ok = False
+            break
+        ptr += t.numel() * t.element_size()
+    if ok:
+        return t0.as_strided((sum(t.shape[0] for t in ts), t0.shape[1]), (t0.shape[1], 1))
+    return torch.cat(ts, 0)
+
+
 class _LoraProjFn(torch.autograd.Function):
     """y = x W^T (+b) (+residual) + scale_s * up_s(down_s(xa_s)) on column segment s.
 
@@ -295,7 +313,7 @@ class _LoraProjFn(torch.autograd.Function):
                 u = torch.cat([u, u.new_zeros(seg_w, r - rs)], 1)
             pieces.append(u)
             info.append((xi, sc, rs))
-        U = pieces[0] if S == 1 else torch.cat(pieces, 0)
+        U = _stack_rows(pieces)
         y = K.gemm(x, pack.w, M, pack.N, pack.K, bias=pack.bias, residual=residual, lora_t=T, lora_u=U,
                    lora_seg=seg_w, lora_scale=1.0)
         ctx.pack, ctx.info, ctx.n_xa, ctx.r, ctx.has_res = pack, info, n_xa, r, residual is not None
@@ -342,7 +360,7 @@ class _LoraProjFn(torch.autograd.Function):
                 segs = [s for s, _ in own]
                 contiguous = segs == list(range(segs[0], segs[0] + len(segs))) and all(D.shape[0] == r for _, D in own)
                 if contiguous:                                   # rank-r part of dx rides in the GEMM epilogue
-                    Dcat = own[0][1].detach() if len(own) == 1 else torch.cat([D.detach() for _, D in own], 0)
+                    Dcat = _stack_rows([D.detach() for _, D in own])
                     dx = K.gemm(dy, pack.wt, M, pack.K, pack.N, lora_t=dT[:, segs[0] * r:], lora_u=Dcat,
                                 lora_seg=pack.K, lora_u_tr=True, lora_r=Dcat.shape[0])
                 else:

@@ -23,7 +23,7 @@ class FlatParams:
     optimizer is one kernel and data parallelism is one all-reduce (24.19 MB for v1)."""
 
     def __init__(self, module: nn.Module):
-        params = [p for p in module.parameters() if p.requires_grad]
+        params = self._ordered(module)
         assert params and all(p.dtype == f32 for p in params)
         dev = params[0].device
         n = sum(p.numel() for p in params)
@@ -41,6 +41,28 @@ class FlatParams:
                 p.data = self.data[off:off + k].view_as(p)
                 p.grad = self.grad[off:off + k].view_as(p)
                 off += k
+
+    @staticmethod
+    def _ordered(module):
+        """Trainable parameters, with the adapter matrices that the fused projection concatenates (q|k|v up
+        weights, k|v down weights of one processor) placed back to back so the concatenation is a view."""
+        seen, out = set(), []
+
+        def add(p):
+            if p is not None and p.requires_grad and id(p) not in seen:
+                seen.add(id(p))
+                out.append(p)
+
+        for m in module.modules():
+            if hasattr(m, "to_q_lora"):
+                for part in ("up", "down"):
+                    for name in ("to_q_lora", "to_k_lora", "to_v_lora"):
+                        layer = getattr(m, name, None)
+                        if layer is not None:
+                            add(getattr(layer, part).weight)
+        for p in module.parameters():
+            add(p)
+        return out
 
     def zero_grad(self):
         self.grad.zero_()
@@ -137,4 +159,9 @@ class ControlLoRATrainer:
         return float(self.loss_sum) / numel
 
     def unscaled_grads(self) -> torch.Tensor:
+        """flat gradient in the internal buffer order (see FlatParams._ordered)"""
         return self.flat.grad / self.state[3]
+
+    def unscaled_grads_module_order(self) -> torch.Tensor:
+        """flat gradient in ``control_lora.parameters()`` order (what the reference / oracle would concatenate)"""
+        return torch.cat([p.grad.reshape(-1) for p in self.control_lora.parameters() if p.requires_grad]) / self.state[3]

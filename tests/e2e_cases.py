@@ -68,7 +68,7 @@ def run_product_step(case, dev):
             out[f"control_{i}"] = c.detach().float()
     out["pred"] = pred.detach().float()
     out["loss"] = torch.tensor([trainer.loss(pred.numel())])
-    out["grads"] = trainer.unscaled_grads().detach().float()
+    out["grads"] = torch.cat([p.grad.reshape(-1) for p in params.parameters()]).detach().float() / float(trainer.state[3])
     return out, trainer
 
 
