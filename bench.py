@@ -103,8 +103,8 @@ def cpu_baseline(steps=2):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=4, help="per-GPU batch (BASELINE: 4)")
     ap.add_argument("--res", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")

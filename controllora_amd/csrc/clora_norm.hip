@@ -25,7 +25,6 @@ struct GnArgs {
     float* stats;   // [B, G, 2]  (mean, rstd)
     float* partial; // [B, nchunk, G, 2]
     float* chpart;  // bwd, trainable affine: [B, nchunk, C, 2] per-channel (sum dyp, sum dyp*xhat)
-    float* table;   // fwd: [2][B][C] (scale, shift); bwd: [5][B][C] (scale, shift, k1, k2, k3)
     float* dgamma;
     float* dbeta;
     int B, HW, C, G, nchunk, rows_per_chunk;
@@ -111,72 +110,6 @@ __global__ __launch_bounds__(256) void gn_fwd_partial_kernel(GnArgs p) {
                     p.partial + ((size_t)b * p.nchunk + chunk) * p.G * 2, nullptr);
 }
 
-// ---- forward, pass 2: mean / rstd per (b, g) and the per-(b, channel) scale/shift table
-__global__ __launch_bounds__(256) void gn_fwd_finalize_kernel(GnArgs p) {
-    __shared__ float mr[64 * 2];
-    const int t = threadIdx.x, b = blockIdx.x;
-    const int cpg = p.C / p.G;
-    // 4 threads per group fold the chunk partials (interleaved, fixed order), then one of them finishes
-    {
-        const int g = t >> 2, part = t & 3;
-        float s = 0.f, q = 0.f;
-        if (g < p.G)
-            for (int c = part; c < p.nchunk; c += 4) {
-                const float* pp = p.partial + (((size_t)b * p.nchunk + c) * p.G + g) * 2;
-                s += pp[0]; q += pp[1];
-            }
-        s += __shfl_xor(s, 1); q += __shfl_xor(q, 1);
-        s += __shfl_xor(s, 2); q += __shfl_xor(q, 2);
-        if (g < p.G && part == 0) {
-            const float n = (float)p.HW * (float)cpg;
-            const float mean = s / n;
-            float var = q / n - mean * mean;
-            var = var < 0.f ? 0.f : var;
-            const float rstd = rsqrtf(var + p.eps);
-            mr[g * 2] = mean; mr[g * 2 + 1] = rstd;
-            p.stats[((size_t)b * p.G + g) * 2] = mean;
-            p.stats[((size_t)b * p.G + g) * 2 + 1] = rstd;
-        }
-    }
-    __syncthreads();
-    float* scale = p.table + (size_t)b * p.C;
-    float* shift = p.table + (size_t)(p.B + b) * p.C;
-    for (int c = t; c < p.C; c += 256) {
-        const int g = c / cpg;
-        const float sc = mr[g * 2 + 1] * p.gamma[c];
-        scale[c] = sc;
-        shift[c] = p.beta[c] - mr[g * 2] * sc;
-    }
-}
-
-__device__ __forceinline__ void ld8f(const float* p, float (&o)[8]) {
-    const floatx4 a = *reinterpret_cast<const floatx4*>(p), b = *reinterpret_cast<const floatx4*>(p + 4);
-    o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3]; o[4] = b[0]; o[5] = b[1]; o[6] = b[2]; o[7] = b[3];
-}
-
-// ---- forward, pass 3: y = x*scale + shift (+SiLU)
-__global__ __launch_bounds__(256) void gn_fwd_apply_kernel(GnArgs p) {
-    const int CH = p.C / 8;
-    const size_t total = (size_t)p.B * p.HW * CH;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const size_t row = i / CH;
-        const int cc = (int)(i - row * CH);
-        const int b = (int)(row / p.HW);
-        const half8 v = ld8(p.x + row * p.C + cc * 8);
-        float sc[8], sh[8];
-        ld8f(p.table + (size_t)b * p.C + cc * 8, sc);
-        ld8f(p.table + (size_t)(p.B + b) * p.C + cc * 8, sh);
-        half8 o;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float yv = (float)v[e] * sc[e] + sh[e];
-            if (p.fuse_silu) yv = silu_f(yv);
-            o[e] = (half_t)yv;
-        }
-        st8(p.y + row * p.C + cc * 8, o);
-    }
-}
-
 // ---- backward, pass 1: per channel a1 = sum dyp, a2 = sum dyp*xhat over this block's rows
 __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(GnArgs p) {
     __shared__ float red[kRedFloats];
@@ -222,42 +155,6 @@ __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(GnArgs p) {
     gn_block_reduce(red, a1, a2, t, p.C, p.G, rl, nrl, c0, cstep, active, p.gamma,
                     p.partial + ((size_t)b * p.nchunk + chunk) * p.G * 2,
                     p.chpart ? p.chpart + ((size_t)b * p.nchunk + chunk) * p.C * 2 : nullptr);
-}
-
-// ---- backward, pass 2: per (b, channel) coefficients  dx = k1*dyp + k2*x + k3
-__global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(GnArgs p) {
-    __shared__ float gs[64 * 2];
-    const int t = threadIdx.x, b = blockIdx.x;
-    const int cpg = p.C / p.G;
-    {
-        const int g = t >> 2, part = t & 3;
-        float s = 0.f, q = 0.f;
-        if (g < p.G)
-            for (int c = part; c < p.nchunk; c += 4) {
-                const float* pp = p.partial + (((size_t)b * p.nchunk + c) * p.G + g) * 2;
-                s += pp[0]; q += pp[1];
-            }
-        s += __shfl_xor(s, 1); q += __shfl_xor(q, 1);
-        s += __shfl_xor(s, 2); q += __shfl_xor(q, 2);
-        if (g < p.G && part == 0) {
-            const float n = (float)p.HW * (float)cpg;
-            gs[g * 2] = s / n; gs[g * 2 + 1] = q / n;
-        }
-    }
-    __syncthreads();
-    const size_t plane = (size_t)p.B * p.C;
-    for (int c = t; c < p.C; c += 256) {
-        const int g = c / cpg;
-        const float mean = p.stats[((size_t)b * p.G + g) * 2], rstd = p.stats[((size_t)b * p.G + g) * 2 + 1];
-        const float sc = rstd * p.gamma[c];
-        const size_t o = (size_t)b * p.C + c;
-        p.table[o] = sc;
-        p.table[plane + o] = p.beta[c] - mean * sc;
-        p.table[2 * plane + o] = sc;                                  // k1 = rstd*gamma
-        const float k2 = -rstd * rstd * gs[g * 2 + 1];
-        p.table[3 * plane + o] = k2;
-        p.table[4 * plane + o] = -k2 * mean - rstd * gs[g * 2];       // k3
-    }
 }
 
 // ---- fused finalize + apply (forward): every block re-folds the chunk partials of its batch element (a few KB
@@ -399,31 +296,6 @@ __global__ __launch_bounds__(256) void gn_bwd_params_kernel(GnArgs p) {
     }
 }
 
-__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(GnArgs p) {
-    const int CH = p.C / 8;
-    const size_t total = (size_t)p.B * p.HW * CH;
-    const size_t plane = (size_t)p.B * p.C;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const size_t row = i / CH;
-        const int cc = (int)(i - row * CH);
-        const int b = (int)(row / p.HW);
-        const half8 xv = ld8(p.x + row * p.C + cc * 8), gv = ld8(p.dy + row * p.C + cc * 8);
-        const float* tb = p.table + (size_t)b * p.C + cc * 8;
-        float sc[8], sh[8], k1[8], k2[8], k3[8];
-        ld8f(tb + 2 * plane, k1); ld8f(tb + 3 * plane, k2); ld8f(tb + 4 * plane, k3);
-        if (p.fuse_silu) { ld8f(tb, sc); ld8f(tb + plane, sh); }
-        half8 o;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float xf = (float)xv[e];
-            float d = (float)gv[e];
-            if (p.fuse_silu) d *= dsilu_f(xf * sc[e] + sh[e]);
-            o[e] = (half_t)(k1[e] * d + k2[e] * xf + k3[e]);
-        }
-        st8(p.y + row * p.C + cc * 8, o);
-    }
-}
-
 // ------------------------------------------------------------------------------------------ LayerNorm
 struct LnArgs {
     const half_t* x;
@@ -519,12 +391,11 @@ int gn_plan(GnArgs& a, void* ws, size_t ws_bytes, bool bwd, bool params) {
     if (rpc > a.HW) rpc = a.HW;
     a.rows_per_chunk = (int)rpc;
     a.nchunk = clora_cdiv(a.HW, rpc);
-    size_t need = (size_t)a.B * a.nchunk * a.G * 2 + (size_t)(bwd ? 5 : 2) * a.B * a.C;
+    size_t need = (size_t)a.B * a.nchunk * a.G * 2;
     if (params) need += (size_t)a.B * a.nchunk * a.C * 2;
     if (!ws || ws_bytes < need * sizeof(float)) return CLORA_ERR_WORKSPACE;
     a.partial = (float*)ws;
-    a.table = a.partial + (size_t)a.B * a.nchunk * a.G * 2;
-    a.chpart = params ? a.table + (size_t)5 * a.B * a.C : nullptr;
+    a.chpart = params ? a.partial + (size_t)a.B * a.nchunk * a.G * 2 : nullptr;
     return CLORA_OK;
 }
 
@@ -540,7 +411,7 @@ extern "C" size_t clora_groupnorm_workspace_bytes(int B, int HW, int C, int G, i
     a.B = B; a.HW = HW; a.C = C; a.G = G;
     static float dummy;
     if (gn_plan(a, &dummy, (size_t)-1, backward != 0, param_grads != 0) != CLORA_OK) return 0;
-    size_t need = (size_t)B * a.nchunk * G * 2 + (size_t)(backward ? 5 : 2) * B * C;
+    size_t need = (size_t)B * a.nchunk * G * 2;
     if (param_grads) need += (size_t)B * a.nchunk * C * 2;
     return need * sizeof(float);
 }

@@ -12,8 +12,8 @@ Reference map (file:line in /root/reference/models.py):
 Per attention site the reference launches ~25-30 micro-kernels for the adapters and materialises the
 score matrix; here a site is: (control add) -> one fused q|k|v GEMM with the rank-r updates in its epilogue
 -> flash attention -> one out-projection GEMM (+ adapter + bias + residual).  Quirks C1-C9 of SURVEY.md
-Appendix C are kept.  Not yet on the fused path (raises NotImplementedError, SURVEY.md 8f "next"):
-``pre_loras`` / ``post_loras`` chaining and ``post_add=True``.
+Appendix C are kept.  ``post_add=True`` and ``pre_loras`` / ``post_loras`` chains run the
+same kernels unfused in the reference's exact order (`_generic_call`).
 """
 from __future__ import annotations
 
@@ -51,6 +51,7 @@ def _flat2(t):
 
 class LoRACrossAttnProcessor(nn.Module):
     fuses_residual = True
+    version = 0
 
     def __init__(self, hidden_size, cross_attention_dim=None, rank=4, post_add=False, key_states_skipped=False,
                  value_states_skipped=False, output_states_skipped=False):
@@ -90,10 +91,60 @@ class LoRACrossAttnProcessor(nn.Module):
         layer = getattr(self, name)
         return (xa, layer.down.weight, layer.up.weight, scale)
 
-    def _check_fast_path(self):
-        if self.post_add or getattr(self, "pre_loras", None) or getattr(self, "post_loras", None):
-            raise NotImplementedError("post_add / pre_loras / post_loras are not on the fused gfx950 path yet "
-                                      "(SURVEY.md section 8f rank 2)")
+    def _needs_generic_path(self):
+        """post_add adapters read the projection they are added to, and chained (pre/post) adapters read earlier
+        adapter outputs: those cannot ride in one GEMM epilogue.  They run the same kernels, unfused, in exactly
+        the reference's order (`_generic_call`)."""
+        chain = list(getattr(self, "pre_loras", [])) + list(getattr(self, "post_loras", []))
+        return bool(self.post_add or chain)
+
+    def _generic_call(self, attn, hidden_states, encoder_hidden_states, scale, residual):
+        """Reference order, one kernel group per adapter (models.py:118-152, 222-287, 357-431 incl. quirks C2/C3)."""
+        version = getattr(self, "version", 0)
+        B, N, C_ = hidden_states.shape
+        chain = list(getattr(self, "pre_loras", [])) + [self] + list(getattr(self, "post_loras", []))
+        h = _flat2(hidden_states)
+        if version == 2:
+            for p in chain:
+                if isinstance(p, ControlLoRACrossAttnProcessorV2):
+                    h = p.process_control_states(h.reshape(B, N, C_), scale)
+        h3 = h.reshape(B, N, C_)
+        packs = attn.fused_packs()
+        if attn.is_cross:
+            e = _flat2(encoder_hidden_states)
+            Nk = encoder_hidden_states.shape[1]
+            q = ops.frozen_linear(h, packs[0])
+            kv = ops.frozen_linear(e, packs[1])
+            k, v = ops.split_channels(kv, C_)
+        else:
+            e, Nk = h, N
+            q, k, v = ops.split3_channels(ops.frozen_linear(h, packs[0]), C_)
+        for p in chain:
+            src = q if p.post_add else h
+            if version == 1 and isinstance(p, ControlLoRACrossAttnProcessor):
+                if p.post_add and p.concat_hidden:
+                    raise NotImplementedError("post_add together with concat_hidden (no shipped config uses it)")
+                src = p.process_control_states(src.reshape(B, N, C_), scale)     # src + scale*to_control(control)
+            q = ops.lora_apply(q, src, p.to_q_lora.down.weight, p.to_q_lora.up.weight, scale)
+        for p in chain:
+            if not p.key_states_skipped:
+                k = ops.lora_apply(k, k if p.post_add else e, p.to_k_lora.down.weight, p.to_k_lora.up.weight, scale)
+        for p in chain:
+            if not p.value_states_skipped:
+                vs = scale if (p is self or version == 0) else 1.0          # quirk C3
+                v = ops.lora_apply(v, v if p.post_add else e, p.to_v_lora.down.weight, p.to_v_lora.up.weight, vs)
+        a = attn.attend(q, ops.concat_channels(k, v), B, N, Nk)
+        if version == 2:
+            for p in chain:
+                if isinstance(p, ControlLoRACrossAttnProcessorV2):
+                    a = p.process_control_states(a.reshape(B, N, C_), scale, is_out=True)
+        out = attn.to_out[0](a)
+        for p in chain:
+            if (p is self and version) or not p.output_states_skipped:       # quirk C2
+                out = ops.lora_apply(out, out if p.post_add else a, p.to_out_lora.down.weight, p.to_out_lora.up.weight, scale)
+        if residual is not None:
+            out = ops.add(out, _flat2(residual))
+        return out.reshape(B, N, C_)
 
     def _attend(self, attn, h2, q_in, e2, B, N, Nk, scale, out_in_fn, residual, own_out_always):
         packs = attn.fused_packs()
@@ -113,8 +164,9 @@ class LoRACrossAttnProcessor(nn.Module):
         return ops.lora_proj(a, attn.to_out[0].pack(), [out_seg], residual=res2)
 
     def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, scale=1.0, residual=None):
-        self._check_fast_path()
         attn.prepare_attention_mask(attention_mask, hidden_states.shape[1])
+        if self._needs_generic_path():
+            return self._generic_call(attn, hidden_states, encoder_hidden_states, scale, residual)
         B, N, C_ = hidden_states.shape
         h2 = _flat2(hidden_states)
         e2 = _flat2(encoder_hidden_states) if attn.is_cross else None
@@ -153,6 +205,8 @@ class _ControlMixin:
 
 
 class ControlLoRACrossAttnProcessor(_ControlMixin, LoRACrossAttnProcessor):
+    version = 1
+
     def __init__(self, hidden_size, cross_attention_dim=None, rank=4, control_rank=None, post_add=False,
                  concat_hidden=False, control_channels=None, control_self_add=True, key_states_skipped=False,
                  value_states_skipped=False, output_states_skipped=False, **kwargs):
@@ -169,8 +223,9 @@ class ControlLoRACrossAttnProcessor(_ControlMixin, LoRACrossAttnProcessor):
 
     def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, scale=1.0, residual=None):
         assert self.control_states is not None
-        self._check_fast_path()
         attn.prepare_attention_mask(attention_mask, hidden_states.shape[1])
+        if self._needs_generic_path():
+            return self._generic_call(attn, hidden_states, encoder_hidden_states, scale, residual)
         B, N, C_ = hidden_states.shape
         h2 = _flat2(hidden_states)
         e2 = _flat2(encoder_hidden_states) if attn.is_cross else None
@@ -181,6 +236,8 @@ class ControlLoRACrossAttnProcessor(_ControlMixin, LoRACrossAttnProcessor):
 
 
 class ControlLoRACrossAttnProcessorV2(_ControlMixin, LoRACrossAttnProcessor):
+    version = 2
+
     def __init__(self, hidden_size, cross_attention_dim=None, rank=4, control_rank=None, control_channels=None, **kwargs):
         super().__init__(hidden_size, cross_attention_dim, rank, post_add=False, key_states_skipped=True,
                          value_states_skipped=True, output_states_skipped=False)
@@ -196,8 +253,9 @@ class ControlLoRACrossAttnProcessorV2(_ControlMixin, LoRACrossAttnProcessor):
 
     def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, scale=1.0, residual=None):
         assert self.control_states is not None
-        self._check_fast_path()
         attn.prepare_attention_mask(attention_mask, hidden_states.shape[1])
+        if self._needs_generic_path():
+            return self._generic_call(attn, hidden_states, encoder_hidden_states, scale, residual)
         B, N, C_ = hidden_states.shape
         e2 = _flat2(encoder_hidden_states) if attn.is_cross else None
         Nk = encoder_hidden_states.shape[1] if attn.is_cross else N

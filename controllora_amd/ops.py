@@ -199,6 +199,27 @@ def concat_channels(a, b):
     return _ConcatFn.apply(a, b)
 
 
+class _SplitFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y, ca):
+        ctx.ca = ca
+        return K.split_channels(y, ca)
+
+    @staticmethod
+    def backward(ctx, da, db):
+        return K.concat_channels(da.contiguous(), db.contiguous()), None
+
+
+def split_channels(y, ca):
+    return _SplitFn.apply(y, ca)
+
+
+def split3_channels(y, c):
+    a, bc = split_channels(y, c)
+    b, cc = split_channels(bc, c)
+    return a, b, cc
+
+
 # ------------------------------------------------------------------------------------------------ attention
 class _AttnSelfFn(torch.autograd.Function):
     """qkv: [B*N, 3*H*D] (q | k | v column blocks, as written by the fused projection)."""
@@ -451,6 +472,50 @@ class _ControlAddFn(torch.autograd.Function):
 
 def control_add(h, ctrl, D, U, scale, concat):
     return _ControlAddFn.apply(h, ctrl, D, U, float(scale), bool(concat))
+
+
+class _LoraApplyFn(torch.autograd.Function):
+    """y = base + fp16(scale * fp16(up(down(x))))  -- one LoRALinearLayer applied the way the reference writes it
+    (`t = t + scale * lora(x)`, models.py:125-147, 232-282).  Building block of the generic (unfused) processor
+    path: post_add=True and pre_loras / post_loras chains, where adapter inputs depend on earlier adapter outputs."""
+
+    @staticmethod
+    def forward(ctx, base, x, D, U, scale):
+        M, N = base.shape
+        T = torch.empty((M, D.shape[0]), dtype=f32, device=base.device)
+        K.lora_down(x, D.detach(), T, 0, M, D.shape[1])
+        y = K.lora_up(base, T, 0, U.detach(), M, N, scale)
+        ctx.save_for_backward(x, T)
+        ctx.params, ctx.scale, ctx.same = (D, U), scale, x is base
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        x, T = ctx.saved_tensors
+        D, U = ctx.params
+        scale = ctx.scale
+        M, N = dy.shape
+        R = D.shape[0]
+        dT = torch.empty((M, R), dtype=f32, device=dy.device)
+        K.lora_down(dy, U.detach(), dT, 0, M, N, kmajor=True, R=R, d_scale=scale)
+        if U.requires_grad:
+            K.lora_wgrad(dy, T, 0, _grad_buffer(U), R, 1, M, N, R, scale=scale)
+        if D.requires_grad:
+            K.lora_wgrad(x, dT, 0, _grad_buffer(D), 1, D.shape[1], M, D.shape[1], R)
+        dbase, dx = dy, None
+        if ctx.same:                       # post_add: the adapter reads the tensor it is added to
+            if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+                dbase = K.lora_up(dy, dT, 0, D.detach(), M, D.shape[1], 1.0, u_tr=True)
+            return dbase, None, None, None, None
+        if ctx.needs_input_grad[1]:
+            dx = K.lora_up(None, dT, 0, D.detach(), M, D.shape[1], 1.0, u_tr=True)
+        return dbase, dx, None, None, None
+
+
+def lora_apply(base, x, down_weight, up_weight, scale):
+    """base [M,N] + scale * LoRA(x [M,K]); pass x = base for post_add adapters."""
+    return _LoraApplyFn.apply(base, x, down_weight, up_weight, float(scale))
 
 
 # ------------------------------------------------------------------------------------------------ trainable conv (hint encoder)

@@ -130,6 +130,11 @@ if __name__ == "__main__":
     bench_gemm("ff1.s2", Bn * 256, 10240, 1280)
     bench_gemm("ff2.s2", Bn * 256, 1280, 5120)
     bench_gemm("big", 8192, 8192, 8192)
+    bench_gemm("sq.s2", Bn * 256, 1280, 1280)
+    bench_gemm("sq.s1", Bn * 1024, 640, 640)
+    bench_gemm("qkvT.s2", Bn * 256, 1280, 3840)
+    bench_gemm("sq.s3", Bn * 64, 1280, 1280)
+    bench_gemm("kv.s2", Bn * 77, 2560, 768)
     bench_conv("res.s0", Bn, 64, 320, 320)
     bench_conv("res.s1", Bn, 32, 640, 640)
     bench_conv("res.s2", Bn, 16, 1280, 1280)
