@@ -177,8 +177,22 @@ def main():
                    "TFLOPs": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["flops"] else None}
                for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])[:8]}
         ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+        # HBM-side traffic per launch of the dominant family: PMC counters cannot be read from inside the process, so
+        # this is the committed result of the two `rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE` passes over this same
+        # command (tools/pmc_summary.py; FETCH_SIZE x2 as calibrated on gfx950), averaged over the family's kernels.
+        traffic, traffic_src = None, None
+        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if dom_name.startswith("clora_gemm") and os.path.exists(pmc_path):
+            pmc = json.load(open(pmc_path))
+            ks = [v for k, v in pmc["kernels"].items() if "gemm_dma_kernel" in k]
+            n = sum(v["launches"] for v in ks)
+            traffic = round(sum(v["launches"] * (v["fetch_bytes_per_launch_corrected"] + (v["write_bytes_per_launch_raw"] or 0.0))
+                                for v in ks) / n)
+            traffic_src = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc, L2<->fabric bytes incl. Infinity-Cache hits)"
         roofline = {"bound": "mfma", "kernel": dom_name, "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                    "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                    "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
+                    "algorithmic_bytes_per_launch": round(dom["bytes"] / dom["calls"]),
                     "launches": dom["calls"], "avg_launch_us": round(dom["ms"] * 1e3 / dom["calls"], 1),
                     "kernel_ms_per_step": round(total_ms, 2), "families": fam,
                     "whole_step_frac_of_mfma_peak": round(

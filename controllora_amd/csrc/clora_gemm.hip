@@ -299,8 +299,16 @@ __global__ __launch_bounds__(256, (DmaOcc<BM, BN>::v)) void gemm_dma_kernel(Gemm
     __shared__ __attribute__((aligned(16))) half_t smem[SMEM];
 
     const int t = threadIdx.x;
-    const int tile_m = blockIdx.x / p.tiles_n, tile_n = blockIdx.x % p.tiles_n;
-    const int split = blockIdx.y;
+    // XCD-aware block order (cdna_hip_programming.md T1): workgroup L runs on XCD L % 8, each with a private L2.
+    // Remap so that every XCD walks a CONTIGUOUS range of logical tiles (n fastest): the N-tiles that share one
+    // block of A rows -- and the 9 taps of a conv that re-read the same input pixels -- hit the same L2.
+    // (PMC evidence in profiles/r01_pmc_traffic.json: fabric reads were several x the algorithmic bytes.)
+    const int tiles = gridDim.x, nwg = gridDim.x * gridDim.y;
+    const int lin = blockIdx.y * gridDim.x + blockIdx.x;
+    const int xq = nwg >> 3, xr = nwg & 7, xcd = lin & 7;
+    const int logical = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (lin >> 3);
+    const int split = logical / tiles, tile = logical - split * tiles;
+    const int tile_m = tile / p.tiles_n, tile_n = tile % p.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int kbeg = split * p.k_per_split;
     const int kend = (kbeg + p.k_per_split < p.K) ? kbeg + p.k_per_split : p.K;
