@@ -38,6 +38,21 @@ class Epilogue(C.Structure):
                 ("lora_u", C.c_void_p), ("ldu", C.c_int), ("lora_u_tr", C.c_int), ("lora_r", C.c_int), ("lora_seg", C.c_int), ("lora_scale", C.c_float)]
 
 
+class LoraDownJob(C.Structure):
+    """mirror of clora_lora_down_job_t"""
+    _fields_ = [("X", C.c_void_p), ("ldx", C.c_int), ("D", C.c_void_p), ("ldd", C.c_int), ("T", C.c_void_p), ("ldt", C.c_int),
+                ("toff", C.c_int), ("M", C.c_int), ("K", C.c_int), ("R", C.c_int), ("accumulate", C.c_int), ("x_rows", C.c_int),
+                ("d_kmajor", C.c_int), ("d_scale", C.c_float)]
+
+
+class LoraWgradJob(C.Structure):
+    """mirror of clora_lora_wgrad_job_t"""
+    _fields_ = [("A", C.c_void_p), ("lda", C.c_int), ("T", C.c_void_p), ("ldt", C.c_int), ("toff", C.c_int), ("G", C.c_void_p),
+                ("gs_n", C.c_int), ("gs_j", C.c_int), ("M", C.c_int), ("N", C.c_int), ("R", C.c_int), ("scale", C.c_float),
+                ("a_rows", C.c_int)]
+
+
+LORA_MAX_JOBS = 8
 _P, _I, _Z, _F = C.c_void_p, C.c_int, C.c_size_t, C.c_float
 _PROTOS = {
     "clora_gemm_f16": [_P, _I, _P, _P, _I, _I, _I, _I, C.POINTER(ConvDesc), C.POINTER(Epilogue), _I, _P, _Z, _P],
@@ -52,6 +67,8 @@ _PROTOS = {
     "clora_geglu_fwd_f16": [_P, _P, _I, _I, _P],
     "clora_geglu_bwd_f16": [_P, _P, _P, _I, _I, _P],
     "clora_lora_down_f16": [_P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P],
+    "clora_lora_down_multi_f16": [C.POINTER(LoraDownJob), _I, _P],
+    "clora_lora_wgrad_multi_f16": [C.POINTER(LoraWgradJob), _I, _P, _Z, _P],
     "clora_lora_up_f16": [_P, _I, _P, _I, _I, _P, _I, _I, _P, _I, _I, _I, _I, _F, _P],
     "clora_lora_wgrad_f16": [_P, _I, _P, _I, _I, _P, _I, _I, _I, _I, _I, _F, _I, _P, _Z, _P],
     "clora_add_f16": [_P, _P, _P, _Z, _P],

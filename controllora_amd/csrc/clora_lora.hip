@@ -21,17 +21,26 @@ namespace {
 // processed four k-steps at a time with ALL loads of the group issued before the first use: the kernel is a
 // pure stream and would otherwise pay one full memory latency per k-step.
 // d_kmajor: D[j][k] lives at D[k*ldd + j] (an up matrix [K, r] acting as U^T in the backward pass).
-__global__ __launch_bounds__(256) void lora_down_kernel(const half_t* __restrict__ X, const float* __restrict__ D,
-                                                        float* __restrict__ T, int ldx, int ldd, int ldt, int toff, int M,
-                                                        int K, int R, int accumulate, int x_rows, int d_kmajor,
-                                                        float dscale) {
+struct DownJobs {
+    clora_lora_down_job_t j[CLORA_LORA_MAX_JOBS];
+};
+
+__global__ __launch_bounds__(256) void lora_down_kernel(DownJobs jobs) {
+    const clora_lora_down_job_t& p = jobs.j[blockIdx.y];
+    const half_t* __restrict__ X = (const half_t*)p.X;
+    const float* __restrict__ D = p.D;
+    float* __restrict__ T = p.T;
+    const int ldx = p.ldx, ldd = p.ldd, ldt = p.ldt, toff = p.toff, M = p.M, K = p.K, R = p.R;
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63, g = l >> 4, li = l & 15;
     const int m0 = (blockIdx.x * 4 + w) * 16;
+    if (m0 >= M) return;                                    // jobs of one launch may differ in M (wave-uniform exit)
     const int m = m0 + li;
     const bool mok = m < M;
-    const size_t xoff = (size_t)(mok ? (x_rows > 0 ? m % x_rows : m) : 0) * ldx;
+    const size_t xoff = (size_t)(mok ? (p.x_rows > 0 ? m % p.x_rows : m) : 0) * ldx;
     const bool jok = li < R;
     const int jj = jok ? li : 0;
+    const int d_kmajor = p.d_kmajor;
+    const float dscale = p.d_scale;
     floatx4 acc = zero4f();
     constexpr int G = 4;                                   // k-steps in flight
     for (int k0 = 0; k0 < K; k0 += 32 * G) {
@@ -78,7 +87,7 @@ __global__ __launch_bounds__(256) void lora_down_kernel(const half_t* __restrict
             const int mm = m0 + 4 * g + r;
             if (mm < M) {
                 float* out = T + (size_t)mm * ldt + toff + li;
-                *out = accumulate ? *out + acc[r] : acc[r];
+                *out = p.accumulate ? *out + acc[r] : acc[r];
             }
         }
     }
@@ -148,11 +157,22 @@ __global__ __launch_bounds__(256) void lora_up_kernel(UpArgs p) {
 //            columns), 16 rows in flight, wave-uniform T rows by batched scalar loads; the 4 waves fold through
 //            LDS and the block writes its [N x RT] slab to the workspace;
 //   stage 2: 64 outputs x 4 slab-lanes per block fold the slabs in a fixed order and add into G.
+struct WgradJobs {
+    clora_lora_wgrad_job_t j[CLORA_LORA_MAX_JOBS];
+    float* part[CLORA_LORA_MAX_JOBS];       // slab area of each job
+    int rpb[CLORA_LORA_MAX_JOBS], nblk[CLORA_LORA_MAX_JOBS];
+};
+
 template <int RT>
-__global__ __launch_bounds__(256) void lora_wgrad_kernel(const half_t* __restrict__ A, const float* __restrict__ T,
-                                                         float* __restrict__ part, int lda, int ldt, int toff, int M,
-                                                         int N, int R, int a_rows, int rows_per_block) {
+__global__ __launch_bounds__(256) void lora_wgrad_kernel(WgradJobs jobs) {
     __shared__ float red[3 * 64 * 8 * RT / ((RT > 8) ? 2 : 1)];
+    const int job = blockIdx.z;
+    const clora_lora_wgrad_job_t& p = jobs.j[job];
+    if ((int)blockIdx.y >= jobs.nblk[job] || (int)blockIdx.x * 512 >= p.N) return;     // block-uniform exit
+    const half_t* __restrict__ A = (const half_t*)p.A;
+    const float* __restrict__ T = p.T;
+    const int lda = p.lda, ldt = p.ldt, toff = p.toff, M = p.M, N = p.N, R = p.R, a_rows = p.a_rows;
+    const int rows_per_block = jobs.rpb[job];
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l = threadIdx.x & 63;
     const int n = (blockIdx.x * 64 + l) * 8;
     const int rpw = rows_per_block / 4;
@@ -194,7 +214,7 @@ __global__ __launch_bounds__(256) void lora_wgrad_kernel(const half_t* __restric
     }
     // fold the 4 waves (fixed order) -- in two halves of the 8 columns when RT = 16 to stay inside 48 KB of LDS
     constexpr int HALF = (RT > 8) ? 2 : 1, EC = 8 / HALF;
-    float* out = part + ((size_t)blockIdx.y * N + n) * RT;
+    float* out = jobs.part[job] + ((size_t)blockIdx.y * N + n) * RT;
 #pragma unroll
     for (int hh = 0; hh < HALF; ++hh) {
         if (hh) __syncthreads();
@@ -219,13 +239,15 @@ __global__ __launch_bounds__(256) void lora_wgrad_kernel(const half_t* __restric
     }
 }
 
-__global__ __launch_bounds__(256) void lora_wgrad_finish_kernel(const float* __restrict__ part, float* __restrict__ G,
-                                                                int nblk, int N, int RT, int R, int gs_n, int gs_j,
-                                                                float scale) {
+__global__ __launch_bounds__(256) void lora_wgrad_finish_kernel(WgradJobs jobs, int RT) {
     __shared__ float red[256];
+    const int job = blockIdx.y;
+    const clora_lora_wgrad_job_t& p = jobs.j[job];
     const int t = threadIdx.x, o = t & 63, q = t >> 6;
     const int i = blockIdx.x * 64 + o;
-    const int total = N * RT;
+    const int total = p.N * RT, nblk = jobs.nblk[job];
+    if ((int)blockIdx.x * 64 >= total) return;               // block-uniform exit
+    const float* part = jobs.part[job];
     float s = 0.f;
     if (i < total) {
         const size_t stride = (size_t)total;
@@ -243,29 +265,44 @@ __global__ __launch_bounds__(256) void lora_wgrad_finish_kernel(const float* __r
     __syncthreads();
     if (q == 0 && i < total) {
         const int n = i / RT, j = i - n * RT;
-        if (j < R) {
+        if (j < p.R) {
             s = red[o] + red[64 + o] + red[128 + o] + red[192 + o];
-            float* dst = G + (size_t)n * gs_n + (size_t)j * gs_j;
-            *dst += scale * s;
+            float* dst = p.G + (size_t)n * p.gs_n + (size_t)j * p.gs_j;
+            *dst += p.scale * s;
         }
     }
 }
 
 }  // namespace
 
+extern "C" int clora_lora_down_multi_f16(const clora_lora_down_job_t* jobs, int njobs, void* stream) {
+    if (!jobs || njobs <= 0 || njobs > CLORA_LORA_MAX_JOBS) return CLORA_ERR_ARG;
+    DownJobs dj;
+    int maxM = 0;
+    for (int i = 0; i < njobs; ++i) {
+        const clora_lora_down_job_t& j = jobs[i];
+        if (!j.X || !j.D || !j.T || j.M <= 0 || j.K <= 0 || j.R <= 0 || j.R > 16 || (j.K & 7) || (j.ldx & 7)) return CLORA_ERR_ARG;
+        if (!j.d_kmajor && ((j.ldd & 3) || ((uintptr_t)j.D & 15))) return CLORA_ERR_ARG;
+        dj.j[i] = j;
+        if (j.M > maxM) maxM = j.M;
+    }
+    hipLaunchKernelGGL(lora_down_kernel, dim3(clora_cdiv(maxM, 64), njobs), dim3(256), 0, (hipStream_t)stream, dj);
+    return clora_check_launch();
+}
+
 extern "C" int clora_lora_down_f16(const clora_half* X, int ldx, const float* D, int ldd, float* T, int ldt, int toff,
                                    int M, int K, int R, int accumulate, int x_rows, int d_kmajor, float d_scale,
                                    void* stream) {
-    if (!X || !D || !T || M <= 0 || K <= 0 || R <= 0 || (K & 7) || (ldx & 7)) return CLORA_ERR_ARG;
-    if (!d_kmajor && ((ldd & 3) || ((uintptr_t)D & 15))) return CLORA_ERR_ARG;
-    hipStream_t s = (hipStream_t)stream;
+    if (R <= 0) return CLORA_ERR_ARG;
     for (int r0 = 0; r0 < R; r0 += 16) {  // ranks > 16 (danbooru-sketch control_rank 256) take several passes over X
-        const int Rp = (R - r0 < 16) ? R - r0 : 16;
-        hipLaunchKernelGGL(lora_down_kernel, dim3(clora_cdiv(M, 64)), dim3(256), 0, s, (const half_t*)X,
-                           d_kmajor ? D + r0 : D + (size_t)r0 * ldd, T, ldx, ldd, ldt, toff + r0, M, K, Rp, accumulate,
-                           x_rows, d_kmajor, d_scale);
+        clora_lora_down_job_t j;
+        j.X = X; j.ldx = ldx; j.D = d_kmajor ? D + r0 : (D ? D + (size_t)r0 * ldd : D); j.ldd = ldd; j.T = T; j.ldt = ldt;
+        j.toff = toff + r0; j.M = M; j.K = K; j.R = (R - r0 < 16) ? R - r0 : 16; j.accumulate = accumulate;
+        j.x_rows = x_rows; j.d_kmajor = d_kmajor; j.d_scale = d_scale;
+        const int rc = clora_lora_down_multi_f16(&j, 1, stream);
+        if (rc != CLORA_OK) return rc;
     }
-    return clora_check_launch();
+    return CLORA_OK;
 }
 
 extern "C" int clora_lora_up_f16(const clora_half* base, int ldb, const float* T, int ldt, int toff, const float* U,
@@ -288,31 +325,54 @@ int wgrad_rows_per_block(int M, int N) {
     while ((long)clora_cdiv(N, 512) * clora_cdiv(M, rpb) > 256) rpb *= 2;
     return rpb;
 }
+int wgrad_rt(int R) { return R <= 4 ? 4 : (R <= 8 ? 8 : 16); }
 }  // namespace
 
 extern "C" size_t clora_lora_wgrad_workspace_bytes(int M, int N, int R) {
-    const int rt = R <= 4 ? 4 : (R <= 8 ? 8 : 16);
-    return (size_t)clora_cdiv(M, wgrad_rows_per_block(M, N)) * N * rt * sizeof(float);
+    return (size_t)clora_cdiv(M, wgrad_rows_per_block(M, N)) * N * wgrad_rt(R > 16 ? 16 : R) * sizeof(float);
+}
+
+/* all jobs of one launch must share the rank class (R <= 4, <= 8 or <= 16) */
+extern "C" int clora_lora_wgrad_multi_f16(const clora_lora_wgrad_job_t* jobs, int njobs, void* workspace,
+                                          size_t workspace_bytes, void* stream) {
+    if (!jobs || njobs <= 0 || njobs > CLORA_LORA_MAX_JOBS) return CLORA_ERR_ARG;
+    WgradJobs wj;
+    const int rt = wgrad_rt(jobs[0].R);
+    size_t off = 0;
+    int gx = 0, gy = 0, maxNRT = 0;
+    for (int i = 0; i < njobs; ++i) {
+        const clora_lora_wgrad_job_t& j = jobs[i];
+        if (!j.A || !j.T || !j.G || j.M <= 0 || j.N <= 0 || j.R <= 0 || j.R > 16 || (j.N & 7) || (j.lda & 7) || wgrad_rt(j.R) != rt)
+            return CLORA_ERR_ARG;
+        wj.j[i] = j;
+        wj.rpb[i] = wgrad_rows_per_block(j.M, j.N);
+        wj.nblk[i] = clora_cdiv(j.M, wj.rpb[i]);
+        wj.part[i] = (float*)workspace + off;
+        off += (size_t)wj.nblk[i] * j.N * rt;
+        if (clora_cdiv(j.N, 512) > gx) gx = clora_cdiv(j.N, 512);
+        if (wj.nblk[i] > gy) gy = wj.nblk[i];
+        if (j.N * rt > maxNRT) maxNRT = j.N * rt;
+    }
+    if (!workspace || workspace_bytes < off * sizeof(float)) return CLORA_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid(gx, gy, njobs);
+    if (rt == 4) hipLaunchKernelGGL((lora_wgrad_kernel<4>), grid, dim3(256), 0, s, wj);
+    else if (rt == 8) hipLaunchKernelGGL((lora_wgrad_kernel<8>), grid, dim3(256), 0, s, wj);
+    else hipLaunchKernelGGL((lora_wgrad_kernel<16>), grid, dim3(256), 0, s, wj);
+    hipLaunchKernelGGL(lora_wgrad_finish_kernel, dim3(clora_cdiv(maxNRT, 64), njobs), dim3(256), 0, s, wj, rt);
+    return clora_check_launch();
 }
 
 extern "C" int clora_lora_wgrad_f16(const clora_half* A, int lda, const float* T, int ldt, int toff, float* G, int gs_n,
                                     int gs_j, int M, int N, int R, float scale, int a_rows, void* workspace,
                                     size_t workspace_bytes, void* stream) {
-    if (!A || !T || !G || M <= 0 || N <= 0 || R <= 0 || (N & 7) || (lda & 7)) return CLORA_ERR_ARG;
-    hipStream_t s = (hipStream_t)stream;
-    const int rpb = wgrad_rows_per_block(M, N);
-    const int nblk = clora_cdiv(M, rpb);
+    if (R <= 0) return CLORA_ERR_ARG;
     for (int r0 = 0; r0 < R; r0 += 16) {
-        const int Rp = (R - r0 < 16) ? R - r0 : 16, to = toff + r0;
-        const int rt = Rp <= 4 ? 4 : (Rp <= 8 ? 8 : 16);
-        if (!workspace || workspace_bytes < (size_t)nblk * N * rt * sizeof(float)) return CLORA_ERR_WORKSPACE;
-        float* part = (float*)workspace;
-        const dim3 grid(clora_cdiv(N, 512), nblk);
-        if (rt == 4) hipLaunchKernelGGL((lora_wgrad_kernel<4>), grid, dim3(256), 0, s, (const half_t*)A, T, part, lda, ldt, to, M, N, Rp, a_rows, rpb);
-        else if (rt == 8) hipLaunchKernelGGL((lora_wgrad_kernel<8>), grid, dim3(256), 0, s, (const half_t*)A, T, part, lda, ldt, to, M, N, Rp, a_rows, rpb);
-        else hipLaunchKernelGGL((lora_wgrad_kernel<16>), grid, dim3(256), 0, s, (const half_t*)A, T, part, lda, ldt, to, M, N, Rp, a_rows, rpb);
-        hipLaunchKernelGGL(lora_wgrad_finish_kernel, dim3(clora_cdiv(N * rt, 64)), dim3(256), 0, s, part,
-                           G + (size_t)r0 * gs_j, nblk, N, rt, Rp, gs_n, gs_j, scale);
+        clora_lora_wgrad_job_t j;
+        j.A = A; j.lda = lda; j.T = T; j.ldt = ldt; j.toff = toff + r0; j.G = G + (size_t)r0 * gs_j; j.gs_n = gs_n; j.gs_j = gs_j;
+        j.M = M; j.N = N; j.R = (R - r0 < 16) ? R - r0 : 16; j.scale = scale; j.a_rows = a_rows;
+        const int rc = clora_lora_wgrad_multi_f16(&j, 1, workspace, workspace_bytes, stream);
+        if (rc != CLORA_OK) return rc;
     }
-    return clora_check_launch();
+    return CLORA_OK;
 }

@@ -232,6 +232,42 @@ def lora_down(X, D, T, toff, M, K, accumulate=False, x_rows=0, ldx=None, kmajor=
     return T
 
 
+def down_job(X, D, T, toff, M, K, accumulate=False, x_rows=0, ldx=None, kmajor=False, R=None, d_scale=1.0):
+    """one problem of lora_down_multi (same arguments as lora_down; rank <= 16)"""
+    assert D.dtype == f32 and D.stride(1) == 1 and T.dtype == f32 and T.stride(1) == 1
+    rank = R if R is not None else (D.shape[1] if kmajor else D.shape[0])
+    return capi.LoraDownJob(ptr(X, f16), ldx if ldx is not None else X.stride(0), ptr(D), D.stride(0), ptr(T), T.stride(0), toff,
+                            M, K, rank, int(accumulate), x_rows, int(kmajor), float(d_scale))
+
+
+def lora_down_multi(jobs):
+    """several adapter down-projections (possibly over different inputs) in one launch"""
+    for i in range(0, len(jobs), capi.LORA_MAX_JOBS):
+        chunk = jobs[i:i + capi.LORA_MAX_JOBS]
+        arr = (capi.LoraDownJob * len(chunk))(*chunk)
+        _call("clora_lora_down_multi_f16", arr, len(chunk), nbytes=sum(2.0 * j.M * j.K for j in chunk))
+
+
+def wgrad_job(A, T, toff, G, gs_n, gs_j, M, N, R, scale=1.0, a_rows=0, lda=None):
+    assert G.dtype == f32 and T.dtype == f32 and R <= 16
+    return capi.LoraWgradJob(ptr(A, f16), lda if lda is not None else A.stride(0), ptr(T), T.stride(0), toff, ptr(G), gs_n, gs_j,
+                             M, N, R, float(scale), a_rows)
+
+
+def lora_wgrad_multi(jobs, device):
+    """several adapter weight-gradient reductions in one launch (+ one fold launch); jobs are grouped by rank class"""
+    groups = {}
+    for j in jobs:
+        groups.setdefault(4 if j.R <= 4 else (8 if j.R <= 8 else 16), []).append(j)
+    wsb = capi.lib().cdll.clora_lora_wgrad_workspace_bytes
+    for _, js in groups.items():
+        for i in range(0, len(js), capi.LORA_MAX_JOBS):
+            chunk = js[i:i + capi.LORA_MAX_JOBS]
+            ws = workspace(sum(wsb(j.M, j.N, j.R) for j in chunk), device)
+            arr = (capi.LoraWgradJob * len(chunk))(*chunk)
+            _call("clora_lora_wgrad_multi_f16", arr, len(chunk), ptr(ws), ws.numel(), nbytes=sum(2.0 * j.M * j.N for j in chunk))
+
+
 def lora_up(base, T, toff, U, M, N, scale, out=None, u_tr=False):
     """Y = base + fp16(scale * fp16(T[:, toff:toff+R] . U^T)); U is [N, R], or with u_tr a down matrix [R, N]."""
     assert U.dtype == f32 and U.stride(1) == 1 and T.dtype == f32

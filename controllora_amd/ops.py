@@ -318,7 +318,7 @@ class _LoraProjFn(torch.autograd.Function):
         r = max(ranks + [1])
         full = all(m is not None for m in meta) and all(rk == r for rk in ranks)
         T = (torch.empty if full else torch.zeros)((M, S * r), dtype=f32, device=x.device)
-        pieces, pi, info = [], 0, []
+        pieces, pi, info, djobs = [], 0, [], []
         for s, m in enumerate(meta):
             if m is None:
                 pieces.append(torch.zeros((seg_w, r), dtype=f32, device=x.device))
@@ -328,12 +328,17 @@ class _LoraProjFn(torch.autograd.Function):
             D, Uw = params[2 * pi], params[2 * pi + 1]
             pi += 1
             rs = D.shape[0]
-            K.lora_down(xas[xi], D.detach(), T, s * r, M, D.shape[1])
+            if rs <= 16:
+                djobs.append(K.down_job(xas[xi], D.detach(), T, s * r, M, D.shape[1]))
+            else:
+                K.lora_down(xas[xi], D.detach(), T, s * r, M, D.shape[1])
             u = Uw.detach() if sc == 1.0 else Uw.detach() * sc
             if rs != r:
                 u = torch.cat([u, u.new_zeros(seg_w, r - rs)], 1)
             pieces.append(u)
             info.append((xi, sc, rs))
+        if djobs:
+            K.lora_down_multi(djobs)                  # every adapter down-projection of this GEMM in one launch
         U = _stack_rows(pieces)
         y = K.gemm(x, pack.w, M, pack.N, pack.K, bias=pack.bias, residual=residual, lora_t=T, lora_u=U,
                    lora_seg=seg_w, lora_scale=1.0)
@@ -354,6 +359,7 @@ class _LoraProjFn(torch.autograd.Function):
         dT = (torch.empty if all(i is not None and i[2] == r for i in info) else torch.zeros)((M, S * r), dtype=f32, device=dy.device)
         d_xas: List[Optional[torch.Tensor]] = [None] * n_xa
         own = []                                  # (segment, D) of adapters fed by x itself -> dgrad GEMM epilogue
+        djobs, wjobs, later = [], [], []
         pi = 0
         for s, m in enumerate(info):
             if m is None:
@@ -362,17 +368,39 @@ class _LoraProjFn(torch.autograd.Function):
             D, Uw = params[2 * pi], params[2 * pi + 1]
             pi += 1
             dys = dy[:, s * seg_w:(s + 1) * seg_w]
+            big = rs > 16
             # dT_s = sc * dy_s . U_s : a "down" projection of dy with U (k-major) as the matrix
-            K.lora_down(dys, Uw.detach(), dT, s * r, M, seg_w, ldx=pack.N, kmajor=True, R=rs, d_scale=sc)
+            if big:
+                K.lora_down(dys, Uw.detach(), dT, s * r, M, seg_w, ldx=pack.N, kmajor=True, R=rs, d_scale=sc)
+            else:
+                djobs.append(K.down_job(dys, Uw.detach(), dT, s * r, M, seg_w, ldx=pack.N, kmajor=True, R=rs, d_scale=sc))
             if Uw.requires_grad:
-                K.lora_wgrad(dys, T, s * r, _grad_buffer(Uw), Uw.shape[1], 1, M, seg_w, rs, scale=sc, lda=pack.N)
+                if big:
+                    later.append((dys, T, s * r, _grad_buffer(Uw), Uw.shape[1], 1, seg_w, rs, sc, pack.N))
+                else:
+                    wjobs.append(K.wgrad_job(dys, T, s * r, _grad_buffer(Uw), Uw.shape[1], 1, M, seg_w, rs, scale=sc, lda=pack.N))
             if D.requires_grad:
-                K.lora_wgrad(xas[xi], dT, s * r, _grad_buffer(D), 1, D.shape[1], M, D.shape[1], rs, scale=1.0)
+                if big:
+                    later.append((xas[xi], dT, s * r, _grad_buffer(D), 1, D.shape[1], D.shape[1], rs, 1.0, None))
+                else:
+                    wjobs.append(K.wgrad_job(xas[xi], dT, s * r, _grad_buffer(D), 1, D.shape[1], M, D.shape[1], rs))
             if xi == 0:
                 own.append((s, D))
-            elif ctx.needs_input_grad[4 + xi]:
-                g = K.lora_up(None, dT, s * r, D.detach(), M, D.shape[1], 1.0, u_tr=True)
-                d_xas[xi] = g if d_xas[xi] is None else K.add(d_xas[xi], g)
+            else:
+                later.append(("dx", xi, s, D))
+        if djobs:
+            K.lora_down_multi(djobs)              # dT of every adapter of this GEMM: one launch
+        if wjobs:
+            K.lora_wgrad_multi(wjobs, dy.device)  # dU and dD of every adapter: one reduction + one fold launch
+        for item in later:
+            if item[0] == "dx":
+                _, xi, s, D = item
+                if ctx.needs_input_grad[4 + xi]:
+                    g = K.lora_up(None, dT, s * r, D.detach(), M, D.shape[1], 1.0, u_tr=True)
+                    d_xas[xi] = g if d_xas[xi] is None else K.add(d_xas[xi], g)
+            else:
+                A_, T_, to_, G_, gsn, gsj, N_, rs_, sc_, lda_ = item
+                K.lora_wgrad(A_, T_, to_, G_, gsn, gsj, M, N_, rs_, scale=sc_, lda=lda_)
         dx = None
         if ctx.needs_input_grad[3]:
             if not own:
@@ -448,21 +476,28 @@ class _ControlAddFn(torch.autograd.Function):
         Dd, Ud = D.detach(), U.detach()
         dT = torch.empty((M, R), dtype=f32, device=dy.device)
         K.lora_down(dy, Ud, dT, 0, M, C_, kmajor=True, R=R, d_scale=scale)
+        wj = []       # (A, T, toff, G, gs_n, gs_j, N, scale, a_rows): batched below when the rank allows
         if U.requires_grad:
-            K.lora_wgrad(dy, T, 0, _grad_buffer(U), R, 1, M, C_, R, scale=scale)
+            wj.append((dy, T, 0, _grad_buffer(U), R, 1, C_, scale, 0))
         dh = dy
         dctrl = None
         if concat:
             if D.requires_grad:
                 gD = _grad_buffer(D)
-                K.lora_wgrad(h, dT, 0, gD, 1, D.shape[1], M, C_, R)
-                K.lora_wgrad(ctrl, dT, 0, gD[:, C_:], 1, D.shape[1], M, Cc, R, a_rows=xr)
+                wj.append((h, dT, 0, gD, 1, D.shape[1], C_, 1.0, 0))
+                wj.append((ctrl, dT, 0, gD[:, C_:], 1, D.shape[1], Cc, 1.0, xr))
             dh = K.lora_up(dy, dT, 0, Dd[:, :C_], M, C_, 1.0, u_tr=True)
             Dc = Dd[:, C_:]
         else:
             if D.requires_grad:
-                K.lora_wgrad(ctrl, dT, 0, _grad_buffer(D), 1, D.shape[1], M, Cc, R, a_rows=xr)
+                wj.append((ctrl, dT, 0, _grad_buffer(D), 1, D.shape[1], Cc, 1.0, xr))
             Dc = Dd
+        if R <= 16:
+            K.lora_wgrad_multi([K.wgrad_job(a_, t_, to_, g_, gn, gj, M, n_, R, scale=sc_, a_rows=ar_)
+                                for a_, t_, to_, g_, gn, gj, n_, sc_, ar_ in wj], dy.device)
+        else:
+            for a_, t_, to_, g_, gn, gj, n_, sc_, ar_ in wj:
+                K.lora_wgrad(a_, t_, to_, g_, gn, gj, M, n_, R, scale=sc_, a_rows=ar_)
         if ctx.needs_input_grad[1]:
             dctrl = K.lora_up(None, dT, 0, Dc, M, Cc, 1.0, u_tr=True)
             if xr:
@@ -499,10 +534,16 @@ class _LoraApplyFn(torch.autograd.Function):
         R = D.shape[0]
         dT = torch.empty((M, R), dtype=f32, device=dy.device)
         K.lora_down(dy, U.detach(), dT, 0, M, N, kmajor=True, R=R, d_scale=scale)
+        wj = []
         if U.requires_grad:
-            K.lora_wgrad(dy, T, 0, _grad_buffer(U), R, 1, M, N, R, scale=scale)
+            wj.append((dy, T, _grad_buffer(U), R, 1, N, scale))
         if D.requires_grad:
-            K.lora_wgrad(x, dT, 0, _grad_buffer(D), 1, D.shape[1], M, D.shape[1], R)
+            wj.append((x, dT, _grad_buffer(D), 1, D.shape[1], D.shape[1], 1.0))
+        if R <= 16 and wj:
+            K.lora_wgrad_multi([K.wgrad_job(a_, t_, 0, g_, gn, gj, M, n_, R, scale=sc_) for a_, t_, g_, gn, gj, n_, sc_ in wj], dy.device)
+        else:
+            for a_, t_, g_, gn, gj, n_, sc_ in wj:
+                K.lora_wgrad(a_, t_, 0, g_, gn, gj, M, n_, R, scale=sc_)
         dbase, dx = dy, None
         if ctx.same:                       # post_add: the adapter reads the tensor it is added to
             if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:

@@ -130,6 +130,23 @@ int clora_geglu_bwd_f16(const clora_half* h, const clora_half* dy, clora_half* d
  * d_scale   : D is multiplied by d_scale on the fly (the LoRA `scale`). */
 int clora_lora_down_f16(const clora_half* X, int ldx, const float* D, int ldd, float* T, int ldt, int toff,
                         int M, int K, int R, int accumulate, int x_rows, int d_kmajor, float d_scale, void* stream);
+/* Several independent problems of the same kind in ONE launch (a v1 self-attention site has three adapter
+ * down-projections in the forward pass and six weight-gradient reductions in the backward pass; each is
+ * launch-latency bound on its own).  R <= 16 per job; wgrad jobs of one call share the rank class (<=4, <=8, <=16). */
+#define CLORA_LORA_MAX_JOBS 8
+typedef struct {
+    const clora_half* X; int ldx; const float* D; int ldd; float* T; int ldt; int toff;
+    int M, K, R, accumulate, x_rows, d_kmajor; float d_scale;
+} clora_lora_down_job_t;
+typedef struct {
+    const clora_half* A; int lda; const float* T; int ldt; int toff; float* G; int gs_n, gs_j;
+    int M, N, R; float scale; int a_rows;
+} clora_lora_wgrad_job_t;
+int clora_lora_down_multi_f16(const clora_lora_down_job_t* jobs, int njobs, void* stream);
+/* workspace >= sum over jobs of clora_lora_wgrad_workspace_bytes(M, N, R) */
+int clora_lora_wgrad_multi_f16(const clora_lora_wgrad_job_t* jobs, int njobs, void* workspace, size_t workspace_bytes,
+                               void* stream);
+
 /* Y[m,n] = (base ? base[m,n] : 0) + fp16(scale * fp16(sum_j T[m,toff+j] U[n,j]))  -- the explicit
  * "hidden + to_control(control)" of models.py:214-218,237-238 and the V2 pre/post adds (:369,:415). */
 int clora_lora_up_f16(const clora_half* base, int ldb, const float* T, int ldt, int toff, const float* U, int ldu,
