@@ -112,17 +112,23 @@ def main():
     ap.add_argument("--no-ddim", action="store_true", help="skip the secondary inference measurement")
     ap.add_argument("--no-graph", action="store_true", help="issue the step eagerly instead of replaying hipGraphs")
     ap.add_argument("--ddim-batch", type=int, default=16)
+    ap.add_argument("--backend", default="nccl", help='torch.distributed backend ("nccl" is RCCL on ROCm; "gloo" only for '
+                    "exercising the N>1 control flow on a box with fewer GPUs than ranks)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     pg = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group("nccl", device_id=dev)      # "nccl" IS RCCL on ROCm
+        if args.backend == "nccl":
+            torch.distributed.init_process_group("nccl", device_id=dev)  # "nccl" IS RCCL on ROCm
+        else:
+            torch.distributed.init_process_group(args.backend)
         pg = torch.distributed.group.WORLD
 
     from controllora_amd import kernels as K
@@ -166,6 +172,8 @@ def main():
     skipped = float(trainer.state[6])
 
     roofline = None
+    if not args.no_roofline and rank != 0:
+        eager_step()                           # the profiled step contains the all-reduce: every rank takes part
     if not args.no_roofline and rank == 0:
         K.PROFILER = K.KernelProfiler()
         eager_step()
