@@ -94,12 +94,32 @@ def workspace(nbytes: int, device) -> torch.Tensor:
 
 GEMM_WS_BYTES = 256 << 20   # split-K slab budget handed to the library's launch planner
 
+# Autotuned launch configurations (tools/tune_gemm.py on an MI355X): exact-shape lookups for the GEMMs of the
+# SD-1.5 step; any other shape falls back to the library's latency model (split_k = 0, tile_cfg = 0).
+_TUNING = None
+
+
+def tuning_key(M, N, K, conv) -> str:
+    if conv is None:
+        return f"{M}x{N}x{K}"
+    return f"{M}x{N}x{K}:c{conv.ksize}m{conv.mul}k{conv.kmul}s{conv.shift}e{conv.need_even}h{conv.Hin}"
+
+
+def _tuned(M, N, K, conv):
+    global _TUNING
+    if _TUNING is None:
+        import json
+        import os
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gemm_tuning_gfx950.json")
+        _TUNING = json.load(open(path))["table"] if os.path.exists(path) else {}
+    return _TUNING.get(tuning_key(M, N, K, conv))
+
 
 def gemm(A: torch.Tensor, Bw: torch.Tensor, M: int, N: int, K: int, *, lda: Optional[int] = None,
          conv: Optional[ConvDesc] = None, bias=None, rowadd=None, rows_per_batch=0, residual=None,
          lora_t=None, lora_u=None, lora_seg=0, lora_scale=1.0, lora_u_tr=False, lora_r=None,
          out: Optional[torch.Tensor] = None,
-         split_k: int = 0, tile_cfg: int = 0) -> torch.Tensor:
+         split_k: int = 0, tile_cfg: int = 0, _tuned: bool = True) -> torch.Tensor:
     """C[M,N] = A . Bw^T with the fused epilogue of clora_epilogue_t."""
     assert A.dtype == f16 and Bw.dtype == f16 and Bw.shape == (N, K) and Bw.is_contiguous()
     C_ = out if out is not None else torch.empty((M, N), dtype=f16, device=A.device)
@@ -120,6 +140,10 @@ def gemm(A: torch.Tensor, Bw: torch.Tensor, M: int, N: int, K: int, *, lda: Opti
         e.lora_t, e.ldt, e.lora_u, e.ldu, e.lora_u_tr = ptr(lora_t), lora_t.stride(0), ptr(lora_u), lora_u.stride(0), int(lora_u_tr)
         e.lora_r = lora_r if lora_r is not None else (lora_u.shape[0] if lora_u_tr else lora_u.shape[1])
         e.lora_seg, e.lora_scale = (lora_seg or N), float(lora_scale)
+    if _tuned and split_k == 0 and tile_cfg == 0:
+        hit = globals()["_tuned"](M, N, K, conv)
+        if hit is not None:
+            tile_cfg, split_k = hit
     ws = workspace(GEMM_WS_BYTES if split_k == 0 else max(split_k, 1) * M * N * 4, A.device) if split_k != 1 else None
     _call("clora_gemm_f16_ex", ptr(A), lda if lda is not None else K, ptr(Bw), ptr(C_), ldc, M, N, K,
           C.byref(conv) if conv is not None else None, C.byref(e), split_k, tile_cfg,
