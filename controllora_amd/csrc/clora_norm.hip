@@ -28,6 +28,7 @@ struct GnArgs {
     float* dgamma;
     float* dbeta;
     int B, HW, C, G, nchunk, rows_per_chunk;
+    int nslab, CS;  // channel slabs (whole groups, multiple of 8 channels) = blockIdx.y: fills the chip at low resolution
     float eps;
     int fuse_silu;
 };
@@ -80,8 +81,8 @@ constexpr int kRedFloats = 2 * 4096;   // LDS: max(nrl*C, C) * 2 floats with nrl
 // ---- forward, pass 1
 __global__ __launch_bounds__(256) void gn_fwd_partial_kernel(GnArgs p) {
     __shared__ float red[kRedFloats];
-    const int t = threadIdx.x, b = blockIdx.y, chunk = blockIdx.x;
-    const int CH = p.C / 8;
+    const int t = threadIdx.x, b = blockIdx.z, chunk = blockIdx.x, cb = blockIdx.y * p.CS;
+    const int CH = p.CS / 8, gps = p.G / p.nslab;
     int rl, nrl, c0, cstep; bool active;
     gn_thread_map(t, CH, rl, nrl, c0, cstep, active);
     const int r_beg = chunk * p.rows_per_chunk;
@@ -94,7 +95,7 @@ __global__ __launch_bounds__(256) void gn_fwd_partial_kernel(GnArgs p) {
     if (active) {
 #pragma unroll 4
         for (int r = r_beg + rl; r < r_end; r += nrl) {
-            const half_t* row = p.x + ((size_t)b * p.HW + r) * p.C;
+            const half_t* row = p.x + ((size_t)b * p.HW + r) * p.C + cb;
 #pragma unroll
             for (int j = 0; j < kMaxCols; ++j) {
                 const int cc = c0 + j * cstep;
@@ -106,15 +107,15 @@ __global__ __launch_bounds__(256) void gn_fwd_partial_kernel(GnArgs p) {
             }
         }
     }
-    gn_block_reduce(red, s, q, t, p.C, p.G, rl, nrl, c0, cstep, active, nullptr,
-                    p.partial + ((size_t)b * p.nchunk + chunk) * p.G * 2, nullptr);
+    gn_block_reduce(red, s, q, t, p.CS, gps, rl, nrl, c0, cstep, active, nullptr,
+                    p.partial + (((size_t)b * p.nchunk + chunk) * p.G + blockIdx.y * gps) * 2, nullptr);
 }
 
 // ---- backward, pass 1: per channel a1 = sum dyp, a2 = sum dyp*xhat over this block's rows
 __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(GnArgs p) {
     __shared__ float red[kRedFloats];
-    const int t = threadIdx.x, b = blockIdx.y, chunk = blockIdx.x;
-    const int CH = p.C / 8, cpg = p.C / p.G;
+    const int t = threadIdx.x, b = blockIdx.z, chunk = blockIdx.x, cb = blockIdx.y * p.CS;
+    const int CH = p.CS / 8, cpg = p.C / p.G, gps = p.G / p.nslab;
     int rl, nrl, c0, cstep; bool active;
     gn_thread_map(t, CH, rl, nrl, c0, cstep, active);
     const int r_beg = chunk * p.rows_per_chunk;
@@ -127,14 +128,14 @@ __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(GnArgs p) {
         for (int e = 0; e < 8; ++e) {
             a1[j][e] = 0.f; a2[j][e] = 0.f;
             const int cc = c0 + j * cstep;
-            const int ch = (cc < CH ? cc : 0) * 8 + e;
+            const int ch = cb + (cc < CH ? cc : 0) * 8 + e;
             const float* st = p.stats + ((size_t)b * p.G + ch / cpg) * 2;
             kmean[j][e] = st[0]; krstd[j][e] = st[1]; kg[j][e] = p.gamma[ch]; kb[j][e] = p.beta[ch];
         }
     if (active) {
 #pragma unroll 2
         for (int r = r_beg + rl; r < r_end; r += nrl) {
-            const size_t off = ((size_t)b * p.HW + r) * p.C;
+            const size_t off = ((size_t)b * p.HW + r) * p.C + cb;
 #pragma unroll
             for (int j = 0; j < kMaxCols; ++j) {
                 const int cc = c0 + j * cstep;
@@ -152,9 +153,9 @@ __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(GnArgs p) {
             }
         }
     }
-    gn_block_reduce(red, a1, a2, t, p.C, p.G, rl, nrl, c0, cstep, active, p.gamma,
-                    p.partial + ((size_t)b * p.nchunk + chunk) * p.G * 2,
-                    p.chpart ? p.chpart + ((size_t)b * p.nchunk + chunk) * p.C * 2 : nullptr);
+    gn_block_reduce(red, a1, a2, t, p.CS, gps, rl, nrl, c0, cstep, active, p.gamma + cb,
+                    p.partial + (((size_t)b * p.nchunk + chunk) * p.G + blockIdx.y * gps) * 2,
+                    p.chpart ? p.chpart + (((size_t)b * p.nchunk + chunk) * p.C + cb) * 2 : nullptr);
 }
 
 // ---- fused finalize + apply (forward): every block re-folds the chunk partials of its batch element (a few KB
@@ -175,8 +176,8 @@ __device__ __forceinline__ void gn_fold_groups(const GnArgs& p, int b, int t, fl
 
 __global__ __launch_bounds__(256) void gn_fwd_apply2_kernel(GnArgs p) {
     __shared__ float mr[64 * 2];
-    const int t = threadIdx.x, b = blockIdx.y, chunk = blockIdx.x;
-    const int CH = p.C / 8, cpg = p.C / p.G;
+    const int t = threadIdx.x, b = blockIdx.z, chunk = blockIdx.x, cb = blockIdx.y * p.CS;
+    const int CH = p.CS / 8, cpg = p.C / p.G;
     gn_fold_groups(p, b, t, mr, 1.0f / ((float)p.HW * (float)cpg));
     __syncthreads();
     if (t < p.G) {                                  // (E[x], E[x^2]) -> (mean, rstd)
@@ -185,7 +186,7 @@ __global__ __launch_bounds__(256) void gn_fwd_apply2_kernel(GnArgs p) {
         var = var < 0.f ? 0.f : var;
         const float rstd = rsqrtf(var + p.eps);
         mr[t * 2 + 1] = rstd;
-        if (chunk == 0) { p.stats[((size_t)b * p.G + t) * 2] = mean; p.stats[((size_t)b * p.G + t) * 2 + 1] = rstd; }
+        if (chunk == 0 && blockIdx.y == 0) { p.stats[((size_t)b * p.G + t) * 2] = mean; p.stats[((size_t)b * p.G + t) * 2 + 1] = rstd; }
     }
     __syncthreads();
     int rl, nrl, c0, cstep; bool active;
@@ -196,7 +197,7 @@ __global__ __launch_bounds__(256) void gn_fwd_apply2_kernel(GnArgs p) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int cc = c0 + j * cstep;
-            const int ch = (cc < CH ? cc : 0) * 8 + e, g = ch / cpg;
+            const int ch = cb + (cc < CH ? cc : 0) * 8 + e, g = ch / cpg;
             sc[j][e] = mr[g * 2 + 1] * p.gamma[ch];
             sh[j][e] = p.beta[ch] - mr[g * 2] * sc[j][e];
         }
@@ -205,7 +206,7 @@ __global__ __launch_bounds__(256) void gn_fwd_apply2_kernel(GnArgs p) {
     const int r_end = (r_beg + p.rows_per_chunk < p.HW) ? r_beg + p.rows_per_chunk : p.HW;
 #pragma unroll 4
     for (int r = r_beg + rl; r < r_end; r += nrl) {
-        const size_t off = ((size_t)b * p.HW + r) * p.C;
+        const size_t off = ((size_t)b * p.HW + r) * p.C + cb;
 #pragma unroll
         for (int j = 0; j < kMaxCols; ++j) {
             const int cc = c0 + j * cstep;
@@ -227,8 +228,8 @@ __global__ __launch_bounds__(256) void gn_fwd_apply2_kernel(GnArgs p) {
 // ---- fused finalize + apply (backward): dx = k1*dyp + k2*x + k3 with per-channel coefficients in registers
 __global__ __launch_bounds__(256) void gn_bwd_apply2_kernel(GnArgs p) {
     __shared__ float gs[64 * 2];
-    const int t = threadIdx.x, b = blockIdx.y, chunk = blockIdx.x;
-    const int CH = p.C / 8, cpg = p.C / p.G;
+    const int t = threadIdx.x, b = blockIdx.z, chunk = blockIdx.x, cb = blockIdx.y * p.CS;
+    const int CH = p.CS / 8, cpg = p.C / p.G;
     gn_fold_groups(p, b, t, gs, 1.0f / ((float)p.HW * (float)cpg));
     __syncthreads();
     int rl, nrl, c0, cstep; bool active;
@@ -239,7 +240,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply2_kernel(GnArgs p) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int cc = c0 + j * cstep;
-            const int ch = (cc < CH ? cc : 0) * 8 + e, g = ch / cpg;
+            const int ch = cb + (cc < CH ? cc : 0) * 8 + e, g = ch / cpg;
             const float mean = p.stats[((size_t)b * p.G + g) * 2], rstd = p.stats[((size_t)b * p.G + g) * 2 + 1];
             const float s_ = rstd * p.gamma[ch];
             sc[j][e] = s_;
@@ -253,7 +254,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply2_kernel(GnArgs p) {
     const int r_end = (r_beg + p.rows_per_chunk < p.HW) ? r_beg + p.rows_per_chunk : p.HW;
 #pragma unroll 2
     for (int r = r_beg + rl; r < r_end; r += nrl) {
-        const size_t off = ((size_t)b * p.HW + r) * p.C;
+        const size_t off = ((size_t)b * p.HW + r) * p.C + cb;
 #pragma unroll
         for (int j = 0; j < kMaxCols; ++j) {
             const int cc = c0 + j * cstep;
@@ -391,6 +392,25 @@ int gn_plan(GnArgs& a, void* ws, size_t ws_bytes, bool bwd, bool params) {
     if (rpc > a.HW) rpc = a.HW;
     a.rows_per_chunk = (int)rpc;
     a.nchunk = clora_cdiv(a.HW, rpc);
+    // channel slabs: when the row chunks alone leave most of the 256 CUs idle (16x16 / 8x8 feature maps with
+    // 1280..2560 channels) split the channels too, at whole-group and 8-channel granularity
+    {
+        const int cpg = a.C / a.G;
+        int unit_groups = 1;                                   // groups per smallest slab: (unit_groups*cpg) % 8 == 0
+        while ((unit_groups * cpg) & 7) ++unit_groups;
+        int nslab = 1;
+        if (a.G % unit_groups == 0) {
+            const int nunits = a.G / unit_groups;
+            const long want = (512 + (long)a.B * a.nchunk - 1) / ((long)a.B * a.nchunk);
+            for (int d = 1; d <= nunits; ++d) {
+                if (nunits % d) continue;
+                if (d <= want || a.C / nslab > 2048) nslab = d;   // largest divisor <= want, grown until a slab fits
+                else break;
+            }
+        }
+        a.nslab = nslab;
+        a.CS = a.C / nslab;
+    }
     size_t need = (size_t)a.B * a.nchunk * a.G * 2;
     if (params) need += (size_t)a.B * a.nchunk * a.C * 2;
     if (!ws || ws_bytes < need * sizeof(float)) return CLORA_ERR_WORKSPACE;
@@ -426,8 +446,8 @@ extern "C" int clora_groupnorm_fwd_f16(const clora_half* x, clora_half* y, const
     int rc = gn_plan(a, workspace, workspace_bytes, false, false);
     if (rc != CLORA_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(gn_fwd_partial_kernel, dim3(a.nchunk, B), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(gn_fwd_apply2_kernel, dim3(a.nchunk, B), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(gn_fwd_partial_kernel, dim3(a.nchunk, a.nslab, B), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(gn_fwd_apply2_kernel, dim3(a.nchunk, a.nslab, B), dim3(256), 0, s, a);
     return clora_check_launch();
 }
 
@@ -443,9 +463,9 @@ extern "C" int clora_groupnorm_bwd_f16(const clora_half* x, const clora_half* dy
     int rc = gn_plan(a, workspace, workspace_bytes, true, dgamma != nullptr);
     if (rc != CLORA_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(gn_bwd_partial_kernel, dim3(a.nchunk, B), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(gn_bwd_partial_kernel, dim3(a.nchunk, a.nslab, B), dim3(256), 0, s, a);
     if (dgamma) hipLaunchKernelGGL(gn_bwd_params_kernel, dim3(clora_cdiv(C, 32)), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(gn_bwd_apply2_kernel, dim3(a.nchunk, B), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(gn_bwd_apply2_kernel, dim3(a.nchunk, a.nslab, B), dim3(256), 0, s, a);
     return clora_check_launch();
 }
 
