@@ -286,11 +286,18 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
 __device__ __attribute__((aligned(16))) const unsigned g_clora_zero16[4] = {0u, 0u, 0u, 0u};
 
 // blocks per CU the LDS ring allows (48 / 36 / 24 KB): the register allocator is told to leave room for them
-template <int BM, int BN> struct DmaOcc { static constexpr int v = (BM * BN >= 128 * 128) ? 3 : ((BM * BN >= 128 * 64) ? 4 : 6); };
+// (NST = 3: 48 / 36 / 24 KB -> 3 / 4 / 6 blocks; the deep rings for grids that cannot fill a CU with blocks anyway
+//  -- 5 x 16 KB, 6 x 12 KB, 8 x 8 KB -- leave 2 blocks per CU but 2-3x the bytes in flight per block)
+template <int BM, int BN, int NST> struct DmaOcc {
+    static constexpr int lds = NST * (BM + BN) * 32 * 2;
+    static constexpr int fit = (160 * 1024) / lds;
+    static constexpr int cap = (BM * BN >= 128 * 128) ? 3 : ((BM * BN >= 128 * 64) ? 4 : 6);
+    static constexpr int v = fit < cap ? fit : cap;
+};
 
-template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256, (DmaOcc<BM, BN>::v)) void gemm_dma_kernel(GemmArgs p) {
-    constexpr int BK = 32, NST = 3;
+template <int BM, int BN, int WM, int WN, int NST>
+__global__ __launch_bounds__(256, (DmaOcc<BM, BN, NST>::v)) void gemm_dma_kernel(GemmArgs p) {
+    constexpr int BK = 32;
     constexpr int FM = BM / WM / 16, FN = BN / WN / 16;
     constexpr int A_IN = BM / 64, B_IN = BN / 64;          // DMA wave-instructions per stage per wave
     constexpr int STAGE = (BM + BN) * BK;                   // halves
@@ -396,14 +403,19 @@ __global__ __launch_bounds__(256, (DmaOcc<BM, BN>::v)) void gemm_dma_kernel(Gemm
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = zero4f();
 
-    if (nk > 0) issue_stage(0);
-    if (nk > 1) issue_stage(1);
+    // NST-1 stages are always in flight: stages past the end of K fetch the zero page (cheap L2 hits), which keeps
+    // the counted wait a compile-time constant
+#pragma unroll
+    for (int st = 0; st < NST - 1; ++st) issue_stage(st);
+    int rd = 0, wr = NST - 1;
     for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) CLORA_WAIT_VMCNT(A_IN + B_IN); else CLORA_WAIT_VMCNT(0);
-        CLORA_RAW_BARRIER();
-        if (kt + 2 < nk) issue_stage((kt + 2) % NST);
-        const half_t* As = smem + (kt % NST) * STAGE;
+        CLORA_WAIT_VMCNT((NST - 2) * (A_IN + B_IN));          // stage kt has landed (loads retire in order)
+        CLORA_RAW_BARRIER();                                   // ... for every wave, and stage kt-1 is fully consumed
+        issue_stage(wr);
+        wr = (wr + 1 == NST) ? 0 : wr + 1;
+        const half_t* As = smem + rd * STAGE;
         const half_t* Bs = As + BM * BK;
+        rd = (rd + 1 == NST) ? 0 : rd + 1;
         half8 af[FM], bf[FN];
 #pragma unroll
         for (int i = 0; i < FM; ++i) af[i] = ld8(As + (wm * FM * 16 + i * 16 + li) * BK + fsw);
@@ -414,6 +426,7 @@ __global__ __launch_bounds__(256, (DmaOcc<BM, BN>::v)) void gemm_dma_kernel(Gemm
 #pragma unroll
             for (int j = 0; j < FN; ++j) acc[i][j] = mfma16(af[i], bf[j], acc[i][j]);
     }
+    CLORA_WAIT_VMCNT(0);                                       // trailing zero-page stages: LDS is reused below
 
     if (p.partial) {
         float* slab = p.partial + (size_t)split * p.M * p.N;
@@ -598,11 +611,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
             }
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int NST = 3>
 int launch_gemm(GemmArgs& a, int splits, hipStream_t s, bool dma) {
     a.tiles_n = clora_cdiv(a.N, BN);
     const int tiles_m = clora_cdiv(a.M, BM);
-    if (dma) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, WM, WN>), dim3(tiles_m * a.tiles_n, splits), dim3(256), 0, s, a);
+    if (dma) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, WM, WN, NST>), dim3(tiles_m * a.tiles_n, splits), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN>), dim3(tiles_m * a.tiles_n, splits), dim3(256), 0, s, a);
     return clora_check_launch();
 }
@@ -672,6 +685,8 @@ extern "C" int clora_gemm_f16_ex(const clora_half* A, int lda, const clora_half*
     }
     bool dma = true;                       // tile_cfg 11..13 = the register-staged v1 main loop (A/B comparisons)
     if (tile_cfg >= 11 && tile_cfg <= 13) { dma = false; tile_cfg -= 10; }
+    bool deep = false;                     // tile_cfg 4..6 = the same tiles with the deep LDS ring (few-block grids)
+    if (tile_cfg >= 4 && tile_cfg <= 6) { deep = true; tile_cfg -= 3; }
     if (tile_cfg >= 1 && tile_cfg <= 3) tile = tile_cfg - 1;
     a.k_per_split = clora_cdiv(clora_cdiv(K, 32), splits) * 32;
     splits = clora_cdiv(K, a.k_per_split);
@@ -680,7 +695,11 @@ extern "C" int clora_gemm_f16_ex(const clora_half* A, int lda, const clora_half*
         a.partial = (float*)workspace;
     }
     int rc;
-    if (tile == 0) rc = launch_gemm<128, 128, 2, 2>(a, splits, s, dma);
+    if (deep) {
+        if (tile == 0) rc = launch_gemm<128, 128, 2, 2, 5>(a, splits, s, true);
+        else if (tile == 1) rc = launch_gemm<128, 64, 4, 1, 6>(a, splits, s, true);
+        else rc = launch_gemm<64, 64, 2, 2, 8>(a, splits, s, true);
+    } else if (tile == 0) rc = launch_gemm<128, 128, 2, 2>(a, splits, s, dma);
     else if (tile == 1) rc = launch_gemm<128, 64, 4, 1>(a, splits, s, dma);
     else rc = launch_gemm<64, 64, 2, 2>(a, splits, s, dma);
     if (rc != CLORA_OK) return rc;

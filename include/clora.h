@@ -74,7 +74,8 @@ typedef struct {
 int clora_gemm_f16(const clora_half* A, int lda, const clora_half* B, clora_half* C, int ldc,
                    int M, int N, int K, const clora_conv_t* conv, const clora_epilogue_t* epi,
                    int split_k, void* workspace, size_t workspace_bytes, void* stream);
-/* same, with the tile shape forced (tile_cfg 1: 128x128, 2: 128x64, 3: 64x64; 0 = automatic) -- tuning / tests */
+/* same, with the main-loop variant forced (tile_cfg 1: 128x128, 2: 128x64, 3: 64x64 tiles with the 3-stage LDS ring;
+ * 4-6: the same tiles with the deep 5/6/8-stage ring; 11-13: register-staged v1 loop; 0 = automatic) -- tuning / tests */
 int clora_gemm_f16_ex(const clora_half* A, int lda, const clora_half* B, clora_half* C, int ldc,
                       int M, int N, int K, const clora_conv_t* conv, const clora_epilogue_t* epi,
                       int split_k, int tile_cfg, void* workspace, size_t workspace_bytes, void* stream);

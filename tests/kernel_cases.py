@@ -21,27 +21,27 @@ def rnd(shape, dev, gen, scale=1.0, dtype=f16):
     return (torch.randn(shape, generator=gen) * scale).to(dtype).to(dev)
 
 
-def case_gemm_plain(dev, M, N, K_, split_k=1, seed=0):
+def case_gemm_plain(dev, M, N, K_, split_k=1, seed=0, tile_cfg=0):
     g = torch.Generator().manual_seed(seed)
     A, B = rnd((M, K_), dev, g), rnd((N, K_), dev, g, 1 / math.sqrt(K_))
-    out = K.gemm(A, B, M, N, K_, split_k=split_k)
+    out = K.gemm(A, B, M, N, K_, split_k=split_k, tile_cfg=tile_cfg)
     assert rel(out, A.float() @ B.float().T) < 6e-4
 
 
-def case_gemm_epilogue(dev, M=200, N=96, K_=64, split_k=1):
+def case_gemm_epilogue(dev, M=200, N=96, K_=64, split_k=1, tile_cfg=0):
     g = torch.Generator().manual_seed(1)
     A, B = rnd((M, K_), dev, g), rnd((N, K_), dev, g, 1 / math.sqrt(K_))
     bias, rowadd, res = rnd((N,), dev, g, dtype=f32), rnd((4, N), dev, g), rnd((M, N), dev, g)
     T, U = rnd((M, 8), dev, g, dtype=f32), rnd((N, 4), dev, g, dtype=f32)
     out = K.gemm(A, B, M, N, K_, bias=bias, rowadd=rowadd, rows_per_batch=M // 4, residual=res, lora_t=T, lora_u=U,
-                 lora_seg=N // 2, lora_scale=0.7, split_k=split_k)
+                 lora_seg=N // 2, lora_scale=0.7, split_k=split_k, tile_cfg=tile_cfg)
     seg = torch.arange(N, device=dev) // (N // 2)
     lora = torch.stack([T[:, int(s) * 4:(int(s) + 1) * 4] @ U[n] for n, s in enumerate(seg.tolist())], 1)
     ref = (A.float() @ B.float().T + bias + rowadd.float().repeat_interleave(M // 4, 0) + 0.7 * lora).half().float() + res.float()
     assert rel(out, ref) < 6e-4
 
 
-def case_conv(dev, Bn, H, W, Ci, Co, stride=1, pad=1, ups=False, asym=False, seed=2):
+def case_conv(dev, Bn, H, W, Ci, Co, stride=1, pad=1, ups=False, asym=False, seed=2, tile_cfg=0):
     """forward, dgrad and wgrad of one 3x3 conv configuration against F.conv2d autograd."""
     g = torch.Generator().manual_seed(seed)
     x = rnd((Bn, Ci, H, W), dev, g)
@@ -60,13 +60,13 @@ def case_conv(dev, Bn, H, W, Ci, Co, stride=1, pad=1, ups=False, asym=False, see
     cd, Ho2, Wo2 = K.conv_fwd_desc(H, W, Ci, 3, stride, pad, upsample=ups, asym_pad=asym)
     assert (Ho2, Wo2) == (Ho, Wo)
     M = Bn * Ho * Wo
-    out = K.gemm(xn, wp, M, Co, 9 * Ci, conv=cd)
+    out = K.gemm(xn, wp, M, Co, 9 * Ci, conv=cd, tile_cfg=tile_cfg, split_k=1 if tile_cfg else 0)
     assert rel(out, y.detach().permute(0, 2, 3, 1).reshape(M, Co)) < 6e-4
     Hi, Wi = xin.shape[2:]
     wd = w.permute(1, 2, 3, 0).contiguous().reshape(Ci, 9 * Co)
     dyn = dy.permute(0, 2, 3, 1).contiguous()
     cdd = K.conv_dgrad_desc(Ho, Wo, Co, Hi, Wi, 3, 2 if asym else stride, pad, asym_pad=asym)
-    dx = K.gemm(dyn, wd, Bn * Hi * Wi, Ci, 9 * Co, conv=cdd)
+    dx = K.gemm(dyn, wd, Bn * Hi * Wi, Ci, 9 * Co, conv=cdd, tile_cfg=tile_cfg, split_k=2 if tile_cfg else 0)
     assert rel(dx, xin.grad.permute(0, 2, 3, 1).reshape(-1, Ci)) < 6e-4
     if ups:
         pooled = K.pool2x2_sum(dx.reshape(Bn, Hi * Wi, Ci), Bn, H, W, Ci)

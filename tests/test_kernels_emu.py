@@ -33,6 +33,15 @@ def test_conv_small_channels():
     KC.case_conv("cpu", 1, 16, 16, 8, 32)       # hint-encoder conv_in shape class (3 -> padded 8 channels)
 
 
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6])
+def test_gemm_tile_configs(tile):
+    """every main-loop variant (tile shape x ring depth), with ragged M/N/K, split-K and the fused epilogue"""
+    KC.case_gemm_plain("cpu", 150, 72, 104, 1, tile_cfg=tile)
+    KC.case_gemm_plain("cpu", 70, 136, 424, 3, tile_cfg=tile)
+    KC.case_gemm_epilogue("cpu", split_k=1, tile_cfg=tile)
+    KC.case_conv("cpu", 1, 8, 8, 16, 24, tile_cfg=tile)
+
+
 @pytest.mark.parametrize("B,H,Nq,Nk,D,fused", [(1, 2, 70, 70, 40, True), (2, 2, 64, 77, 40, False), (1, 2, 33, 130, 80, False),
                                                (1, 1, 40, 40, 160, True), (1, 2, 20, 20, 8, False), (1, 1, 150, 77, 64, False),
                                                (1, 2, 640, 77, 40, False)])

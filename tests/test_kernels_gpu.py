@@ -41,6 +41,15 @@ def test_conv_small_channels():
     KC.case_conv(DEV, 1, 64, 64, 8, 32)
 
 
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6])
+def test_gemm_tile_configs(tile):
+    """every main-loop variant (tile shape x ring depth), with ragged M/N/K, split-K and the fused epilogue"""
+    KC.case_gemm_plain(DEV, 1000, 328, 1256, 1, tile_cfg=tile)
+    KC.case_gemm_plain(DEV, 333, 640, 2568, 3, tile_cfg=tile)
+    KC.case_gemm_epilogue(DEV, M=2000, N=320, K_=320, split_k=1, tile_cfg=tile)
+    KC.case_conv(DEV, 2, 32, 32, 64, 128, tile_cfg=tile)
+
+
 @pytest.mark.parametrize("B,H,Nq,Nk,D,fused", [
     (1, 8, 4096, 4096, 40, True), (2, 8, 4096, 77, 40, False), (2, 8, 1024, 1024, 80, True), (2, 8, 1024, 77, 80, False),
     (2, 8, 256, 256, 160, True), (2, 8, 64, 77, 160, False), (1, 2, 70, 70, 40, True), (1, 1, 150, 77, 64, False),

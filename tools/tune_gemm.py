@@ -42,15 +42,22 @@ K.gemm = orig
 torch.cuda.synchronize()
 print(f"{len(seen)} distinct GEMM signatures", flush=True)
 
-def timeit(fn, iters=6, warm=2):
+def timeit(fn, iters=10, warm=2):
+    """GPU-side time per call: the calls are captured into one hipGraph (no Python / launch overhead between
+    kernels -- the same regime as the captured train step) and the replay is timed with events."""
     for _ in range(warm):
         fn()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(iters):
+            fn()
+    g.replay()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize(); e0.record()
-    for _ in range(iters):
-        fn()
+    g.replay(); g.replay()
     e1.record(); torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / iters * 1e3
+    return e0.elapsed_time(e1) / (2 * iters) * 1e3
 
 table = {}
 for (M, N, Kd, ck), cnt in sorted(seen.items(), key=lambda kv: -kv[0][0] * kv[0][1] * kv[0][2]):
@@ -64,7 +71,7 @@ for (M, N, Kd, ck), cnt in sorted(seen.items(), key=lambda kv: -kv[0][0] * kv[0]
     res_ = torch.randn(M, N, device=dev).half()
     best, err = None, None
     auto = timeit(lambda: K.gemm(A, Bw, M, N, Kd, conv=conv, out=out, residual=res_, split_k=0, tile_cfg=0, _tuned=False))
-    for tile in (1, 2, 3):
+    for tile in (1, 2, 3, 4, 5, 6):
         for sk in (1, 2, 3, 4, 6, 8, 12, 16):
             if sk > 1 and (Kd // 32) // sk < 4:
                 continue
@@ -84,6 +91,6 @@ for (M, N, Kd, ck), cnt in sorted(seen.items(), key=lambda kv: -kv[0][0] * kv[0]
     table[key] = [best[1], best[2]]
     print(f"{key:48s} x{cnt:3d} auto {auto:8.1f}us best tile={best[1]} sk={best[2]:2d} {best[0]:8.1f}us  ({auto / best[0]:.2f}x)", flush=True)
 path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "controllora_amd", "gemm_tuning_gfx950.json")
-json.dump(dict(device=torch.cuda.get_device_name(0), note="tile: 1=128x128 2=128x64 3=64x64; value = [tile, split_k]", table=table),
+json.dump(dict(device=torch.cuda.get_device_name(0), note="tile: 1=128x128 2=128x64 3=64x64, 4-6 = same tiles with the deep LDS ring; value = [tile, split_k]", table=table),
           open(path, "w"), indent=0)
 print("wrote", path)
