@@ -111,7 +111,8 @@ def _tuned(M, N, K, conv):
         import json
         import os
         path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gemm_tuning_gfx950.json")
-        _TUNING = json.load(open(path))["table"] if os.path.exists(path) else {}
+        use = os.path.exists(path) and os.environ.get("CLORA_GEMM_TUNING", "1") != "0"   # "0": latency model only (A/B runs)
+        _TUNING = json.load(open(path))["table"] if use else {}
     return _TUNING.get(tuning_key(M, N, K, conv))
 
 
