@@ -27,7 +27,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HOT_PATH_TFLOP_PER_IMAGE_512 = 1.81      # fwd 803.3 + bwd 929.4 GFLOP UNet + 3x(adapters + hint)
+def hot_path_tflop_per_image(res):
+    """algorithmic work of one trained image (roofline.py: shapes only, 2 x MACs; SURVEY.md section 8d: 1.81 @512^2)"""
+    import roofline as R
+    cfg = json.load(open(os.path.join(ROOT, "configs", "fill50k.json")))
+    return R.train_step_flops_per_image(res, cfg, 1.51 * (res / 512) ** 2)["total"] / 1e12
 MFMA_PEAK_TFLOPS = 2500.0                # dense fp16, MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
 
@@ -204,7 +208,8 @@ def main():
                     "launches": dom["calls"], "avg_launch_us": round(dom["ms"] * 1e3 / dom["calls"], 1),
                     "kernel_ms_per_step": round(total_ms, 2), "families": fam,
                     "whole_step_frac_of_mfma_peak": round(
-                        images_per_s / world * HOT_PATH_TFLOP_PER_IMAGE_512 * (args.res / 512) ** 2 / MFMA_PEAK_TFLOPS, 4)}
+                        images_per_s / world * hot_path_tflop_per_image(args.res) / MFMA_PEAK_TFLOPS, 4),
+                    "whole_step_algorithmic_TFLOPs": round(images_per_s / world * hot_path_tflop_per_image(args.res), 1)}
 
     # secondary line of BASELINE.json's metric: 50-step DDIM latency, 512^2, 16 images, CFG 9.0 (UNet batch 32),
     # control batch 1 (the inference call pattern of apps/gradio_canny2image.py:66-92); replicas only, rank 0, N=1
