@@ -217,6 +217,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, fl
                                                     float lr, float beta1, float beta2, float eps, float wd) {
     if (st[6] != 0.f) return;  // GradScaler semantics: skip the step on inf/nan
     const float gm = st[5], bc1 = st[7], rbc2 = rsqrtf(st[8]);
+    lr *= (st[10] > 0.f ? st[10] : 1.0f);   // device-resident LR-schedule multiplier (0 = unset): graphs stay valid
     const float step_size = lr / bc1;
     EW_LOOP(i, n) {
         const float gr = g[i] * gm;

@@ -70,7 +70,8 @@ class FlatParams:
 
 class ControlLoRATrainer:
     def __init__(self, unet, control_lora, lr=1e-4, betas=(0.9, 0.999), weight_decay=1e-2, eps=1e-8, max_grad_norm=1.0,
-                 init_scale=65536.0, dynamic_scale=True, growth_interval=2000, process_group=None, world_size=1):
+                 init_scale=65536.0, dynamic_scale=True, growth_interval=2000, process_group=None, world_size=1,
+                 gradient_accumulation_steps=1, lr_lambda=None):
         self.unet, self.control_lora = unet, control_lora
         trainable = {id(p) for p in control_lora.parameters()}
         for p in unet.parameters():          # the installed processors are sub-modules of the UNet too: keep them trainable
@@ -84,28 +85,43 @@ class ControlLoRATrainer:
         self.state[3] = init_scale
         self.loss_sum = torch.zeros(1, dtype=f32, device=dev)
         self.pg, self.world = process_group, world_size
+        # gradient accumulation (train...:174-178, `accelerator.accumulate`): micro-batch losses are divided by the
+        # number of accumulation steps and the optimizer runs on the last micro-batch only
+        self.accum, self._micro = max(1, int(gradient_accumulation_steps)), 0
+        # LR schedule (train...:660-665 get_scheduler): multiplier(step) written to state[10] before each optimizer step
+        self.lr_lambda, self.global_step = lr_lambda, 0
         if world_size > 1:
             torch.distributed.broadcast(self.flat.data, src=0, group=process_group)   # identical adapter init
 
     # -- pieces (kept separate so tests can check each against the oracle)
     def forward_backward(self, noisy_latents, timesteps, encoder_hidden_states, guide, target):
-        self.flat.zero_grad()
+        if self._micro == 0:
+            self.flat.zero_grad()
         self.loss_sum.zero_()
         self.control_lora(guide)                                    # injects control states into the 32 processors
         pred = self.unet(noisy_latents, timesteps, encoder_hidden_states).sample
         pred_c = pred.contiguous()
         dpred = torch.empty_like(pred_c)
         n = pred_c.numel()
-        K.mse(pred_c, target.to(f16).contiguous(), self.loss_sum, dpred, 2.0 / n, self.state[3:4])
+        K.mse(pred_c, target.to(f16).contiguous(), self.loss_sum, dpred, 2.0 / n / self.accum, self.state[3:4])
         pred_c.backward(dpred)
         return pred
 
     def optimizer_step(self):
+        """all-reduce + clip + AdamW; with gradient accumulation only every `accum`-th call does anything"""
+        self._micro += 1
+        if self._micro < self.accum:
+            return False
+        self._micro = 0
+        if self.lr_lambda is not None:
+            self.state[10:11].fill_(max(float(self.lr_lambda(self.global_step)), 1e-30))
+        self.global_step += 1
         g = self.flat.grad
         if self.world > 1:
             torch.distributed.all_reduce(g, group=self.pg)           # RCCL over xGMI: one flat 24 MB buffer
             g.mul_(1.0 / self.world)
         self._optimizer_kernels()
+        return True
 
     def _optimizer_kernels(self):
         g = self.flat.grad
@@ -147,12 +163,45 @@ class ControlLoRATrainer:
         for dst, src in zip(self._static, (noisy_latents, timesteps, encoder_hidden_states, guide, target)):
             if src is not None and src.data_ptr() != dst.data_ptr():
                 dst.copy_(src, non_blocking=True)
+        assert self.accum == 1, "the captured step assumes one micro-batch per optimizer step"
         self._g_fb.replay()
         if self.world > 1:
             torch.distributed.all_reduce(self.flat.grad, group=self.pg)
             self.flat.grad.mul_(1.0 / self.world)
+        if self.lr_lambda is not None:
+            self.state[10:11].fill_(max(float(self.lr_lambda(self.global_step)), 1e-30))
+        self.global_step += 1
         self._g_opt.replay()
         return self._static_pred
+
+    # -- checkpoint / resume (train...:713-735 `accelerator.save_state / load_state`: weights, optimizer moments,
+    # GradScaler state and the step counters; one flat tensor each because the trainer state IS flat)
+    def state_dict(self) -> Dict[str, torch.Tensor]:
+        return {"params": self.flat.data.detach().cpu().clone(), "exp_avg": self.flat.exp_avg.cpu().clone(),
+                "exp_avg_sq": self.flat.exp_avg_sq.cpu().clone(), "state": self.state.cpu().clone(),
+                "global_step": torch.tensor([self.global_step], dtype=torch.int64)}
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor]) -> None:
+        if sd["params"].numel() != self.flat.numel:
+            raise ValueError(f"checkpoint holds {sd['params'].numel()} trainable values, the model has {self.flat.numel}")
+        with torch.no_grad():
+            self.flat.data.copy_(sd["params"])
+            self.flat.exp_avg.copy_(sd["exp_avg"])
+            self.flat.exp_avg_sq.copy_(sd["exp_avg_sq"])
+            self.state.copy_(sd["state"])
+        self.global_step, self._micro = int(sd["global_step"][0]), 0
+
+    def save_state(self, directory: str) -> None:
+        import os
+        from safetensors.torch import save_file
+        os.makedirs(directory, exist_ok=True)
+        save_file(self.state_dict(), os.path.join(directory, "trainer_state.safetensors"))
+        self.control_lora.save_pretrained(directory)
+
+    def load_state(self, directory: str) -> None:
+        import os
+        from safetensors.torch import load_file
+        self.load_state_dict(load_file(os.path.join(directory, "trainer_state.safetensors")))
 
     # -- host-visible scalars (each forces a sync; call outside the timed region)
     def loss(self, numel) -> float:

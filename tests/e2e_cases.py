@@ -84,3 +84,54 @@ def check_against_golden(case, dev, golden_dir, tol_pred=5e-3, tol_grad=2.5e-2):
         lim = tol_grad if k == "grads" else (tol_pred if k == "pred" else (2e-3 if k == "loss" else 4e-3))
         assert e < lim, f"{case}:{k} rel-L2 {e:.3e} (limit {lim})  all={errs}"
     return errs
+
+
+def check_trainer_features(dev, golden_dir, real_backward=True):
+    """gradient accumulation (train...:174-178), LR-schedule multiplier and checkpoint/resume (train...:713-735)
+    of the device-resident trainer: accumulated grads equal the single-batch golden grads, the optimizer only
+    runs on the last micro-batch, and a trainer restored from `state_dict` continues bit-identically."""
+    inp = cases.seeded_inputs()
+    noisy = unet_ref.DDPMSchedule().add_noise(inp["latents"], inp["noise"], inp["timesteps"]).to(dev).to(f16)
+    args = (noisy, inp["timesteps"].to(dev), inp["ehs"].to(dev).to(f16), inp["guide"].to(dev).to(f16), inp["noise"].to(dev))
+    sched = lambda step: 0.5 if step == 0 else 1.0
+
+    def make(**kw):
+        unet, params, _ = build_product_case("v1", dev)
+        return ControlLoRATrainer(unet, params, init_scale=128.0, dynamic_scale=False, lr_lambda=sched, **kw)
+
+    gen = torch.Generator().manual_seed(3)
+
+    def backward(tr):
+        if real_backward:
+            tr.forward_backward(*args)
+        else:                                    # synthetic scaled gradients: same values for every trainer / call
+            if tr._micro == 0:
+                tr.flat.zero_grad()
+            g = torch.Generator().manual_seed(5)
+            tr.flat.grad += (torch.randn(tr.flat.numel, generator=g) * 128.0 / tr.accum).to(dev)
+
+    a = make(gradient_accumulation_steps=2)
+    p0 = a.flat.data.clone()
+    backward(a)
+    assert a.optimizer_step() is False and torch.equal(a.flat.data, p0)          # first micro-batch: no update
+    backward(a)
+    if real_backward:
+        gold = load_file(os.path.join(golden_dir, "case_v1.safetensors"))["grads"]
+        assert rel(a.unscaled_grads_module_order(), gold) < 2.5e-2               # two half-weighted micro-batches
+    assert a.optimizer_step() is True and not torch.equal(a.flat.data, p0)
+    assert float(a.state[10]) == 0.5 and a.global_step == 1
+    # Adam's first update has magnitude lr * multiplier (+ decoupled weight decay): 0.5e-4 here
+    delta = (a.flat.data - p0 * (1 - 0.5e-4 * 1e-2)).abs().max()
+    assert 0.45e-4 < float(delta) < 0.51e-4
+
+    sd = a.state_dict()
+    a.accum = 1
+    backward(a)
+    a.optimizer_step()
+    b = make()
+    b.load_state_dict(sd)
+    assert b.global_step == 1
+    backward(b)
+    b.optimizer_step()
+    assert float(b.state[10]) == 1.0
+    assert torch.equal(a.flat.data, b.flat.data) and torch.equal(a.flat.exp_avg_sq, b.flat.exp_avg_sq)

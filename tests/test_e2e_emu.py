@@ -72,3 +72,10 @@ def test_pre_post_lora_chain_matches_oracle(kind):
                                    list(o_main.named_parameters()) + list(o_pre.named_parameters()) + list(o_post.named_parameters())):
             if b_.grad is not None and float(b_.grad.norm()) > 0:
                 assert E.rel(a.grad, b_.grad) < 3e-2, (n, E.rel(a.grad, b_.grad))
+
+
+
+def test_trainer_accumulation_lr_schedule_and_resume(golden_dir):
+    """host logic of gradient accumulation / LR multiplier / checkpoint-resume with synthetic gradients (the full
+    version with real forward/backward passes runs in the GPU suite: tests/test_e2e_gpu.py)"""
+    E.check_trainer_features("cpu", golden_dir, real_backward=False)

@@ -91,3 +91,7 @@ def test_graph_replay_matches_eager_step():
     assert s0 == s1 == 2.0
     assert abs(l0 - l1) < 1e-5 * max(1.0, abs(l0))
     assert float((p0 - p1).norm() / p0.norm()) < 1e-5
+
+
+def test_trainer_accumulation_lr_schedule_and_resume(golden_dir):
+    E.check_trainer_features("cuda", golden_dir, real_backward=True)
