@@ -381,6 +381,53 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------ row softmax
+// y[r, :] = softmax(scale * x[r, :]) for the single-head d=512 attention of the VAE mid block (upstream
+// AutoencoderKL AttentionBlock; reference call sites train_text_to_image_control_lora.py:403,753 and
+// apps/gradio_canny2image.py decode), whose head dim is beyond the flash kernels' register budget: scores are
+// materialised by the GEMM kernel and normalised here.  One wave per row, the row lives in registers
+// (cols <= 64 lanes x kSmCols x 8), fp32 max / sum, in-place allowed.
+constexpr int kSmCols = 16;
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const half_t* x, half_t* y, int rows, int cols, int ld, float scale) {
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + w;
+    if (row >= rows) return;
+    const int CH = cols / 8;
+    const half_t* xr = x + (size_t)row * ld;
+    half_t* yr = y + (size_t)row * ld;
+    half8 v[kSmCols];
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int j = 0; j < kSmCols; ++j) {
+        const int cc = l + 64 * j;
+        if (cc < CH) {
+            v[j] = ld8(xr + cc * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) mx = fmaxf(mx, (float)v[j][e]);
+        }
+    }
+    mx = wave_max(mx) * scale;
+    float f[kSmCols][8];
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < kSmCols; ++j)
+        if (l + 64 * j < CH) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { f[j][e] = expf((float)v[j][e] * scale - mx); sum += f[j][e]; }
+        }
+    const float inv = 1.0f / wave_sum(sum);
+#pragma unroll
+    for (int j = 0; j < kSmCols; ++j) {
+        const int cc = l + 64 * j;
+        if (cc < CH) {
+            half8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (half_t)(f[j][e] * inv);
+            st8(yr + cc * 8, o);
+        }
+    }
+}
+
 int gn_plan(GnArgs& a, void* ws, size_t ws_bytes, bool bwd, bool params) {
     if (a.B <= 0 || a.HW <= 0 || a.C <= 0 || a.G <= 0 || a.G > 64 || (a.C % a.G) || (a.C & 7) || a.C > 4096)
         return CLORA_ERR_ARG;
@@ -484,5 +531,14 @@ extern "C" int clora_layernorm_bwd_f16(const clora_half* x, const clora_half* dy
     LnArgs a = LnArgs();
     a.x = (const half_t*)x; a.dy = (const half_t*)dy; a.y = (half_t*)dx; a.gamma = gamma; a.M = M; a.C = C; a.eps = eps;
     hipLaunchKernelGGL((layernorm_kernel<true>), dim3(clora_cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, a);
+    return clora_check_launch();
+}
+
+extern "C" int clora_softmax_rows_f16(const clora_half* x, clora_half* y, int rows, int cols, int ld, float scale,
+                                      void* stream) {
+    if (!x || !y || rows <= 0 || cols <= 0 || (cols & 7) || (ld & 7) || ld < cols || cols / 8 > 64 * kSmCols || !(scale > 0.f))
+        return CLORA_ERR_ARG;
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3(clora_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream,
+                       (const half_t*)x, (half_t*)y, rows, cols, ld, scale);
     return clora_check_launch();
 }

@@ -165,6 +165,16 @@ def conv_wgrad(dY: torch.Tensor, X: torch.Tensor, M: int, N: int, K: int, conv: 
 
 
 # ------------------------------------------------------------------ attention
+def softmax_rows(x: torch.Tensor, scale: float = 1.0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """row softmax of a 2-D fp16 matrix (fp32 statistics); `out` may alias `x`"""
+    assert x.dim() == 2 and x.stride(1) == 1
+    y = out if out is not None else torch.empty_like(x)
+    assert y.stride(0) == x.stride(0)
+    _call("clora_softmax_rows_f16", ptr(x, f16), ptr(y, f16), x.shape[0], x.shape[1], x.stride(0), float(scale),
+          nbytes=4.0 * x.numel())
+    return y
+
+
 def attn_fwd(q, k, v, B, H, Nq, Nk, D, scale, out=None):
     """q/k/v: 2-D row-strided views [B*N, >=H*D] (stride(0) is the row pitch)."""
     o = out if out is not None else torch.empty((B * Nq, H * D), dtype=f16, device=q.device)

@@ -23,6 +23,9 @@ class LinearPack:
     def __init__(self, weight: torch.Tensor, bias: Optional[torch.Tensor], pad_n_to: int = 8):
         w = weight.detach().reshape(weight.shape[0], -1).to(f16)
         N, Kd = w.shape
+        if Kd % 8:                                   # e.g. the VAE's 4-channel post_quant_conv: zero-padded input channels
+            w = torch.cat([w, w.new_zeros(N, 8 - Kd % 8)], 1)
+            Kd = w.shape[1]
         Np = (N + pad_n_to - 1) // pad_n_to * pad_n_to
         if Np != N:
             w = torch.cat([w, w.new_zeros(Np - N, Kd)], 0)

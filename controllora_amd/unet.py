@@ -56,11 +56,11 @@ class _Packed(nn.Module):
 
 
 class Conv3x3(_Packed):
-    def __init__(self, cin, cout, stride=1, pad=1, upsample=False, need_dgrad=True):
+    def __init__(self, cin, cout, stride=1, pad=1, upsample=False, need_dgrad=True, asym_pad=False):
         super().__init__()
         self.weight = _frozen(torch.empty(cout, cin, 3, 3, dtype=f16))
         self.bias = _frozen(torch.empty(cout, dtype=f16))
-        self.cfg = dict(stride=stride, pad=pad, upsample=upsample, need_dgrad=need_dgrad)
+        self.cfg = dict(stride=stride, pad=pad, upsample=upsample, need_dgrad=need_dgrad, asym_pad=asym_pad)
 
     def _build(self):
         return ops.ConvPack(self.weight, self.bias, **self.cfg)

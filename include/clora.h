@@ -114,6 +114,11 @@ int clora_groupnorm_bwd_f16(const clora_half* x, const clora_half* dy, clora_hal
                             const float* beta, const float* stats, float* dgamma, float* dbeta, int B, int HW, int C,
                             int G, int fuse_silu, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- row softmax  y[r,:] = softmax(scale * x[r,:])  (fp32 max/sum; cols % 8 == 0, cols <= 8192, scale > 0; in place
+ * allowed).  Normalises the materialised scores of the VAE's single-head d=512 attention (upstream AutoencoderKL
+ * AttentionBlock, used at reference train_text_to_image_control_lora.py:753 / apps/gradio_canny2image.py). */
+int clora_softmax_rows_f16(const clora_half* x, clora_half* y, int rows, int cols, int ld, float scale, void* stream);
+
 /* ---- LayerNorm over the last dim (upstream BasicTransformerBlock.norm1/2/3, eps 1e-5). */
 int clora_layernorm_fwd_f16(const clora_half* x, clora_half* y, const float* gamma, const float* beta, int M, int C,
                             float eps, void* stream);

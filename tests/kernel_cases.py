@@ -130,6 +130,16 @@ def case_groupnorm(dev, B, HW, C, G, silu, eps=1e-5, seed=4, train_params=False)
         assert rel(dg, g32.grad) < 1e-3 and rel(db, b32.grad) < 1e-3
 
 
+def case_softmax_rows(dev, rows, cols, scale=0.37, seed=6):
+    g = torch.Generator().manual_seed(seed)
+    x = (rnd((rows, cols), dev, g).float() * 4).half()
+    y = K.softmax_rows(x, scale)
+    ref = torch.softmax(x.float() * scale, -1)
+    assert float((y.float() - ref).abs().max()) < 1e-3 and float((y.float().sum(-1) - 1).abs().max()) < 4e-3
+    K.softmax_rows(x, scale, out=x)                      # in place
+    assert torch.equal(x, y)
+
+
 def case_layernorm(dev, M, C, seed=5):
     g = torch.Generator().manual_seed(seed)
     x = rnd((M, C), dev, g)

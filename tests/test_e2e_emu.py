@@ -79,3 +79,8 @@ def test_trainer_accumulation_lr_schedule_and_resume(golden_dir):
     """host logic of gradient accumulation / LR multiplier / checkpoint-resume with synthetic gradients (the full
     version with real forward/backward passes runs in the GPU suite: tests/test_e2e_gpu.py)"""
     E.check_trainer_features("cpu", golden_dir, real_backward=False)
+
+
+def test_vae_encode_decode_matches_oracle():
+    from tests import vae_cases
+    print(vae_cases.check_vae("cpu", res=32, batch=1))

@@ -95,3 +95,8 @@ def test_graph_replay_matches_eager_step():
 
 def test_trainer_accumulation_lr_schedule_and_resume(golden_dir):
     E.check_trainer_features("cuda", golden_dir, real_backward=True)
+
+
+def test_vae_encode_decode_matches_oracle():
+    from tests import vae_cases
+    print(vae_cases.check_vae("cuda", res=64, batch=2))

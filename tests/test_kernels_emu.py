@@ -75,3 +75,8 @@ def test_elementwise():
 
 def test_loss_and_optimizer():
     KC.case_loss_and_optimizer("cpu")
+
+
+@pytest.mark.parametrize("rows,cols", [(5, 64), (9, 1032)])
+def test_softmax_rows(rows, cols):
+    KC.case_softmax_rows("cpu", rows, cols)

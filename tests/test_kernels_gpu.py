@@ -86,3 +86,8 @@ def test_elementwise():
 
 def test_loss_and_optimizer():
     KC.case_loss_and_optimizer(DEV, n=100000)
+
+
+@pytest.mark.parametrize("rows,cols", [(4096, 4096), (1000, 72), (7, 8192)])
+def test_softmax_rows(rows, cols):
+    KC.case_softmax_rows(DEV, rows, cols)
