@@ -21,6 +21,14 @@ class DDPMScheduler:
         return a * original_samples + s * noise
 
 
+    def get_velocity(self, sample, noise, timesteps):
+        """v-prediction target (reference train...:776-777): sqrt(a_t) * noise - sqrt(1 - a_t) * sample"""
+        ac = self.alphas_cumprod.to(device=sample.device, dtype=sample.dtype)
+        a = ac[timesteps].sqrt().reshape(-1, 1, 1, 1)
+        s = (1 - ac[timesteps]).sqrt().reshape(-1, 1, 1, 1)
+        return a * noise - s * sample
+
+
 class DDIMScheduler(DDPMScheduler):
     """eta = 0, steps_offset = 1, set_alpha_to_one = False (the SD-1.5 scheduler config)."""
 

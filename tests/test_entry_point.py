@@ -1,0 +1,97 @@
+"""The drop-in training entry point (train_text_to_image_control_lora.py): flag surface of the reference's parse_args
+(reference train_text_to_image_control_lora.py:84-326), LR schedules, the synthetic fill50k data path (CPU), and on
+the GPU a short run with checkpoint + resume + final artefacts (reference :713-735, 796-809, 922-929)."""
+import json
+import os
+
+import pytest
+import torch
+
+import train_text_to_image_control_lora as T
+from controllora_amd import data, text
+
+REFERENCE_FLAGS = """pretrained_model_name_or_path revision dataset_name dataset_config_name train_data_dir image_column
+guide_column caption_column validation_prompt num_validation_images validation_epochs max_train_samples output_dir cache_dir
+seed resolution train_batch_size num_train_epochs max_train_steps gradient_accumulation_steps gradient_checkpointing
+learning_rate scale_lr lr_scheduler lr_warmup_steps use_8bit_adam allow_tf32 dataloader_num_workers adam_beta1 adam_beta2
+adam_weight_decay adam_epsilon max_grad_norm push_to_hub hub_token hub_model_id logging_dir mixed_precision report_to
+local_rank checkpointing_steps resume_from_checkpoint enable_xformers_memory_efficient_attention control_lora_config""".split()
+
+
+def test_all_reference_flags_are_accepted_with_reference_defaults():
+    assert len(REFERENCE_FLAGS) == 44
+    a = T.parse_args(["--pretrained_model_name_or_path", "x", "--dataset_name", "d", "--control_lora_config", "c.json"])
+    for f in REFERENCE_FLAGS:
+        assert hasattr(a, f), f
+    assert (a.resolution, a.train_batch_size, a.num_train_epochs, a.learning_rate, a.lr_scheduler, a.lr_warmup_steps) == \
+        (512, 16, 100, 1e-4, "constant", 500)
+    assert (a.adam_beta1, a.adam_beta2, a.adam_weight_decay, a.adam_epsilon, a.max_grad_norm) == (0.9, 0.999, 1e-2, 1e-8, 1.0)
+    assert (a.checkpointing_steps, a.output_dir, a.image_column, a.guide_column, a.caption_column) == \
+        (500, "sd-fill50k-model-control-lora", "image", "guide", "text")
+    with pytest.raises(ValueError):                      # reference :322-324
+        T.parse_args(["--pretrained_model_name_or_path", "x", "--control_lora_config", "c.json"])
+    with pytest.raises(SystemExit):                      # --control_lora_config is required (reference :315)
+        T.parse_args(["--pretrained_model_name_or_path", "x", "--dataset_name", "d"])
+
+
+def test_lr_schedules():
+    assert [data.lr_lambda("constant", 5, 100)(s) for s in (0, 50)] == [1.0, 1.0]
+    f = data.lr_lambda("constant_with_warmup", 10, 100)
+    assert f(0) == 0.0 and f(5) == 0.5 and f(10) == 1.0 and f(99) == 1.0
+    f = data.lr_lambda("linear", 10, 110)
+    assert f(5) == 0.5 and f(10) == 1.0 and abs(f(60) - 0.5) < 1e-12 and f(110) == 0.0
+    f = data.lr_lambda("cosine", 0, 100)
+    assert f(0) == 1.0 and abs(f(50) - 0.5) < 1e-12 and abs(f(100)) < 1e-12
+    f = data.lr_lambda("polynomial", 0, 100)
+    assert f(0) == 1.0 and abs(f(100) - 1e-7) < 1e-12 and f(1000) == 1e-7
+    assert data.lr_lambda("cosine_with_restarts", 0, 100)(100) == 0.0
+    with pytest.raises(ValueError):
+        data.lr_lambda("nope", 0, 1)
+
+
+def test_synthetic_fill50k_and_tokenizer():
+    tok = text.HashTokenizer()
+    ds = data.SyntheticFill50k(64, 8, seed=42, tokenizer=tok)
+    a, b = ds[3], ds[3]
+    assert torch.equal(a["pixel_values"], b["pixel_values"]) and a["caption"] == b["caption"]       # deterministic
+    assert a["pixel_values"].shape == (3, 64, 64) and float(a["pixel_values"].min()) >= -1 and float(a["pixel_values"].max()) <= 1
+    g = a["guide_values"]
+    assert set(g.unique().tolist()) == {-1.0, 1.0} and 0 < float((g > 0).float().mean()) < 0.2       # thin outline
+    ids = a["input_ids"]
+    assert ids.shape == (77,) and ids[0] == text.BOS and ids[-1] == text.EOS
+    batch = data.collate([ds[0], ds[1]])
+    assert batch["pixel_values"].shape == (2, 3, 64, 64) and batch["input_ids"].shape == (2, 77)
+
+
+def test_entry_point_refuses_to_run_without_a_gpu(tmp_path):
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError, match="MI355X"):
+        T.main(["--pretrained_model_name_or_path", "random:small", "--dataset_name", "synthetic:fill50k",
+                "--control_lora_config", "configs/fill50k.json", "--output_dir", str(tmp_path)])
+
+
+@pytest.mark.gpu
+def test_short_run_checkpoint_resume_and_artifacts(tmp_path):
+    from oracle import cases
+    cfg = tmp_path / "small.json"
+    cfg.write_text(json.dumps({k: (list(v) if isinstance(v, tuple) else v) for k, v in cases.SMALL_CLORA_V1.items()}))
+    out = tmp_path / "run"
+    common = ["--pretrained_model_name_or_path", "random:small", "--dataset_name", "synthetic:fill50k", "--control_lora_config", str(cfg),
+              "--output_dir", str(out), "--resolution", "64", "--train_batch_size", "2", "--max_train_samples", "16", "--seed", "3",
+              "--mixed_precision", "fp16", "--checkpointing_steps", "2", "--lr_scheduler", "constant_with_warmup", "--lr_warmup_steps", "2"]
+    assert T.main(common + ["--max_train_steps", "4"]) == 4
+    assert sorted(d for d in os.listdir(out) if d.startswith("checkpoint-")) == ["checkpoint-2", "checkpoint-4"]
+    for f in ("config.json", "diffusion_pytorch_model.bin", "diffusion_pytorch_model.safetensors"):
+        assert (out / f).exists(), f
+    assert (out / "checkpoint-4" / "trainer_state.safetensors").exists()
+    logs = [json.loads(l) for l in open(out / "logs" / "train_log.jsonl")]
+    assert logs[0]["step"] == 1 and all(l["step_loss"] == l["step_loss"] for l in logs)            # finite losses
+    # resume: continues at step 5 from checkpoint-4 and trains the adapters further (hipGraph and eager paths)
+    assert T.main(common + ["--max_train_steps", "6", "--resume_from_checkpoint", "latest", "--no_hipgraph",
+                            "--validation_prompt", "red circle with blue background", "--num_validation_images", "1"]) == 6
+    assert (out / "checkpoint-6").exists() and len(os.listdir(out / "validation")) == 1
+    from controllora_amd import models as M
+    m = M.ControlLoRA.from_pretrained(str(out))
+    ups = [p for n, p in m.named_parameters() if n.endswith("to_q_lora.up.weight")]
+    assert any(float(p.abs().max()) > 0 for p in ups)                                                # zero-init `up` has moved
