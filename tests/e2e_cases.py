@@ -89,7 +89,8 @@ def check_against_golden(case, dev, golden_dir, tol_pred=5e-3, tol_grad=2.5e-2):
 def check_trainer_features(dev, golden_dir, real_backward=True):
     """gradient accumulation (train...:174-178), LR-schedule multiplier and checkpoint/resume (train...:713-735)
     of the device-resident trainer: accumulated grads equal the single-batch golden grads, the optimizer only
-    runs on the last micro-batch, and a trainer restored from `state_dict` continues bit-identically."""
+    runs on the last micro-batch, and a trainer restored from `state_dict` continues identically
+    (bit-exact with synthetic gradients; to fp32 round-off with real backward passes, whose wgrad uses atomics)."""
     inp = cases.seeded_inputs()
     noisy = unet_ref.DDPMSchedule().add_noise(inp["latents"], inp["noise"], inp["timesteps"]).to(dev).to(f16)
     args = (noisy, inp["timesteps"].to(dev), inp["ehs"].to(dev).to(f16), inp["guide"].to(dev).to(f16), inp["noise"].to(dev))
@@ -134,4 +135,7 @@ def check_trainer_features(dev, golden_dir, real_backward=True):
     backward(b)
     b.optimizer_step()
     assert float(b.state[10]) == 1.0
-    assert torch.equal(a.flat.data, b.flat.data) and torch.equal(a.flat.exp_avg_sq, b.flat.exp_avg_sq)
+    if real_backward:      # the hint-encoder wgrad kernel combines its M-chunks with fp32 atomics: last-bit run-to-run noise
+        assert rel(a.flat.data, b.flat.data) < 1e-5 and rel(a.flat.exp_avg_sq, b.flat.exp_avg_sq) < 1e-3
+    else:
+        assert torch.equal(a.flat.data, b.flat.data) and torch.equal(a.flat.exp_avg_sq, b.flat.exp_avg_sq)
