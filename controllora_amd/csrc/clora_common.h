@@ -39,6 +39,19 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
                                      (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
 #define CLORA_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 #define CLORA_RAW_BARRIER() __builtin_amdgcn_s_barrier()
+// gfx950 LDS transpose read (ds_read_b64_tr_b16), semantics measured with tools/probes/tr16_probe.hip: every lane
+// passes the address of 4 contiguous fp16; within each 16-lane group lane i receives element (i & 3) of the words
+// of lanes (i >> 2) + 4j, j = 0..3.  Pointing lane l at row (l & 15) >> 2, columns (l & 3)*4.. of a row-major
+// [4][16] block gives lane i column (i & 15), rows 0..3: a row-major LDS tile feeds a k-strided MFMA operand without
+// a transposing write pass.
+typedef __fp16 clora_fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+__device__ __forceinline__ half4v clora_ds_read_tr16(const half_t* lptr) {
+    clora_fp16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) clora_fp16x4*)(lptr));
+    half4v r;
+    __builtin_memcpy(&r, &v, 8);
+    return r;
+}
+#define CLORA_DS_READ_TR16(lptr) clora_ds_read_tr16(lptr)
 #endif
 
 __device__ __forceinline__ floatx4 mfma16(half8 a, half8 b, floatx4 c) {

@@ -529,75 +529,140 @@ struct WgradArgs {
     clora_conv_t conv;
 };
 
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
-    constexpr int BT = 64, BMR = 32, LD = BMR + 8;
-    __shared__ __attribute__((aligned(16))) half_t smem[2 * BT * LD];
-    half_t* At = smem;             // [n][m]
-    half_t* Bt = smem + BT * LD;   // [kcol][m]
+// One block = 64(n) x 64(kcol) tile of dW over one chunk of GEMM rows m; the reduction index m is the MFMA k index.
+// Both operands are k-strided in memory (dY [m][n], gather(X) [m][kcol]), so they are staged ROW-MAJOR by LDS-DMA
+// (no staging registers, no transposing ds_write pass) as 16-column sub-tiles [64 m][16] and fetched with the gfx950
+// transpose read ds_read_b64_tr_b16: a 16-lane group reads a [4 m][16 col] block (4 rows x 32 B = 128 contiguous
+// bytes, conflict free) and every lane receives its column's 4 consecutive m -- two of them make one MFMA operand.
+// 3-stage ring of 64-row stages (16 KB each), counted vmcnt waits, one barrier per stage, as in gemm_dma_kernel.
+// The bias gradient rides along as an all-ones input column at kcol == K (fetched from a 16-byte "one page").
+__device__ __attribute__((aligned(16))) const unsigned short g_clora_one16[8] = {0x3C00u, 0, 0, 0, 0, 0, 0, 0};
+
+__global__ __launch_bounds__(256, 3) void conv_wgrad_kernel(WgradArgs p) {
+    constexpr int BMR = 64, NST = 3;
+    constexpr int SUB = BMR * 16;                 // halves per [64 m][16 col] sub-tile
+    constexpr int STAGE = 8 * SUB;                // 4 dY sub-tiles + 4 X sub-tiles
+    __shared__ __attribute__((aligned(16))) half_t smem[NST * STAGE];
     const int t = threadIdx.x;
     const int tile = blockIdx.x;
     const int tn = tile % p.tiles_n, tk = tile / p.tiles_n;
-    const int n0 = tn * BT, k0 = tk * BT;
+    const int n0 = tn * 64, k0 = tk * 64;
     const int mbeg = blockIdx.y * p.m_per_block;
     const int mend = (mbeg + p.m_per_block < p.M) ? mbeg + p.m_per_block : p.M;
+    const int nst = (mend - mbeg + BMR - 1) / BMR;
     const bool conv = p.conv.enabled != 0;
-
-    // loader: chunk (row mr = t/8, 8 consecutive columns cc = (t%8)*8) of both 32x64 tiles
-    const int mr = t >> 3, cc = (t & 7) * 8;
-    const int kcol = k0 + cc;
-    int tap = 0, ci = kcol, ky = 0, kx = 0;
-    if (conv) { tap = kcol / p.conv.Cin; ci = kcol - tap * p.conv.Cin; ky = tap / p.conv.ksize; kx = tap - ky * p.conv.ksize; }
-    const bool kcol_ok = kcol < p.K;
-    const bool bias_col = p.db != nullptr && kcol == p.K;   // K % 8 == 0: the ones column starts a chunk
-    const bool ncol_ok = (n0 + cc) < p.N;
+    const half_t* zero_page = reinterpret_cast<const half_t*>(g_clora_zero16);
+    const half_t* one_page = reinterpret_cast<const half_t*>(g_clora_one16);
 
     const int w = t >> 6, l = t & 63, g = l >> 4, li = l & 15;
-    const int wm = w >> 1, wn = w & 1;  // 2x2 waves, each 32(n) x 32(kcol)
+    // ---- loader: wave w fills, per stage, rows (w&1)*32 .. +32 of sub-tiles {w>>1, 2+(w>>1)} of dY and of X;
+    // lane -> (row l>>1, 8-column chunk l&1) so that the lane-linear DMA image is exactly [32 m][16 col]
+    const int lm = (w & 1) * 32 + (l >> 1);
+    const int c8 = (l & 1) * 8;
+    int ncol[2], kcol[2], ky[2], kx[2], ci[2];
+    bool n_ok[2], k_ok[2], k_one[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int sub = q * 2 + (w >> 1);
+        ncol[q] = n0 + sub * 16 + c8;
+        kcol[q] = k0 + sub * 16 + c8;
+        n_ok[q] = ncol[q] < p.N;
+        k_ok[q] = kcol[q] < p.K;
+        k_one[q] = p.db != nullptr && kcol[q] == p.K;          // K % 8 == 0: the ones column starts a chunk
+        ky[q] = 0; kx[q] = 0; ci[q] = kcol[q];
+        if (conv && k_ok[q]) {
+            const int tap = kcol[q] / p.conv.Cin;
+            ci[q] = kcol[q] - tap * p.conv.Cin;
+            ky[q] = tap / p.conv.ksize;
+            kx[q] = tap - ky[q] * p.conv.ksize;
+        }
+    }
+    int mrow = mbeg + lm;
+    auto issue_stage = [&](int buf) {
+        half_t* base = smem + buf * STAGE + (w & 1) * 512;     // second half of a sub-tile = rows 32..63 = +512 halves
+        const bool mok = mrow < mend;
+        size_t xrow = 0;
+        int ty0 = 0, tx0 = 0;
+        if (mok) {
+            if (!conv) {
+                xrow = (size_t)mrow * p.ldx;
+            } else {
+                const int hw = p.conv.Hout * p.conv.Wout;
+                const int b = mrow / hw, rem = mrow - b * hw;
+                const int yo = rem / p.conv.Wout, xo = rem - yo * p.conv.Wout;
+                xrow = (size_t)b * p.conv.Hin * p.conv.Win;
+                ty0 = yo * p.conv.mul + p.conv.off;
+                tx0 = xo * p.conv.mul + p.conv.off;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int sub = q * 2 + (w >> 1);
+            const half_t* src = (mok && n_ok[q]) ? p.dY + (size_t)mrow * p.ldy + ncol[q] : zero_page;
+            CLORA_GLDS16(src, base + sub * SUB);
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int sub = q * 2 + (w >> 1);
+            const half_t* src = zero_page;
+            if (mok && k_one[q]) src = one_page;
+            else if (mok && k_ok[q]) {
+                if (!conv) {
+                    src = p.X + xrow + kcol[q];
+                } else {
+                    const int ty = ty0 + ky[q] * p.conv.kmul, tx = tx0 + kx[q] * p.conv.kmul;
+                    bool ok = ty >= 0 && ty < p.conv.lim_h && tx >= 0 && tx < p.conv.lim_w;
+                    if (p.conv.need_even) ok = ok && (((ty | tx) & 1) == 0);
+                    if (ok) src = p.X + (xrow + (size_t)(ty >> p.conv.shift) * p.conv.Win + (tx >> p.conv.shift)) * p.conv.Cin + ci[q];
+                }
+            }
+            CLORA_GLDS16(src, base + (4 + sub) * SUB);
+        }
+        mrow += BMR;
+    };
+
+    const int wm = w >> 1, wn = w & 1;               // 2x2 waves, each 32(n) x 32(kcol)
+    // transpose-read address of this lane inside a sub-tile: row g*8 + (li>>2) (+4 for the second half), cols (l&3)*4
+    const int troff = (g * 8 + (li >> 2)) * 16 + (l & 3) * 4;
     floatx4 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = zero4f();
 
-    for (int mt = mbeg; mt < mend; mt += BMR) {
-        const int m = mt + mr;
-        half8 va = zero8(), vb = zero8();
-        if (m < mend) {
-            if (ncol_ok) va = ld8(p.dY + (size_t)m * p.ldy + n0 + cc);
-            if (bias_col) vb[0] = (half_t)1.0f;
-            if (kcol_ok) {
-                if (!conv) {
-                    vb = ld8(p.X + (size_t)m * p.ldx + kcol);
-                } else {
-                    const int hw = p.conv.Hout * p.conv.Wout;
-                    const int b = m / hw, rem = m - b * hw;
-                    const int yo = rem / p.conv.Wout, xo = rem - yo * p.conv.Wout;
-                    const int ty = yo * p.conv.mul + p.conv.off + ky * p.conv.kmul;
-                    const int tx = xo * p.conv.mul + p.conv.off + kx * p.conv.kmul;
-                    bool ok = ty >= 0 && ty < p.conv.lim_h && tx >= 0 && tx < p.conv.lim_w;
-                    if (p.conv.need_even) ok = ok && (((ty | tx) & 1) == 0);
-                    if (ok)
-                        vb = ld8(p.X + (((size_t)b * p.conv.Hin + (ty >> p.conv.shift)) * p.conv.Win + (tx >> p.conv.shift)) * p.conv.Cin + ci);
-                }
+#pragma unroll
+    for (int st = 0; st < NST - 1; ++st) issue_stage(st);
+    int rd = 0, wr = NST - 1;
+    for (int it = 0; it < nst; ++it) {
+        CLORA_WAIT_VMCNT((NST - 2) * 4);
+        CLORA_RAW_BARRIER();
+        issue_stage(wr);
+        wr = (wr + 1 == NST) ? 0 : wr + 1;
+        const half_t* Ys = smem + rd * STAGE;
+        const half_t* Xs = Ys + 4 * SUB;
+        rd = (rd + 1 == NST) ? 0 : rd + 1;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {                        // two MFMA k-steps of 32 rows
+            half8 af[2], bf[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const half_t* q = Ys + (wm * 2 + i) * SUB + ks * 512 + troff;
+                const half4v lo = CLORA_DS_READ_TR16(q), hi = CLORA_DS_READ_TR16(q + 64);
+                af[i] = half8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
             }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const half_t* q = Xs + (wn * 2 + j) * SUB + ks * 512 + troff;
+                const half4v lo = CLORA_DS_READ_TR16(q), hi = CLORA_DS_READ_TR16(q + 64);
+                bf[j] = half8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = mfma16(af[i], bf[j], acc[i][j]);
         }
-        __syncthreads();  // previous iteration's fragment reads are done
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            At[(cc + e) * LD + mr] = va[e];
-            Bt[(cc + e) * LD + mr] = vb[e];
-        }
-        __syncthreads();
-        half8 af[2], bf[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) af[i] = ld8(At + (wm * 32 + i * 16 + li) * LD + g * 8);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) bf[j] = ld8(Bt + (wn * 32 + j * 16 + li) * LD + g * 8);
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) acc[i][j] = mfma16(af[i], bf[j], acc[i][j]);
     }
+    CLORA_WAIT_VMCNT(0);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -737,7 +802,7 @@ extern "C" int clora_conv_wgrad_f16(const clora_half* dY, int ldy, const clora_h
     a.tiles_k = clora_cdiv(K + (db ? 8 : 0), 64);
     const int tiles = a.tiles_n * a.tiles_k;
     int chunks = clora_cdiv(2048, tiles);              // aim for ~2048 blocks
-    int mpb = clora_cdiv(clora_cdiv(M, chunks), 32) * 32;
+    int mpb = clora_cdiv(clora_cdiv(M, chunks), 64) * 64;
     if (mpb < 256) mpb = 256;
     a.m_per_block = mpb;
     hipLaunchKernelGGL(conv_wgrad_kernel, dim3(tiles, clora_cdiv(M, mpb)), dim3(256), 0, (hipStream_t)stream, a);

@@ -37,6 +37,7 @@ struct Wave {
     int arg[64], mode[64];
     hipemu_half8 a[64], b[64];
     hipemu_floatx4 c[64], d[64];
+    uint64_t tr[64];
     bool present[64];
 };
 
@@ -128,6 +129,29 @@ void glds16(const void* gptr, void* lptr) {
         for (int i = 0; i < 64; ++i)
             if (w->present[i]) memcpy(base + 16 * i, w->gsrc[i], 16);
     });
+}
+
+// ds_read_b64_tr_b16 as measured on gfx950 (tools/probes/tr16_probe.hip): every lane supplies the LDS address of a
+// word of 4 contiguous 16-bit elements; within each group of 16 lanes, lane i receives element (i & 3) of the words
+// supplied by lanes (i >> 2) + 4*j, j = 0..3.  With lane l pointing at row (l & 15) >> 2, columns (l & 3)*4.. of a
+// [4][16] block, lane i therefore gets column (i & 15), rows 0..3.
+uint64_t ds_read_tr16_b64(const void* lptr) {
+    Wave* w = cur->wave;
+    int l = cur->lane;
+    w->gsrc[l] = lptr;
+    collective([](Wave* w) {
+        for (int i = 0; i < 64; ++i) {
+            if (!w->present[i]) continue;
+            uint16_t out[4];
+            for (int b = 0; b < 4; ++b) {
+                const int src = (i & ~15) + ((i & 15) >> 2) + 4 * b;
+                if (!w->present[src]) { fprintf(stderr, "hipemu: transpose read with a missing lane\n"); abort(); }
+                out[b] = ((const uint16_t*)w->gsrc[src])[i & 3];
+            }
+            memcpy(&w->tr[i], out, 8);
+        }
+    });
+    return w->tr[l];
 }
 
 hipemu_floatx4 mfma_16x16x32_f16(hipemu_half8 a, hipemu_half8 b, hipemu_floatx4 c) {

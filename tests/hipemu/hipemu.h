@@ -88,6 +88,14 @@ namespace hipemu { void glds16(const void* gptr, void* lptr); }
 #define CLORA_GLDS16(gptr, lptr) hipemu::glds16((const void*)(gptr), (void*)(lptr))
 #define CLORA_WAIT_VMCNT(n) ((void)0)
 #define CLORA_RAW_BARRIER() hipemu::sync_threads()
+namespace hipemu { uint64_t ds_read_tr16_b64(const void* lptr); }
+typedef _Float16 hipemu_half4 __attribute__((ext_vector_type(4)));
+static inline hipemu_half4 hipemu_tr16(const void* p) {
+    uint64_t u = hipemu::ds_read_tr16_b64(p);
+    hipemu_half4 r; memcpy(&r, &u, 8);
+    return r;
+}
+#define CLORA_DS_READ_TR16(lptr) hipemu_tr16((const void*)(lptr))
 static inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }
 static inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v; return o; }
 static inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
