@@ -25,6 +25,10 @@ struct DownJobs {
     clora_lora_down_job_t j[CLORA_LORA_MAX_JOBS];
 };
 
+// KSPLIT (few rows: the 32x32 / 16x16 / 8x8 levels and the 77-token text context): one block = ONE 16-row group,
+// its four waves each take a quarter of K and the partial tiles are folded through LDS -- 4x more blocks and a 4x
+// shorter dependent load chain for what is a pure latency problem at those sizes.
+template <bool KSPLIT>
 __global__ __launch_bounds__(256) void lora_down_kernel(DownJobs jobs) {
     const clora_lora_down_job_t& p = jobs.j[blockIdx.y];
     const half_t* __restrict__ X = (const half_t*)p.X;
@@ -32,8 +36,14 @@ __global__ __launch_bounds__(256) void lora_down_kernel(DownJobs jobs) {
     float* __restrict__ T = p.T;
     const int ldx = p.ldx, ldd = p.ldd, ldt = p.ldt, toff = p.toff, M = p.M, K = p.K, R = p.R;
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63, g = l >> 4, li = l & 15;
-    const int m0 = (blockIdx.x * 4 + w) * 16;
-    if (m0 >= M) return;                                    // jobs of one launch may differ in M (wave-uniform exit)
+    const int m0 = KSPLIT ? blockIdx.x * 16 : (blockIdx.x * 4 + w) * 16;
+    if (m0 >= M) return;                                    // jobs of one launch may differ in M (block/wave-uniform exit)
+    int kbeg = 0, kend = K;
+    if (KSPLIT) {
+        const int per = ((K + 31) / 32 + 3) / 4 * 32;
+        kbeg = w * per;
+        kend = (kbeg + per < K) ? kbeg + per : K;
+    }
     const int m = m0 + li;
     const bool mok = m < M;
     const size_t xoff = (size_t)(mok ? (p.x_rows > 0 ? m % p.x_rows : m) : 0) * ldx;
@@ -43,14 +53,14 @@ __global__ __launch_bounds__(256) void lora_down_kernel(DownJobs jobs) {
     const float dscale = p.d_scale;
     floatx4 acc = zero4f();
     constexpr int G = 4;                                   // k-steps in flight
-    for (int k0 = 0; k0 < K; k0 += 32 * G) {
+    for (int k0 = kbeg; k0 < kend; k0 += 32 * G) {
         half8 a[G];
         floatx4 d0[G], d1[G];
 #pragma unroll
         for (int u = 0; u < G; ++u) {                      // issue every load of the group ...
             const int k = k0 + u * 32 + g * 8;
             a[u] = zero8(); d0[u] = zero4f(); d1[u] = zero4f();
-            if (k < K) {                                   // K % 8 == 0: a chunk is all-valid or all-out
+            if (k < kend) {                                // K % 8 == 0: a chunk is all-valid or all-out
                 if (mok) a[u] = ld8(X + xoff + k);
                 if (jok) {
                     if (d_kmajor) {
@@ -78,6 +88,18 @@ __global__ __launch_bounds__(256) void lora_down_kernel(DownJobs jobs) {
             }
             acc = mfma16(a[u], bh, acc);
             acc = mfma16(a[u], bl, acc);
+        }
+    }
+    if (KSPLIT) {                                           // fold the four K-quarters (fixed order) into wave 0
+        __shared__ floatx4 part[3][64];
+        if (w > 0) part[w - 1][l] = acc;
+        __syncthreads();
+        if (w > 0) return;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const floatx4 o = part[q][l];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] += o[r];
         }
     }
     // C layout: lane holds T[m0 + 4g + r][toff + li]
@@ -286,7 +308,10 @@ extern "C" int clora_lora_down_multi_f16(const clora_lora_down_job_t* jobs, int 
         dj.j[i] = j;
         if (j.M > maxM) maxM = j.M;
     }
-    hipLaunchKernelGGL(lora_down_kernel, dim3(clora_cdiv(maxM, 64), njobs), dim3(256), 0, (hipStream_t)stream, dj);
+    if (maxM <= 4096)
+        hipLaunchKernelGGL(lora_down_kernel<true>, dim3(clora_cdiv(maxM, 16), njobs), dim3(256), 0, (hipStream_t)stream, dj);
+    else
+        hipLaunchKernelGGL(lora_down_kernel<false>, dim3(clora_cdiv(maxM, 64), njobs), dim3(256), 0, (hipStream_t)stream, dj);
     return clora_check_launch();
 }
 
