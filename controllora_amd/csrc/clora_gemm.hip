@@ -524,6 +524,7 @@ struct WgradArgs {
     float* dW;
     float* db;   // optional bias gradient: handled as one extra all-ones input column k == K
     int ldy, ldx, M, N, K;
+    int oihw_ci;   // > 0: dW is the parameter itself, [N][oihw_ci][ks][ks] (OIHW); the padded input channels are dropped
     int m_per_block;
     int tiles_n, tiles_k;
     clora_conv_t conv;
@@ -671,9 +672,34 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_kernel(WgradArgs p) {
             for (int r = 0; r < 4; ++r) {
                 const int n = n0 + wm * 32 + i * 16 + 4 * g + r;
                 const int kk = k0 + wn * 32 + j * 16 + li;
-                if (n < p.N && kk < p.K) atomicAdd(p.dW + (size_t)n * p.K + kk, acc[i][j][r]);
-                else if (n < p.N && kk == p.K && p.db) atomicAdd(p.db + n, acc[i][j][r]);
+                if (n < p.N && kk < p.K) {
+                    if (p.oihw_ci > 0) {                       // (ky,kx,ci) gather order -> OIHW parameter layout
+                        const int cin = p.conv.enabled ? p.conv.Cin : p.K;
+                        const int tap = kk / cin, ci = kk - tap * cin;
+                        const int taps = p.conv.enabled ? p.conv.ksize * p.conv.ksize : 1;
+                        if (ci < p.oihw_ci) atomicAdd(p.dW + ((size_t)n * p.oihw_ci + ci) * taps + tap, acc[i][j][r]);
+                    } else {
+                        atomicAdd(p.dW + (size_t)n * p.K + kk, acc[i][j][r]);
+                    }
+                } else if (n < p.N && kk == p.K && p.db) atomicAdd(p.db + n, acc[i][j][r]);
             }
+}
+
+// fp32 master weight [Co][Ci][ks][ks] of a trainable conv -> the two fp16 GEMM operands of this step in one launch:
+// fwd [Co][ks*ks][Cip] (gather order ky,kx,ci; channels zero-padded to Cip) and, optionally, dgrad [Cip][ks*ks][Cop].
+__global__ __launch_bounds__(256) void conv_weight_pack_kernel(const float* w, int Co, int Ci, int taps, int Cip, int Cop,
+                                                               half_t* fwd, half_t* dgrad) {
+    const int nf = Co * taps * Cip, nd = dgrad ? Cip * taps * Cop : 0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < nf + nd; i += gridDim.x * 256) {
+        if (i < nf) {
+            const int ci = i % Cip, tap = (i / Cip) % taps, co = i / (Cip * taps);
+            fwd[i] = ci < Ci ? (half_t)w[((size_t)co * Ci + ci) * taps + tap] : (half_t)0.f;
+        } else {
+            const int q = i - nf;
+            const int co = q % Cop, tap = (q / Cop) % taps, ci = q / (Cop * taps);
+            dgrad[q] = (ci < Ci && co < Co) ? (half_t)w[((size_t)co * Ci + ci) * taps + tap] : (half_t)0.f;
+        }
+    }
 }
 
 template <int BM, int BN, int WM, int WN, int NST = 3>
@@ -784,12 +810,25 @@ extern "C" int clora_gemm_f16(const clora_half* A, int lda, const clora_half* B,
     return clora_gemm_f16_ex(A, lda, B, C, ldc, M, N, K, conv, epi, split_k, 0, workspace, workspace_bytes, stream);
 }
 
+extern "C" int clora_conv_weight_pack_f32(const float* w, int Co, int Ci, int ksize, int Cip, int Cop, clora_half* fwd,
+                                          clora_half* dgrad, void* stream) {
+    if (!w || !fwd || Co <= 0 || Ci <= 0 || (ksize != 1 && ksize != 3) || Cip < Ci || (Cip & 7) || (dgrad && (Cop < Co || (Cop & 7))))
+        return CLORA_ERR_ARG;
+    const int taps = ksize * ksize;
+    const long total = (long)Co * taps * Cip + (dgrad ? (long)Cip * taps * Cop : 0);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(conv_weight_pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, Co, Ci, taps, Cip, Cop,
+                       (half_t*)fwd, (half_t*)dgrad);
+    return clora_check_launch();
+}
+
 extern "C" int clora_conv_wgrad_f16(const clora_half* dY, int ldy, const clora_half* X, int ldx, float* dW, float* db,
-                                    int M, int N, int K, const clora_conv_t* conv, void* stream) {
-    if (!dY || !X || !dW || M <= 0 || N <= 0 || K <= 0 || (K & 7) || (N & 7) || (ldy & 7)) return CLORA_ERR_ARG;
+                                    int M, int N, int K, const clora_conv_t* conv, int oihw_ci, void* stream) {
+    if (!dY || !X || !dW || M <= 0 || N <= 0 || K <= 0 || (K & 7) || (N & 7) || (ldy & 7) || oihw_ci < 0) return CLORA_ERR_ARG;
     WgradArgs a;
     a.dY = (const half_t*)dY; a.X = (const half_t*)X; a.dW = dW; a.db = db;
-    a.ldy = ldy; a.ldx = ldx; a.M = M; a.N = N; a.K = K;
+    a.ldy = ldy; a.ldx = ldx; a.M = M; a.N = N; a.K = K; a.oihw_ci = oihw_ci;
     if (conv && conv->enabled) {
         a.conv = *conv;
         if ((conv->Cin & 7) || K != conv->ksize * conv->ksize * conv->Cin) return CLORA_ERR_ARG;

@@ -28,6 +28,7 @@ struct GnArgs {
     float* dgamma;
     float* dbeta;
     int B, HW, C, G, nchunk, rows_per_chunk;
+    int accumulate_params;   // dgamma / dbeta are += (they are the parameters' .grad) instead of written
     int nslab, CS;  // channel slabs (whole groups, multiple of 8 channels) = blockIdx.y: fills the chip at low resolution
     float eps;
     int fuse_silu;
@@ -292,8 +293,8 @@ __global__ __launch_bounds__(256) void gn_bwd_params_kernel(GnArgs p) {
     __syncthreads();
     if (part == 0 && c < p.C) {
         for (int q = 1; q < 8; ++q) { sa += red[(q * 32 + cl) * 2]; sb += red[(q * 32 + cl) * 2 + 1]; }
-        p.dbeta[c] = sa;
-        p.dgamma[c] = sb;
+        if (p.accumulate_params) { p.dbeta[c] += sa; p.dgamma[c] += sb; }
+        else { p.dbeta[c] = sa; p.dgamma[c] = sb; }
     }
 }
 
@@ -500,13 +501,13 @@ extern "C" int clora_groupnorm_fwd_f16(const clora_half* x, clora_half* y, const
 
 extern "C" int clora_groupnorm_bwd_f16(const clora_half* x, const clora_half* dy, clora_half* dx, const float* gamma,
                                        const float* beta, const float* stats, float* dgamma, float* dbeta, int B,
-                                       int HW, int C, int G, int fuse_silu, void* workspace, size_t workspace_bytes,
-                                       void* stream) {
+                                       int HW, int C, int G, int fuse_silu, int accumulate_params, void* workspace,
+                                       size_t workspace_bytes, void* stream) {
     if (!x || !dy || !dx || !gamma || !beta || !stats || ((dgamma == nullptr) != (dbeta == nullptr))) return CLORA_ERR_ARG;
     GnArgs a = GnArgs();
     a.x = (const half_t*)x; a.dy = (const half_t*)dy; a.y = (half_t*)dx; a.gamma = gamma; a.beta = beta;
     a.stats = const_cast<float*>(stats); a.dgamma = dgamma; a.dbeta = dbeta;
-    a.B = B; a.HW = HW; a.C = C; a.G = G; a.fuse_silu = fuse_silu;
+    a.B = B; a.HW = HW; a.C = C; a.G = G; a.fuse_silu = fuse_silu; a.accumulate_params = accumulate_params;
     int rc = gn_plan(a, workspace, workspace_bytes, true, dgamma != nullptr);
     if (rc != CLORA_OK) return rc;
     hipStream_t s = (hipStream_t)stream;

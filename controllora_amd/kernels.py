@@ -160,8 +160,26 @@ def conv_wgrad(dY: torch.Tensor, X: torch.Tensor, M: int, N: int, K: int, conv: 
     buf = torch.zeros(N * K + (N if with_bias else 0), dtype=f32, device=dY.device)
     dW, db = buf[:N * K].view(N, K), (buf[N * K:] if with_bias else None)
     _call("clora_conv_wgrad_f16", ptr(dY, f16), N, ptr(X, f16), ldx if ldx is not None else K, ptr(dW), ptr(db), M, N, K,
-          C.byref(conv) if conv is not None else None, flops=2.0 * M * N * K)
+          C.byref(conv) if conv is not None else None, 0, flops=2.0 * M * N * K)
     return (dW, db) if with_bias else dW
+
+
+def conv_wgrad_into(dY: torch.Tensor, X: torch.Tensor, M: int, N: int, K: int, conv: Optional[ConvDesc],
+                    weight_grad: torch.Tensor, bias_grad: Optional[torch.Tensor]):
+    """accumulate the weight (OIHW, fp32) and bias gradients of a trainable conv straight into the parameters' .grad"""
+    assert weight_grad.dtype == f32 and weight_grad.is_contiguous() and weight_grad.shape[0] == N
+    _call("clora_conv_wgrad_f16", ptr(dY, f16), N, ptr(X, f16), K, ptr(weight_grad), ptr(bias_grad, f32) if bias_grad is not None else None,
+          M, N, K, C.byref(conv) if conv is not None else None, weight_grad.shape[1], flops=2.0 * M * N * K)
+
+
+def conv_weight_pack(weight: torch.Tensor, Cip: int, need_dgrad: bool):
+    """fp32 [Co,Ci,k,k] -> fp16 forward operand [Co, k*k*Cip] and (optionally) dgrad operand [Cip, k*k*Cop], one launch"""
+    Co, Ci, k, _ = weight.shape
+    Cop = (Co + 7) // 8 * 8
+    fwd = torch.empty((Co, k * k * Cip), dtype=f16, device=weight.device)
+    dgrad = torch.empty((Cip, k * k * Cop), dtype=f16, device=weight.device) if need_dgrad else None
+    _call("clora_conv_weight_pack_f32", ptr(weight, f32), Co, Ci, k, Cip, Cop, ptr(fwd), ptr(dgrad) if dgrad is not None else None)
+    return fwd, dgrad
 
 
 # ------------------------------------------------------------------ attention
@@ -213,17 +231,22 @@ def groupnorm_fwd(x, gamma, beta, G, eps, silu):
     return y, stats
 
 
-def groupnorm_bwd(x, dy, gamma, beta, stats, G, silu, want_param_grads=False):
+def groupnorm_bwd(x, dy, gamma, beta, stats, G, silu, want_param_grads=False, grads_into=None):
+    """grads_into = (dgamma_buffer, dbeta_buffer): accumulate the affine gradients there instead of returning them"""
     B, HW, Cc = x.shape
     dx = torch.empty_like(x)
     dg = db = None
-    if want_param_grads:
+    if grads_into is not None:
+        dg, db = grads_into
+        want_param_grads = True
+    elif want_param_grads:
         dg = torch.empty(Cc, dtype=f32, device=x.device)
         db = torch.empty(Cc, dtype=f32, device=x.device)
     ws = _gn_ws(B, HW, Cc, G, x.device, True, want_param_grads)
     _call("clora_groupnorm_bwd_f16", ptr(x, f16), ptr(dy, f16), ptr(dx), ptr(gamma, f32), ptr(beta, f32), ptr(stats, f32),
-          ptr(dg), ptr(db), B, HW, Cc, G, int(silu), ptr(ws), ws.numel())
-    return dx, dg, db
+          ptr(dg, f32) if dg is not None else None, ptr(db, f32) if db is not None else None, B, HW, Cc, G, int(silu),
+          int(grads_into is not None), ptr(ws), ws.numel())
+    return (dx, None, None) if grads_into is not None else (dx, dg, db)
 
 
 def layernorm_fwd(x, gamma, beta, eps):

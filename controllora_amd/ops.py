@@ -124,15 +124,19 @@ class _GroupNormFn(torch.autograd.Function):
         y, stats = K.groupnorm_fwd(x, gamma, beta, G, eps, silu)
         ctx.save_for_backward(x, gamma, beta, stats)
         ctx.cfg = (G, silu)
+        ctx.affine = (gamma, beta)              # the Parameter objects (leaf tensors) when the norm is trainable
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, gamma, beta, stats = ctx.saved_tensors
         G, silu = ctx.cfg
-        train = ctx.needs_input_grad[1]
-        dx, dg, db = K.groupnorm_bwd(x, dy.contiguous(), gamma, beta, stats, G, silu, want_param_grads=train)
-        return dx, dg, db, None, None, None
+        into = None
+        if ctx.needs_input_grad[1]:             # trainable affine (hint encoder): accumulate into .grad, no AccumulateGrad add
+            g_, b_ = ctx.affine
+            into = (_grad_buffer(g_), _grad_buffer(b_))
+        dx, _, _ = K.groupnorm_bwd(x, dy.contiguous(), gamma, beta, stats, G, silu, grads_into=into)
+        return dx, None, None, None, None, None
 
 
 def group_norm(x, gamma, beta, G, eps, silu):
@@ -565,48 +569,46 @@ def lora_apply(base, x, down_weight, up_weight, scale):
 # ------------------------------------------------------------------------------------------------ trainable conv (hint encoder)
 class _TrainConvFn(torch.autograd.Function):
     """Conv2d of the trainable hint encoder (reference models.py:470, 529, 594-597, 684): fp32 master
-    weight, fp16 compute (what accelerate's autocast does around control_lora.forward)."""
+    weight, fp16 compute (what accelerate's autocast does around control_lora.forward).
+    One pack launch makes both fp16 GEMM operands of the step; the weight / bias gradients are accumulated by the
+    wgrad kernel straight into the parameters' .grad (OIHW), so autograd sees no gradient for them."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, B, H, W, stride, asym_pad, need_dx):
         Co, Ci, k, _ = weight.shape
         Cip = x.shape[1]
+        wp, wd = K.conv_weight_pack(weight.detach(), Cip, need_dx)
         if k == 3:
-            wp = torch.zeros((Co, 3, 3, Cip), dtype=f16, device=x.device)
-            wp[:, :, :, :Ci] = weight.detach().permute(0, 2, 3, 1)
             cd, Ho, Wo = K.conv_fwd_desc(H, W, Cip, 3, stride, 0 if asym_pad else 1, False, asym_pad)
-            y = K.gemm(x, wp.reshape(Co, 9 * Cip), B * Ho * Wo, Co, 9 * Cip, conv=cd, bias=bias.detach())
+            y = K.gemm(x, wp, B * Ho * Wo, Co, 9 * Cip, conv=cd, bias=bias.detach())
         else:
-            wp = weight.detach().reshape(Co, Ci).to(f16)
             cd, Ho, Wo = None, H, W
-            y = K.gemm(x, wp, B * H * W, Co, Ci, bias=bias.detach())
-        ctx.save_for_backward(x, weight)
+            y = K.gemm(x, wp, B * H * W, Co, Cip, bias=bias.detach())
+        ctx.save_for_backward(x)
+        ctx.params, ctx.wd = (weight, bias), wd
         ctx.cfg = (B, H, W, Ho, Wo, stride, asym_pad, need_dx, cd)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         dy = dy.contiguous()
-        x, weight = ctx.saved_tensors
+        (x,) = ctx.saved_tensors
+        weight, bias = ctx.params
         B, H, W, Ho, Wo, stride, asym_pad, need_dx, cd = ctx.cfg
         Co, Ci, k, _ = weight.shape
         Cip = x.shape[1]
+        Cop = (Co + 7) // 8 * 8
         M = B * Ho * Wo
         dx = None
-        if k == 3:
-            if need_dx:
-                wd = torch.zeros((Cip, 3, 3, Co), dtype=f16, device=x.device)
-                wd[:Ci] = weight.detach().permute(1, 2, 3, 0)
-                cdd = K.conv_dgrad_desc(Ho, Wo, Co, H, W, 3, stride, 1, asym_pad)
-                dx = K.gemm(dy, wd.reshape(Cip, 9 * Co), B * H * W, Cip, 9 * Co, conv=cdd)
-            dWp, db = K.conv_wgrad(dy, x, M, Co, 9 * Cip, cd, with_bias=True)
-            dW = dWp.reshape(Co, 3, 3, Cip)[:, :, :, :Ci].permute(0, 3, 1, 2).contiguous()
-        else:
-            if need_dx:
-                dx = K.gemm(dy, weight.detach().reshape(Co, Ci).t().contiguous().to(f16), M, Ci, Co)
-            dWp, db = K.conv_wgrad(dy, x, M, Co, Ci, None, with_bias=True)
-            dW = dWp.reshape(Co, Ci, 1, 1)
-        return dx, dW, db, None, None, None, None, None, None
+        if need_dx:
+            if k == 3:
+                cdd = K.conv_dgrad_desc(Ho, Wo, Cop, H, W, 3, stride, 1, asym_pad)
+                dx = K.gemm(dy, ctx.wd, B * H * W, Cip, 9 * Cop, conv=cdd)
+            else:
+                dx = K.gemm(dy, ctx.wd, M, Cip, Cop)
+        if weight.requires_grad:
+            K.conv_wgrad_into(dy, x, M, Co, k * k * Cip, cd, _grad_buffer(weight), _grad_buffer(bias) if bias.requires_grad else None)
+        return dx, None, None, None, None, None, None, None, None
 
 
 def train_conv(x, weight, bias, B, H, W, stride=1, asym_pad=False, need_dx=True):

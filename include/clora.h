@@ -85,7 +85,16 @@ int clora_gemm_f16_ex(const clora_half* A, int lda, const clora_half* B, clora_h
  * Weight gradient of the trainable hint-encoder convolutions (reference models.py:470,529,594-597,684:
  * autograd of F.conv2d).  `conv` as in the forward of that layer (NULL = 1x1 / linear). */
 int clora_conv_wgrad_f16(const clora_half* dY, int ldy, const clora_half* X, int ldx, float* dW, float* db,
-                         int M, int N, int K, const clora_conv_t* conv, void* stream);
+                         int M, int N, int K, const clora_conv_t* conv, int oihw_ci, void* stream);
+/* oihw_ci > 0: dW is the parameter's own gradient, laid out [N][oihw_ci][ks][ks] like the Conv2d weight
+ * (reference models.py:470); the kernel accumulates straight into it and drops the zero-padded input channels.
+ * oihw_ci == 0: dW is [N, K] in the gather's (ky, kx, ci) column order. */
+
+/* fp32 master weight [Co][Ci][ks][ks] -> fp16 GEMM operands of the step: fwd [Co][ks*ks][Cip] and (dgrad != NULL)
+ * dgrad [Cip][ks*ks][Cop], zero padded.  What autocast's per-step weight cast does around the hint encoder
+ * (reference train...:683), fused with the layout change the implicit GEMM wants. */
+int clora_conv_weight_pack_f32(const float* w, int Co, int Ci, int ksize, int Cip, int Cop, clora_half* fwd,
+                               clora_half* dgrad, void* stream);
 
 /* ---- attention core: O = softmax(Q K^T * scale) V per (batch, head), flash-style (never
  * materialises the [B*H, N, Nk] scores the reference builds at models.py:140-141, 270-271).
@@ -108,11 +117,13 @@ int clora_attn_bwd_f16(const clora_half* q, int ldq, const clora_half* k, int ld
 int clora_groupnorm_fwd_f16(const clora_half* x, clora_half* y, const float* gamma, const float* beta, float* stats,
                             int B, int HW, int C, int G, float eps, int fuse_silu, void* workspace,
                             size_t workspace_bytes, void* stream);
-/* dx (and, when dgamma != NULL, dgamma/dbeta are WRITTEN: deterministic two-stage reduction, no atomics). */
+/* dx (and, when dgamma != NULL, dgamma/dbeta: deterministic two-stage reduction, no atomics; WRITTEN, or added to
+ * when accumulate_params != 0 -- the trainable hint-encoder norms pass their .grad buffers). */
 size_t clora_groupnorm_workspace_bytes(int B, int HW, int C, int G, int backward, int param_grads);
 int clora_groupnorm_bwd_f16(const clora_half* x, const clora_half* dy, clora_half* dx, const float* gamma,
                             const float* beta, const float* stats, float* dgamma, float* dbeta, int B, int HW, int C,
-                            int G, int fuse_silu, void* workspace, size_t workspace_bytes, void* stream);
+                            int G, int fuse_silu, int accumulate_params, void* workspace, size_t workspace_bytes,
+                            void* stream);
 
 /* ---- row softmax  y[r,:] = softmax(scale * x[r,:])  (fp32 max/sum; cols % 8 == 0, cols <= 8192, scale > 0; in place
  * allowed).  Normalises the materialised scores of the VAE's single-head d=512 attention (upstream AutoencoderKL

@@ -76,6 +76,37 @@ def case_conv(dev, Bn, H, W, Ci, Co, stride=1, pad=1, ups=False, asym=False, see
     assert rel(dW, w32.grad.permute(0, 2, 3, 1).reshape(Co, 9 * Ci)) < 1e-4
     assert rel(db, dy.float().sum((0, 2, 3))) < 1e-4
     assert rel(K.colsum(dyn.reshape(M, Co), M, Co), dy.float().sum((0, 2, 3))) < 1e-4
+    if Ci % 8 == 0 and not ups:
+        # trainable-conv path: one pack launch for both fp16 operands, gradients accumulated into OIHW .grad buffers
+        wf, wdg = K.conv_weight_pack(w.float().contiguous(), Ci, True)
+        assert torch.equal(wf, wp) and torch.equal(wdg, wd)
+        gW = torch.ones((Co, Ci, 3, 3), dtype=f32, device=dev)
+        gb = torch.ones((Co,), dtype=f32, device=dev)
+        K.conv_wgrad_into(dyn, xn, M, Co, 9 * Ci, cd, gW, gb)
+        assert rel(gW - 1, w32.grad) < 1e-4 and rel(gb - 1, dy.float().sum((0, 2, 3))) < 1e-4
+
+
+def case_conv_padded_channels(dev, seed=9):
+    """3 -> padded 8 input channels (the hint encoder's conv_in): packing pads with zeros, the OIHW gradient drops them"""
+    g = torch.Generator().manual_seed(seed)
+    Bn, H, W, Ci, Cip, Co = 2, 8, 8, 3, 8, 16
+    x = rnd((Bn, Ci, H, W), dev, g)
+    w = rnd((Co, Ci, 3, 3), dev, g, dtype=f32)
+    xin = x.float().clone()
+    w32 = w.half().float().clone().requires_grad_(True)
+    y = F.conv2d(xin, w32, padding=1)
+    dy = rnd((Bn, Co, H, W), dev, g)
+    y.backward(dy.float())
+    xn = torch.zeros((Bn, H, W, Cip), dtype=f16, device=dev)
+    xn[..., :Ci] = x.permute(0, 2, 3, 1)
+    wf, _ = K.conv_weight_pack(w, Cip, False)
+    cd, Ho, Wo = K.conv_fwd_desc(H, W, Cip, 3, 1, 1)
+    M = Bn * Ho * Wo
+    out = K.gemm(xn.reshape(M, Cip), wf, M, Co, 9 * Cip, conv=cd)
+    assert rel(out, y.detach().permute(0, 2, 3, 1).reshape(M, Co)) < 1e-3
+    gW = torch.zeros((Co, Ci, 3, 3), dtype=f32, device=dev)
+    K.conv_wgrad_into(dy.permute(0, 2, 3, 1).contiguous().reshape(M, Co), xn.reshape(M, Cip), M, Co, 9 * Cip, cd, gW, None)
+    assert rel(gW, w32.grad) < 1e-4
 
 
 def _attn_ref(q, k, v, H, scale):

@@ -80,3 +80,7 @@ def test_loss_and_optimizer():
 @pytest.mark.parametrize("rows,cols", [(5, 64), (9, 1032)])
 def test_softmax_rows(rows, cols):
     KC.case_softmax_rows("cpu", rows, cols)
+
+
+def test_conv_padded_channels_pack_and_oihw_grad():
+    KC.case_conv_padded_channels("cpu")

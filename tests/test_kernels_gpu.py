@@ -91,3 +91,7 @@ def test_loss_and_optimizer():
 @pytest.mark.parametrize("rows,cols", [(4096, 4096), (1000, 72), (7, 8192)])
 def test_softmax_rows(rows, cols):
     KC.case_softmax_rows(DEV, rows, cols)
+
+
+def test_conv_padded_channels_pack_and_oihw_grad():
+    KC.case_conv_padded_channels(DEV)

@@ -4,12 +4,15 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from controllora_amd import kernels as K
 dev = torch.device("cuda", 0)
-def timeit(fn, iters=20, warm=3):
+def timeit(fn, iters=10, warm=2):
     for _ in range(warm): fn()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(iters): fn()
+    g.replay()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize(); e0.record()
-    for _ in range(iters): fn()
-    e1.record(); torch.cuda.synchronize()
+    torch.cuda.synchronize(); e0.record(); g.replay(); e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters * 1e3
 B = 4
 shapes = [(4096, 320), (4096, 640), (4096, 960), (1024, 320), (1024, 640), (1024, 960), (1024, 1280), (1024, 1920),
