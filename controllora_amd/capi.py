@@ -62,10 +62,10 @@ _PROTOS = {
     "clora_attn_fwd_f16": [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _F, _P],
     "clora_attn_bwd_f16": [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _F, _P, _Z, _P],
     "clora_groupnorm_fwd_f16": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P, _Z, _P],
-    "clora_groupnorm_bwd_f16": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _Z, _P],
+    "clora_groupnorm_bwd_f16": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _Z, _P],
     "clora_layernorm_fwd_f16": [_P, _P, _P, _P, _I, _I, _F, _P],
     "clora_softmax_rows_f16": [_P, _P, _I, _I, _I, _F, _P],
-    "clora_layernorm_bwd_f16": [_P, _P, _P, _P, _I, _I, _F, _P],
+    "clora_layernorm_bwd_f16": [_P, _P, _P, _P, _P, _I, _I, _F, _P],
     "clora_geglu_fwd_f16": [_P, _P, _I, _I, _P],
     "clora_geglu_bwd_f16": [_P, _P, _P, _I, _I, _P],
     "clora_lora_down_f16": [_P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P],

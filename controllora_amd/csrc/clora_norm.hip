@@ -19,6 +19,7 @@ constexpr int kLnCols = 4;    // LayerNorm: chunks per lane, C <= 2048
 struct GnArgs {
     const half_t* x;
     const half_t* dy;
+    const half_t* dres;   // bwd, optional: a second gradient of x (residual / shortcut branch) added into dx
     half_t* y;      // fwd: output, bwd: dx
     const float* gamma;
     const float* beta;
@@ -269,6 +270,11 @@ __global__ __launch_bounds__(256) void gn_bwd_apply2_kernel(GnArgs p) {
                     if (p.fuse_silu) d *= dsilu_f(xf * sc[j][e] + sh[j][e]);
                     o[e] = (half_t)(k1[j][e] * d + k2[j][e] * xf + k3[j][e]);
                 }
+                if (p.dres) {
+                    const half8 rr = ld8(p.dres + off + cc * 8);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = (half_t)((float)o[e] + (float)rr[e]);
+                }
                 st8(p.y + off + cc * 8, o);
             }
         }
@@ -302,6 +308,7 @@ __global__ __launch_bounds__(256) void gn_bwd_params_kernel(GnArgs p) {
 struct LnArgs {
     const half_t* x;
     const half_t* dy;
+    const half_t* dres;   // bwd, optional: the residual branch's gradient of x, added into dx
     half_t* y;
     const float* gamma;
     const float* beta;
@@ -375,6 +382,11 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs p) {
                 for (int e = 0; e < 8; ++e) {
                     const float xh = ((float)xv[j][e] - mean) * rstd;
                     o[e] = (half_t)(rstd * ((float)gv[j][e] * p.gamma[cc * 8 + e] - s1 - xh * s2));
+                }
+                if (p.dres) {
+                    const half8 rr = ld8(p.dres + off + cc * 8);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = (half_t)((float)o[e] + (float)rr[e]);
                 }
                 st8(p.y + off + cc * 8, o);
             }
@@ -499,13 +511,13 @@ extern "C" int clora_groupnorm_fwd_f16(const clora_half* x, clora_half* y, const
     return clora_check_launch();
 }
 
-extern "C" int clora_groupnorm_bwd_f16(const clora_half* x, const clora_half* dy, clora_half* dx, const float* gamma,
+extern "C" int clora_groupnorm_bwd_f16(const clora_half* x, const clora_half* dy, const clora_half* dres, clora_half* dx, const float* gamma,
                                        const float* beta, const float* stats, float* dgamma, float* dbeta, int B,
                                        int HW, int C, int G, int fuse_silu, int accumulate_params, void* workspace,
                                        size_t workspace_bytes, void* stream) {
     if (!x || !dy || !dx || !gamma || !beta || !stats || ((dgamma == nullptr) != (dbeta == nullptr))) return CLORA_ERR_ARG;
     GnArgs a = GnArgs();
-    a.x = (const half_t*)x; a.dy = (const half_t*)dy; a.y = (half_t*)dx; a.gamma = gamma; a.beta = beta;
+    a.x = (const half_t*)x; a.dy = (const half_t*)dy; a.dres = (const half_t*)dres; a.y = (half_t*)dx; a.gamma = gamma; a.beta = beta;
     a.stats = const_cast<float*>(stats); a.dgamma = dgamma; a.dbeta = dbeta;
     a.B = B; a.HW = HW; a.C = C; a.G = G; a.fuse_silu = fuse_silu; a.accumulate_params = accumulate_params;
     int rc = gn_plan(a, workspace, workspace_bytes, true, dgamma != nullptr);
@@ -526,11 +538,11 @@ extern "C" int clora_layernorm_fwd_f16(const clora_half* x, clora_half* y, const
     return clora_check_launch();
 }
 
-extern "C" int clora_layernorm_bwd_f16(const clora_half* x, const clora_half* dy, clora_half* dx, const float* gamma,
-                                       int M, int C, float eps, void* stream) {
+extern "C" int clora_layernorm_bwd_f16(const clora_half* x, const clora_half* dy, const clora_half* dres, clora_half* dx,
+                                       const float* gamma, int M, int C, float eps, void* stream) {
     if (!x || !dy || !dx || !gamma || M <= 0 || C <= 0 || (C & 7) || C / 8 > 64 * kLnCols) return CLORA_ERR_ARG;
     LnArgs a = LnArgs();
-    a.x = (const half_t*)x; a.dy = (const half_t*)dy; a.y = (half_t*)dx; a.gamma = gamma; a.M = M; a.C = C; a.eps = eps;
+    a.x = (const half_t*)x; a.dy = (const half_t*)dy; a.dres = (const half_t*)dres; a.y = (half_t*)dx; a.gamma = gamma; a.M = M; a.C = C; a.eps = eps;
     hipLaunchKernelGGL((layernorm_kernel<true>), dim3(clora_cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, a);
     return clora_check_launch();
 }

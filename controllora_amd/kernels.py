@@ -231,8 +231,9 @@ def groupnorm_fwd(x, gamma, beta, G, eps, silu):
     return y, stats
 
 
-def groupnorm_bwd(x, dy, gamma, beta, stats, G, silu, want_param_grads=False, grads_into=None):
-    """grads_into = (dgamma_buffer, dbeta_buffer): accumulate the affine gradients there instead of returning them"""
+def groupnorm_bwd(x, dy, gamma, beta, stats, G, silu, want_param_grads=False, grads_into=None, dres=None):
+    """grads_into = (dgamma_buffer, dbeta_buffer): accumulate the affine gradients there instead of returning them;
+    dres: gradient of x from the branch that bypasses the norm (added into dx by the kernel)"""
     B, HW, Cc = x.shape
     dx = torch.empty_like(x)
     dg = db = None
@@ -243,7 +244,9 @@ def groupnorm_bwd(x, dy, gamma, beta, stats, G, silu, want_param_grads=False, gr
         dg = torch.empty(Cc, dtype=f32, device=x.device)
         db = torch.empty(Cc, dtype=f32, device=x.device)
     ws = _gn_ws(B, HW, Cc, G, x.device, True, want_param_grads)
-    _call("clora_groupnorm_bwd_f16", ptr(x, f16), ptr(dy, f16), ptr(dx), ptr(gamma, f32), ptr(beta, f32), ptr(stats, f32),
+    assert dres is None or (dres.shape == x.shape and dres.is_contiguous())
+    _call("clora_groupnorm_bwd_f16", ptr(x, f16), ptr(dy, f16), ptr(dres, f16) if dres is not None else None, ptr(dx),
+          ptr(gamma, f32), ptr(beta, f32), ptr(stats, f32),
           ptr(dg, f32) if dg is not None else None, ptr(db, f32) if db is not None else None, B, HW, Cc, G, int(silu),
           int(grads_into is not None), ptr(ws), ws.numel())
     return (dx, None, None) if grads_into is not None else (dx, dg, db)
@@ -256,10 +259,12 @@ def layernorm_fwd(x, gamma, beta, eps):
     return y
 
 
-def layernorm_bwd(x, dy, gamma, eps):
+def layernorm_bwd(x, dy, gamma, eps, dres=None):
+    """dres: gradient of x from the branch that bypasses the norm (added into dx by the kernel)"""
     x2 = _c2(x)
     dx = torch.empty_like(x)
-    _call("clora_layernorm_bwd_f16", ptr(x2, f16), ptr(_c2(dy), f16), ptr(dx), ptr(gamma, f32), x2.shape[0], x2.shape[1], float(eps))
+    _call("clora_layernorm_bwd_f16", ptr(x2, f16), ptr(_c2(dy), f16), ptr(_c2(dres), f16) if dres is not None else None, ptr(dx),
+          ptr(gamma, f32), x2.shape[0], x2.shape[1], float(eps))
     return dx
 
 

@@ -119,46 +119,65 @@ def frozen_conv3x3(x, pack: ConvPack, B, H, W, residual=None, rowadd=None):
 
 # ------------------------------------------------------------------------------------------------ norms / activations
 class _GroupNormFn(torch.autograd.Function):
+    """fork=True additionally returns x itself (an alias): callers route the branch that bypasses the norm (residual /
+    shortcut) through it, so x has this ONE consumer in the autograd graph and the two gradients are summed inside
+    the backward kernel instead of by a separate autograd add."""
+
     @staticmethod
-    def forward(ctx, x, gamma, beta, G, eps, silu):
+    def forward(ctx, x, gamma, beta, G, eps, silu, fork):
         y, stats = K.groupnorm_fwd(x, gamma, beta, G, eps, silu)
         ctx.save_for_backward(x, gamma, beta, stats)
         ctx.cfg = (G, silu)
         ctx.affine = (gamma, beta)              # the Parameter objects (leaf tensors) when the norm is trainable
-        return y
+        return (y, x) if fork else y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dres=None):
         x, gamma, beta, stats = ctx.saved_tensors
         G, silu = ctx.cfg
         into = None
         if ctx.needs_input_grad[1]:             # trainable affine (hint encoder): accumulate into .grad, no AccumulateGrad add
             g_, b_ = ctx.affine
             into = (_grad_buffer(g_), _grad_buffer(b_))
-        dx, _, _ = K.groupnorm_bwd(x, dy.contiguous(), gamma, beta, stats, G, silu, grads_into=into)
-        return dx, None, None, None, None, None
+        dx, _, _ = K.groupnorm_bwd(x, dy.contiguous(), gamma, beta, stats, G, silu, grads_into=into,
+                                   dres=dres.contiguous().view_as(x) if dres is not None else None)
+        return dx, None, None, None, None, None, None
 
 
 def group_norm(x, gamma, beta, G, eps, silu):
     """x [B, HW, C] fp16, gamma/beta fp32 (frozen buffers or trainable parameters)."""
-    return _GroupNormFn.apply(x, gamma, beta, G, eps, silu)
+    return _GroupNormFn.apply(x, gamma, beta, G, eps, silu, False)
+
+
+def group_norm_fork(x, gamma, beta, G, eps, silu):
+    """-> (GroupNorm(x), x): use the second output for the residual / shortcut branch (see _GroupNormFn)."""
+    return _GroupNormFn.apply(x, gamma, beta, G, eps, silu, True)
 
 
 class _LayerNormFn(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x, gamma, beta, eps):
-        ctx.save_for_backward(x, gamma)
-        ctx.eps = eps
-        return K.layernorm_fwd(x, gamma, beta, eps)
+    """fork=True: also returns x (alias) for the residual branch, whose gradient the backward kernel adds into dx
+    (x + f(LN(x)) is every BasicTransformerBlock sub-layer; see _GroupNormFn)."""
 
     @staticmethod
-    def backward(ctx, dy):
+    def forward(ctx, x, gamma, beta, eps, fork):
+        ctx.save_for_backward(x, gamma)
+        ctx.eps = eps
+        y = K.layernorm_fwd(x, gamma, beta, eps)
+        return (y, x) if fork else y
+
+    @staticmethod
+    def backward(ctx, dy, dres=None):
         x, gamma = ctx.saved_tensors
-        return K.layernorm_bwd(x, dy.contiguous(), gamma, ctx.eps), None, None, None
+        dx = K.layernorm_bwd(x, dy.contiguous(), gamma, ctx.eps, dres=dres.contiguous().view_as(x) if dres is not None else None)
+        return dx, None, None, None, None
 
 
 def layer_norm(x, gamma, beta, eps=1e-5):
-    return _LayerNormFn.apply(x, gamma, beta, eps)
+    return _LayerNormFn.apply(x, gamma, beta, eps, False)
+
+
+def layer_norm_fork(x, gamma, beta, eps=1e-5):
+    return _LayerNormFn.apply(x, gamma, beta, eps, True)
 
 
 class _GegluFn(torch.autograd.Function):

@@ -116,11 +116,20 @@ class GroupNorm(_Norm):
         g, b = self.pack()
         return ops.group_norm(x, g, b, self.groups, self.eps, silu)
 
+    def fork(self, x, silu):
+        """-> (norm(x), x'): route the branch that bypasses the norm through x' (gradient add fused into the backward)"""
+        g, b = self.pack()
+        return ops.group_norm_fork(x, g, b, self.groups, self.eps, silu)
+
 
 class LayerNorm(_Norm):
     def forward(self, x):
         g, b = self.pack()
         return ops.layer_norm(x, g, b, 1e-5)
+
+    def fork(self, x):
+        g, b = self.pack()
+        return ops.layer_norm_fork(x, g, b, 1e-5)
 
 
 # ------------------------------------------------------------------------------------------------ attention
@@ -224,10 +233,13 @@ class BasicTransformerBlock(nn.Module):
 
     def forward(self, x, ehs, kw):
         B, N, C_ = x.shape
-        x = self.attn1(self.norm1(x), residual=x, **kw)
-        x = self.attn2(self.norm2(x), encoder_hidden_states=ehs, residual=x, **kw)
-        x2 = x.reshape(B * N, C_)
-        return self.ff(self.norm3(x).reshape(B * N, C_), x2).reshape(B, N, C_)
+        grad = torch.is_grad_enabled() and x.requires_grad
+        n, xr = self.norm1.fork(x) if grad else (self.norm1(x), x)
+        x = self.attn1(n, residual=xr, **kw)
+        n, xr = self.norm2.fork(x) if grad else (self.norm2(x), x)
+        x = self.attn2(n, encoder_hidden_states=ehs, residual=xr, **kw)
+        n, xr = self.norm3.fork(x) if grad else (self.norm3(x), x)
+        return self.ff(n.reshape(B * N, C_), xr.reshape(B * N, C_)).reshape(B, N, C_)
 
 
 class Transformer2DModel(nn.Module):
@@ -241,10 +253,11 @@ class Transformer2DModel(nn.Module):
 
     def forward(self, x, ehs, kw):
         B, N, C_ = x.shape
-        h = self.proj_in(self.norm(x, False).reshape(B * N, C_)).reshape(B, N, -1)
+        n, xr = self.norm.fork(x, False) if (torch.is_grad_enabled() and x.requires_grad) else (self.norm(x, False), x)
+        h = self.proj_in(n.reshape(B * N, C_)).reshape(B, N, -1)
         for blk in self.transformer_blocks:
             h = blk(h, ehs, kw)
-        return self.proj_out(h.reshape(B * N, -1), x.reshape(B * N, C_)).reshape(B, N, C_)
+        return self.proj_out(h.reshape(B * N, -1), xr.reshape(B * N, C_)).reshape(B, N, C_)
 
 
 # ------------------------------------------------------------------------------------------------ resnet / samplers
@@ -262,10 +275,11 @@ class ResnetBlock2D(nn.Module):
         B, N, Cin = x.shape
         with torch.no_grad():  # the time embedding has no trainable ancestor
             t = self.time_emb_proj(temb_act)
-        h = self.conv1(self.norm1(x, True).reshape(B * N, Cin), B, H, W, rowadd=t)
+        n, xr = self.norm1.fork(x, True) if (torch.is_grad_enabled() and x.requires_grad) else (self.norm1(x, True), x)
+        h = self.conv1(n.reshape(B * N, Cin), B, H, W, rowadd=t)
         Cout = h.shape[1]
         h = self.norm2(h.reshape(B, N, Cout), True).reshape(B * N, Cout)
-        x2 = x.reshape(B * N, Cin)
+        x2 = xr.reshape(B * N, Cin)
         sc = self.conv_shortcut(x2) if self.conv_shortcut is not None else x2
         return self.conv2(h, B, H, W, residual=sc).reshape(B, N, Cout)
 

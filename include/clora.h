@@ -120,7 +120,7 @@ int clora_groupnorm_fwd_f16(const clora_half* x, clora_half* y, const float* gam
 /* dx (and, when dgamma != NULL, dgamma/dbeta: deterministic two-stage reduction, no atomics; WRITTEN, or added to
  * when accumulate_params != 0 -- the trainable hint-encoder norms pass their .grad buffers). */
 size_t clora_groupnorm_workspace_bytes(int B, int HW, int C, int G, int backward, int param_grads);
-int clora_groupnorm_bwd_f16(const clora_half* x, const clora_half* dy, clora_half* dx, const float* gamma,
+int clora_groupnorm_bwd_f16(const clora_half* x, const clora_half* dy, const clora_half* dres, clora_half* dx, const float* gamma,
                             const float* beta, const float* stats, float* dgamma, float* dbeta, int B, int HW, int C,
                             int G, int fuse_silu, int accumulate_params, void* workspace, size_t workspace_bytes,
                             void* stream);
@@ -133,8 +133,10 @@ int clora_softmax_rows_f16(const clora_half* x, clora_half* y, int rows, int col
 /* ---- LayerNorm over the last dim (upstream BasicTransformerBlock.norm1/2/3, eps 1e-5). */
 int clora_layernorm_fwd_f16(const clora_half* x, clora_half* y, const float* gamma, const float* beta, int M, int C,
                             float eps, void* stream);
-int clora_layernorm_bwd_f16(const clora_half* x, const clora_half* dy, clora_half* dx, const float* gamma, int M, int C,
-                            float eps, void* stream);
+int clora_layernorm_bwd_f16(const clora_half* x, const clora_half* dy, const clora_half* dres, clora_half* dx,
+                            const float* gamma, int M, int C, float eps, void* stream);
+/* dres (both norm backwards, may be NULL): a second gradient of x -- the residual / shortcut branch that forked off
+ * before the norm (x + attn(LN(x)), ResnetBlock2D's shortcut) -- added into dx, so autograd never issues the add. */
 
 /* ---- GEGLU: y[m, j] = h[m, j] * gelu_erf(h[m, F + j])  (upstream FeedForward). */
 int clora_geglu_fwd_f16(const clora_half* h, clora_half* y, int M, int F, void* stream);

@@ -159,6 +159,13 @@ def case_groupnorm(dev, B, HW, C, G, silu, eps=1e-5, seed=4, train_params=False)
     assert rel(dx, x32.grad) < 2e-3
     if train_params:
         assert rel(dg, g32.grad) < 1e-3 and rel(db, b32.grad) < 1e-3
+    # fused second gradient (residual branch) and in-place accumulation of the affine gradients
+    dres = rnd((B, HW, C), dev, g)
+    acc_g, acc_b = torch.ones(C, dtype=f32, device=dev), torch.ones(C, dtype=f32, device=dev)
+    dx2, _, _ = K.groupnorm_bwd(x, dy, gamma, beta, stats, G, silu, grads_into=(acc_g, acc_b) if train_params else None, dres=dres)
+    assert rel(dx2, x32.grad + dres.float()) < 2e-3
+    if train_params:
+        assert rel(acc_g - 1, g32.grad) < 1e-3 and rel(acc_b - 1, b32.grad) < 1e-3
 
 
 def case_softmax_rows(dev, rows, cols, scale=0.37, seed=6):
@@ -181,6 +188,8 @@ def case_layernorm(dev, M, C, seed=5):
     dy = rnd((M, C), dev, g)
     y.backward(dy.float())
     assert rel(K.layernorm_bwd(x, dy, gamma, 1e-5), x32.grad) < 1e-3
+    dres = rnd((M, C), dev, g)                      # fused residual-branch gradient
+    assert rel(K.layernorm_bwd(x, dy, gamma, 1e-5, dres=dres), x32.grad + dres.float()) < 1e-3
 
 
 def case_geglu(dev, M, Fdim, seed=6):
