@@ -42,14 +42,14 @@ class LoraDownJob(C.Structure):
     """mirror of clora_lora_down_job_t"""
     _fields_ = [("X", C.c_void_p), ("ldx", C.c_int), ("D", C.c_void_p), ("ldd", C.c_int), ("T", C.c_void_p), ("ldt", C.c_int),
                 ("toff", C.c_int), ("M", C.c_int), ("K", C.c_int), ("R", C.c_int), ("accumulate", C.c_int), ("x_rows", C.c_int),
-                ("d_kmajor", C.c_int), ("d_scale", C.c_float)]
+                ("d_kmajor", C.c_int), ("d_scale", C.c_float), ("X2", C.c_void_p), ("ldx2", C.c_int)]
 
 
 class LoraWgradJob(C.Structure):
     """mirror of clora_lora_wgrad_job_t"""
     _fields_ = [("A", C.c_void_p), ("lda", C.c_int), ("T", C.c_void_p), ("ldt", C.c_int), ("toff", C.c_int), ("G", C.c_void_p),
                 ("gs_n", C.c_int), ("gs_j", C.c_int), ("M", C.c_int), ("N", C.c_int), ("R", C.c_int), ("scale", C.c_float),
-                ("a_rows", C.c_int)]
+                ("a_rows", C.c_int), ("A2", C.c_void_p), ("lda2", C.c_int)]
 
 
 LORA_MAX_JOBS = 8

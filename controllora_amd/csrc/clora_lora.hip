@@ -31,7 +31,7 @@ struct DownJobs {
 template <bool KSPLIT>
 __global__ __launch_bounds__(256) void lora_down_kernel(DownJobs jobs) {
     const clora_lora_down_job_t& p = jobs.j[blockIdx.y];
-    const half_t* __restrict__ X = (const half_t*)p.X;
+    const half_t* X = (const half_t*)p.X;
     const float* __restrict__ D = p.D;
     float* __restrict__ T = p.T;
     const int ldx = p.ldx, ldd = p.ldd, ldt = p.ldt, toff = p.toff, M = p.M, K = p.K, R = p.R;
@@ -46,13 +46,16 @@ __global__ __launch_bounds__(256) void lora_down_kernel(DownJobs jobs) {
     }
     const int m = m0 + li;
     const bool mok = m < M;
-    const size_t xoff = (size_t)(mok ? (p.x_rows > 0 ? m % p.x_rows : m) : 0) * ldx;
+    size_t xoff = (size_t)(mok ? (p.x_rows > 0 ? m % p.x_rows : m) : 0) * ldx;
     const bool jok = li < R;
     const int jj = jok ? li : 0;
     const int d_kmajor = p.d_kmajor;
     const float dscale = p.d_scale;
     floatx4 acc = zero4f();
     constexpr int G = 4;                                   // k-steps in flight
+    const int npass = p.X2 ? 2 : 1;                        // second input: (X + X2) . D^T by linearity, same accumulator
+    for (int pass = 0; pass < npass; ++pass) {
+    if (pass == 1) { X = (const half_t*)p.X2; xoff = (size_t)(mok ? m : 0) * p.ldx2; }
     for (int k0 = kbeg; k0 < kend; k0 += 32 * G) {
         half8 a[G];
         floatx4 d0[G], d1[G];
@@ -89,6 +92,7 @@ __global__ __launch_bounds__(256) void lora_down_kernel(DownJobs jobs) {
             acc = mfma16(a[u], bh, acc);
             acc = mfma16(a[u], bl, acc);
         }
+    }
     }
     if (KSPLIT) {                                           // fold the four K-quarters (fixed order) into wave 0
         __shared__ floatx4 part[3][64];
@@ -218,6 +222,11 @@ __global__ __launch_bounds__(256) void lora_wgrad_kernel(WgradJobs jobs) {
             if (nok && m < m_end) {
                 const int ar = a_rows > 0 ? m % a_rows : m;
                 a[u] = ld8(A + (size_t)ar * lda + n);
+                if (p.A2) {                                  // adapter input = fp16(A + A2), as the reference forms it
+                    const half8 a2 = ld8((const half_t*)p.A2 + (size_t)m * p.lda2 + n);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) a[u][e] = (half_t)((float)a[u][e] + (float)a2[e]);
+                }
             }
         }
 #pragma unroll
@@ -304,6 +313,7 @@ extern "C" int clora_lora_down_multi_f16(const clora_lora_down_job_t* jobs, int 
     for (int i = 0; i < njobs; ++i) {
         const clora_lora_down_job_t& j = jobs[i];
         if (!j.X || !j.D || !j.T || j.M <= 0 || j.K <= 0 || j.R <= 0 || j.R > 16 || (j.K & 7) || (j.ldx & 7)) return CLORA_ERR_ARG;
+        if (j.X2 && (j.ldx2 & 7)) return CLORA_ERR_ARG;
         if (!j.d_kmajor && ((j.ldd & 3) || ((uintptr_t)j.D & 15))) return CLORA_ERR_ARG;
         dj.j[i] = j;
         if (j.M > maxM) maxM = j.M;
@@ -323,7 +333,7 @@ extern "C" int clora_lora_down_f16(const clora_half* X, int ldx, const float* D,
         clora_lora_down_job_t j;
         j.X = X; j.ldx = ldx; j.D = d_kmajor ? D + r0 : (D ? D + (size_t)r0 * ldd : D); j.ldd = ldd; j.T = T; j.ldt = ldt;
         j.toff = toff + r0; j.M = M; j.K = K; j.R = (R - r0 < 16) ? R - r0 : 16; j.accumulate = accumulate;
-        j.x_rows = x_rows; j.d_kmajor = d_kmajor; j.d_scale = d_scale;
+        j.x_rows = x_rows; j.d_kmajor = d_kmajor; j.d_scale = d_scale; j.X2 = nullptr; j.ldx2 = 0;
         const int rc = clora_lora_down_multi_f16(&j, 1, stream);
         if (rc != CLORA_OK) return rc;
     }
@@ -395,7 +405,7 @@ extern "C" int clora_lora_wgrad_f16(const clora_half* A, int lda, const float* T
     for (int r0 = 0; r0 < R; r0 += 16) {
         clora_lora_wgrad_job_t j;
         j.A = A; j.lda = lda; j.T = T; j.ldt = ldt; j.toff = toff + r0; j.G = G + (size_t)r0 * gs_j; j.gs_n = gs_n; j.gs_j = gs_j;
-        j.M = M; j.N = N; j.R = (R - r0 < 16) ? R - r0 : 16; j.scale = scale; j.a_rows = a_rows;
+        j.M = M; j.N = N; j.R = (R - r0 < 16) ? R - r0 : 16; j.scale = scale; j.a_rows = a_rows; j.A2 = nullptr; j.lda2 = 0;
         const int rc = clora_lora_wgrad_multi_f16(&j, 1, workspace, workspace_bytes, stream);
         if (rc != CLORA_OK) return rc;
     }

@@ -295,12 +295,13 @@ def lora_down(X, D, T, toff, M, K, accumulate=False, x_rows=0, ldx=None, kmajor=
     return T
 
 
-def down_job(X, D, T, toff, M, K, accumulate=False, x_rows=0, ldx=None, kmajor=False, R=None, d_scale=1.0):
-    """one problem of lora_down_multi (same arguments as lora_down; rank <= 16)"""
+def down_job(X, D, T, toff, M, K, accumulate=False, x_rows=0, ldx=None, kmajor=False, R=None, d_scale=1.0, X2=None):
+    """one problem of lora_down_multi (same arguments as lora_down; rank <= 16); X2: second input, T = (X + X2) . D^T"""
     assert D.dtype == f32 and D.stride(1) == 1 and T.dtype == f32 and T.stride(1) == 1
     rank = R if R is not None else (D.shape[1] if kmajor else D.shape[0])
     return capi.LoraDownJob(ptr(X, f16), ldx if ldx is not None else X.stride(0), ptr(D), D.stride(0), ptr(T), T.stride(0), toff,
-                            M, K, rank, int(accumulate), x_rows, int(kmajor), float(d_scale))
+                            M, K, rank, int(accumulate), x_rows, int(kmajor), float(d_scale),
+                            ptr(X2, f16) if X2 is not None else None, X2.stride(0) if X2 is not None else 0)
 
 
 def lora_down_multi(jobs):
@@ -311,10 +312,12 @@ def lora_down_multi(jobs):
         _call("clora_lora_down_multi_f16", arr, len(chunk), nbytes=sum(2.0 * j.M * j.K for j in chunk))
 
 
-def wgrad_job(A, T, toff, G, gs_n, gs_j, M, N, R, scale=1.0, a_rows=0, lda=None):
+def wgrad_job(A, T, toff, G, gs_n, gs_j, M, N, R, scale=1.0, a_rows=0, lda=None, A2=None):
+    """A2: the reduction runs over fp16(A + A2) -- an adapter whose input is a sum of two tensors"""
     assert G.dtype == f32 and T.dtype == f32 and R <= 16
     return capi.LoraWgradJob(ptr(A, f16), lda if lda is not None else A.stride(0), ptr(T), T.stride(0), toff, ptr(G), gs_n, gs_j,
-                             M, N, R, float(scale), a_rows)
+                             M, N, R, float(scale), a_rows, ptr(A2, f16) if A2 is not None else None,
+                             A2.stride(0) if A2 is not None else 0)
 
 
 def lora_wgrad_multi(jobs, device):

@@ -230,8 +230,15 @@ class ControlLoRACrossAttnProcessor(_ControlMixin, LoRACrossAttnProcessor):
         h2 = _flat2(hidden_states)
         e2 = _flat2(encoder_hidden_states) if attn.is_cross else None
         Nk = encoder_hidden_states.shape[1] if attn.is_cross else N
-        hc = self.process_control_states(hidden_states, scale)      # hidden + control term feeds ONLY the q adapter
-        out = self._attend(attn, h2, hc, e2, B, N, Nk, scale, lambda a: a, residual, own_out_always=True)  # quirk C2
+        if self.concat_hidden:
+            q_in = self.process_control_states(hidden_states, scale)     # h + to_control(cat(h, ctrl)): depends on h
+        else:
+            # hidden + control term feeds ONLY the q adapter (models.py:237-238); Lq(h + c) = Lq(h) + Lq(c), so the sum is
+            # never formed: h keeps one consumer (no autograd gradient add) and the q/k/v downs share their read of h
+            ctrl = self._control_tokens(hidden_states)
+            c = ops.control_term(_flat2(ctrl), self.to_control.down.weight, self.to_control.up.weight, scale, B * N)
+            q_in = (h2, c)
+        out = self._attend(attn, h2, q_in, e2, B, N, Nk, scale, lambda a: a, residual, own_out_always=True)  # quirk C2
         return out.reshape(B, N, C_)
 
 

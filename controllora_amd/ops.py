@@ -330,8 +330,10 @@ class _LoraProjFn(torch.autograd.Function):
     """y = x W^T (+b) (+residual) + scale_s * up_s(down_s(xa_s)) on column segment s.
 
     One frozen GEMM over x with the rank-r updates applied in its epilogue.
-    ``meta[s]`` is None (no adapter on that segment) or (xa_index, scale); xa_index selects the adapter input
-    among ``xas`` (0 = x itself).  Tensor arguments are (x, residual, *xas[1:], D_0, U_0, D_1, U_1, ...)."""
+    ``meta[s]`` is None (no adapter on that segment) or (xa_indices, scale); the indices select the adapter input(s)
+    among ``xas`` (0 = x itself).  Several indices mean the adapter acts on the SUM of those tensors, evaluated by
+    linearity as down(a) + down(b) (SURVEY.md section 8c pin 5: Lq(h + c) = Lq(h) + Lq(c)) so the sum is never
+    materialised and h keeps a single consumer.  Tensor arguments are (x, residual, *xas[1:], D_0, U_0, D_1, U_1, ...)."""
 
     @staticmethod
     def forward(ctx, pack: LinearPack, meta, n_xa, x, residual, *rest):
@@ -350,19 +352,22 @@ class _LoraProjFn(torch.autograd.Function):
                 pieces.append(torch.zeros((seg_w, r), dtype=f32, device=x.device))
                 info.append(None)
                 continue
-            xi, sc = m
+            xis, sc = m
             D, Uw = params[2 * pi], params[2 * pi + 1]
             pi += 1
             rs = D.shape[0]
-            if rs <= 16:
-                djobs.append(K.down_job(xas[xi], D.detach(), T, s * r, M, D.shape[1]))
+            assert len(xis) <= 2
+            if rs <= 16:                              # both inputs of a summed adapter input go through ONE job
+                djobs.append(K.down_job(xas[xis[0]], D.detach(), T, s * r, M, D.shape[1],
+                                        X2=xas[xis[1]] if len(xis) > 1 else None))
             else:
-                K.lora_down(xas[xi], D.detach(), T, s * r, M, D.shape[1])
+                for n_in, xi in enumerate(xis):       # separate launches: stream order makes the accumulation safe
+                    K.lora_down(xas[xi], D.detach(), T, s * r, M, D.shape[1], accumulate=n_in > 0)
             u = Uw.detach() if sc == 1.0 else Uw.detach() * sc
             if rs != r:
                 u = torch.cat([u, u.new_zeros(seg_w, r - rs)], 1)
             pieces.append(u)
-            info.append((xi, sc, rs))
+            info.append((xis, sc, rs))
         if djobs:
             K.lora_down_multi(djobs)                  # every adapter down-projection of this GEMM in one launch
         U = _stack_rows(pieces)
@@ -390,7 +395,7 @@ class _LoraProjFn(torch.autograd.Function):
         for s, m in enumerate(info):
             if m is None:
                 continue
-            xi, sc, rs = m
+            xis, sc, rs = m
             D, Uw = params[2 * pi], params[2 * pi + 1]
             pi += 1
             dys = dy[:, s * seg_w:(s + 1) * seg_w]
@@ -406,14 +411,17 @@ class _LoraProjFn(torch.autograd.Function):
                 else:
                     wjobs.append(K.wgrad_job(dys, T, s * r, _grad_buffer(Uw), Uw.shape[1], 1, M, seg_w, rs, scale=sc, lda=pack.N))
             if D.requires_grad:
-                if big:
-                    later.append((xas[xi], dT, s * r, _grad_buffer(D), 1, D.shape[1], D.shape[1], rs, 1.0, None))
+                if big:                               # separate launches in stream order: accumulation is safe
+                    for xi in xis:
+                        later.append((xas[xi], dT, s * r, _grad_buffer(D), 1, D.shape[1], D.shape[1], rs, 1.0, None))
+                else:                                 # ONE job over fp16(xa_0 + xa_1): jobs of a launch must not share G
+                    wjobs.append(K.wgrad_job(xas[xis[0]], dT, s * r, _grad_buffer(D), 1, D.shape[1], M, D.shape[1], rs,
+                                             A2=xas[xis[1]] if len(xis) > 1 else None))
+            for xi in xis:
+                if xi == 0:
+                    own.append((s, D))
                 else:
-                    wjobs.append(K.wgrad_job(xas[xi], dT, s * r, _grad_buffer(D), 1, D.shape[1], M, D.shape[1], rs))
-            if xi == 0:
-                own.append((s, D))
-            else:
-                later.append(("dx", xi, s, D))
+                    later.append(("dx", xi, s, D))
         if djobs:
             K.lora_down_multi(djobs)              # dT of every adapter of this GEMM: one launch
         if wjobs:
@@ -449,7 +457,8 @@ class _LoraProjFn(torch.autograd.Function):
 
 def lora_proj(x, pack: LinearPack, segs: Sequence[Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor, float]]],
               residual=None):
-    """segs[s] = None or (xa, down_weight [r,K], up_weight [seg,r], scale)."""
+    """segs[s] = None or (xa, down_weight [r,K], up_weight [seg,r], scale); xa is a tensor, or a tuple of tensors
+    whose sum is the adapter input."""
     xas = [x]
     meta, params = [], []
     for sg in segs:
@@ -457,11 +466,14 @@ def lora_proj(x, pack: LinearPack, segs: Sequence[Optional[Tuple[torch.Tensor, t
             meta.append(None)
             continue
         xa, D, U, sc = sg
-        idx = next((i for i, t in enumerate(xas) if t is xa), None)
-        if idx is None:
-            xas.append(xa)
-            idx = len(xas) - 1
-        meta.append((idx, float(sc)))
+        idxs = []
+        for one in (xa if isinstance(xa, (tuple, list)) else (xa,)):
+            idx = next((i for i, t in enumerate(xas) if t is one), None)
+            if idx is None:
+                xas.append(one)
+                idx = len(xas) - 1
+            idxs.append(idx)
+        meta.append((tuple(idxs), float(sc)))
         params += [D, U]
     return _LoraProjFn.apply(pack, tuple(meta), len(xas), x, residual, *xas[1:], *params)
 
@@ -533,6 +545,56 @@ class _ControlAddFn(torch.autograd.Function):
 
 def control_add(h, ctrl, D, U, scale, concat):
     return _ControlAddFn.apply(h, ctrl, D, U, float(scale), bool(concat))
+
+
+class _ControlTermFn(torch.autograd.Function):
+    """c = fp16(scale * fp16(up(down(ctrl))))  [M, C]: the v1 control term on its own (reference models.py:214-218),
+    for callers that feed `h + c` to an adapter by linearity instead of materialising the sum.  ctrl [Mc, Cc] may hold
+    fewer batch elements than M rows (control batch 1 broadcast, quirk C6)."""
+
+    @staticmethod
+    def forward(ctx, ctrl, D, U, scale, M):
+        Mc, Cc = ctrl.shape
+        R, C_ = D.shape[0], U.shape[0]
+        xr = Mc if Mc != M else 0
+        T = torch.empty((M, R), dtype=f32, device=ctrl.device)
+        K.lora_down(ctrl, D.detach(), T, 0, M, Cc, x_rows=xr)
+        c = K.lora_up(None, T, 0, U.detach(), M, C_, scale)
+        ctx.save_for_backward(ctrl, T)
+        ctx.params, ctx.cfg = (D, U), (scale, xr, M)
+        return c
+
+    @staticmethod
+    def backward(ctx, dc):
+        dc = dc.contiguous()
+        ctrl, T = ctx.saved_tensors
+        D, U = ctx.params
+        scale, xr, M = ctx.cfg
+        Mc, Cc = ctrl.shape
+        R, C_ = D.shape[0], U.shape[0]
+        dT = torch.empty((M, R), dtype=f32, device=dc.device)
+        K.lora_down(dc, U.detach(), dT, 0, M, C_, kmajor=True, R=R, d_scale=scale)
+        wj = []
+        if U.requires_grad:
+            wj.append((dc, T, _grad_buffer(U), R, 1, C_, scale, 0))
+        if D.requires_grad:
+            wj.append((ctrl, dT, _grad_buffer(D), 1, D.shape[1], Cc, 1.0, xr))
+        if R <= 16 and wj:
+            K.lora_wgrad_multi([K.wgrad_job(a_, t_, 0, g_, gn, gj, M, n_, R, scale=sc_, a_rows=ar_)
+                                for a_, t_, g_, gn, gj, n_, sc_, ar_ in wj], dc.device)
+        else:
+            for a_, t_, g_, gn, gj, n_, sc_, ar_ in wj:
+                K.lora_wgrad(a_, t_, 0, g_, gn, gj, M, n_, R, scale=sc_, a_rows=ar_)
+        dctrl = None
+        if ctx.needs_input_grad[0]:
+            dctrl = K.lora_up(None, dT, 0, D.detach(), M, Cc, 1.0, u_tr=True)
+            if xr:
+                dctrl = dctrl.reshape(M // Mc, Mc, Cc).float().sum(0).to(f16)
+        return dctrl, None, None, None, None
+
+
+def control_term(ctrl, D, U, scale, M):
+    return _ControlTermFn.apply(ctrl, D, U, float(scale), int(M))
 
 
 class _LoraApplyFn(torch.autograd.Function):

@@ -156,10 +156,12 @@ int clora_lora_down_f16(const clora_half* X, int ldx, const float* D, int ldd, f
 typedef struct {
     const clora_half* X; int ldx; const float* D; int ldd; float* T; int ldt; int toff;
     int M, K, R, accumulate, x_rows, d_kmajor; float d_scale;
+    const clora_half* X2; int ldx2;   /* optional second input [M, K]: T = (X + X2) . D^T without forming the sum */
 } clora_lora_down_job_t;
 typedef struct {
     const clora_half* A; int lda; const float* T; int ldt; int toff; float* G; int gs_n, gs_j;
     int M, N, R; float scale; int a_rows;
+    const clora_half* A2; int lda2;   /* optional: the reduction runs over fp16(A + A2) (an adapter fed by a sum of tensors) */
 } clora_lora_wgrad_job_t;
 int clora_lora_down_multi_f16(const clora_lora_down_job_t* jobs, int njobs, void* stream);
 /* workspace >= sum over jobs of clora_lora_wgrad_workspace_bytes(M, N, R) */

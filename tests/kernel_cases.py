@@ -216,6 +216,11 @@ def case_lora(dev, M, Kd, N, R, x_rows=0, seed=7):
     assert rel(T[:, 4:], Tref) < 1e-5
     K.lora_down(X, D, T, 4, M, Kd, accumulate=True, x_rows=x_rows)
     assert rel(T[:, 4:], 2 * Tref) < 1e-5
+    if R <= 16:                                   # second input by linearity: T = (X + X2) . D^T in one job
+        X2 = rnd((M, Kd), dev, g)
+        T2 = torch.zeros((M, R + 4), dtype=f32, device=dev)
+        K.lora_down_multi([K.down_job(X, D, T2, 4, M, Kd, x_rows=x_rows, X2=X2)])
+        assert rel(T2[:, 4:], Tref + X2.float() @ D.T) < 1e-5
     T[:, 4:] = Tref
     base = rnd((M, N), dev, g)
     y = K.lora_up(base, T, 4, U, M, N, 0.6)
@@ -231,6 +236,11 @@ def case_lora(dev, M, Kd, N, R, x_rows=0, seed=7):
     G2 = torch.zeros((R, N), dtype=f32, device=dev)
     K.lora_wgrad(A, T, 4, G2, 1, N, M, N, R, scale=1.0, a_rows=x_rows)
     assert rel(G2, (Af.T @ Tref).T) < 1e-4
+    if R <= 16:                                   # reduction over fp16(A + A2)
+        A2 = rnd((M, N), dev, g)
+        G3 = torch.zeros((N, R), dtype=f32, device=dev)
+        K.lora_wgrad_multi([K.wgrad_job(A, T, 4, G3, R, 1, M, N, R, a_rows=x_rows, A2=A2)], dev)
+        assert rel(G3, (Af + A2.float()).half().float().T @ Tref) < 1e-4
 
 
 def case_elementwise(dev, seed=8):
