@@ -810,6 +810,39 @@ extern "C" int clora_gemm_f16(const clora_half* A, int lda, const clora_half* B,
     return clora_gemm_f16_ex(A, lda, B, C, ldc, M, N, K, conv, epi, split_k, 0, workspace, workspace_bytes, stream);
 }
 
+// staging [Co][taps*Cip (+ bias column block)] in the gather's column order -> += into the OIHW parameter gradients; the
+// staging buffer is left zeroed for the next step (it is persistent: no per-step fill launch).  The wgrad kernel keeps
+// its atomics on the gather-ordered layout because OIHW puts consecutive channels 9 floats apart (measured: 3x slower).
+__global__ __launch_bounds__(256) void conv_wgrad_unpack_kernel(float* stage, float* stage_b, float* gw, float* gb, int Co, int Ci,
+                                                                int taps, int Cip) {
+    const int nw = Co * taps * Cip;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < nw + (gb ? Co : 0); i += gridDim.x * 256) {
+        if (i < nw) {
+            const int ci = i % Cip, tap = (i / Cip) % taps, co = i / (Cip * taps);
+            const float v = stage[i];
+            stage[i] = 0.f;
+            if (ci < Ci) gw[((size_t)co * Ci + ci) * taps + tap] += v;
+        } else {
+            const int co = i - nw;
+            gb[co] += stage_b[co];
+            stage_b[co] = 0.f;
+        }
+    }
+}
+
+extern "C" int clora_conv_wgrad_unpack_f32(float* stage, float* stage_b, float* grad_w, float* grad_b, int Co, int Ci, int ksize,
+                                           int Cip, void* stream) {
+    if (!stage || !grad_w || Co <= 0 || Ci <= 0 || Cip < Ci || (ksize != 1 && ksize != 3) || ((grad_b == nullptr) != (stage_b == nullptr)))
+        return CLORA_ERR_ARG;
+    const int taps = ksize * ksize;
+    const long total = (long)Co * taps * Cip + (grad_b ? Co : 0);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(conv_wgrad_unpack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, stage, stage_b, grad_w, grad_b,
+                       Co, Ci, taps, Cip);
+    return clora_check_launch();
+}
+
 extern "C" int clora_conv_weight_pack_f32(const float* w, int Co, int Ci, int ksize, int Cip, int Cop, clora_half* fwd,
                                           clora_half* dgrad, void* stream) {
     if (!w || !fwd || Co <= 0 || Ci <= 0 || (ksize != 1 && ksize != 3) || Cip < Ci || (Cip & 7) || (dgrad && (Cop < Co || (Cop & 7))))

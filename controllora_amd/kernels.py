@@ -172,6 +172,20 @@ def conv_wgrad_into(dY: torch.Tensor, X: torch.Tensor, M: int, N: int, K: int, c
           M, N, K, C.byref(conv) if conv is not None else None, weight_grad.shape[1], flops=2.0 * M * N * K)
 
 
+def conv_wgrad_staged(dY, X, M, N, K, conv, stage: torch.Tensor, weight_grad: torch.Tensor, bias_grad: Optional[torch.Tensor], Cip: int):
+    """3x3 trainable conv: coalesced atomics into the persistent, gather-ordered staging buffer `stage` (fp32
+    [N*K + N], zero on entry and left zero), then one unpack launch adds it into the OIHW weight / bias gradients."""
+    assert stage.dtype == f32 and stage.numel() == N * K + N and weight_grad.dtype == f32 and weight_grad.is_contiguous()
+    sw, sb = stage[:N * K], stage[N * K:]
+    _call("clora_conv_wgrad_f16", ptr(dY, f16), N, ptr(X, f16), K, ptr(sw), ptr(sb), M, N, K,
+          C.byref(conv) if conv is not None else None, 0, flops=2.0 * M * N * K)
+    Co, Ci, k, _ = weight_grad.shape
+    _call("clora_conv_wgrad_unpack_f32", ptr(sw), ptr(sb) if bias_grad is not None else None, ptr(weight_grad),
+          ptr(bias_grad, f32) if bias_grad is not None else None, Co, Ci, k, Cip)
+    if bias_grad is None:
+        sb.zero_()
+
+
 def conv_weight_pack(weight: torch.Tensor, Cip: int, need_dgrad: bool):
     """fp32 [Co,Ci,k,k] -> fp16 forward operand [Co, k*k*Cip] and (optionally) dgrad operand [Cip, k*k*Cop], one launch"""
     Co, Ci, k, _ = weight.shape

@@ -688,7 +688,15 @@ class _TrainConvFn(torch.autograd.Function):
             else:
                 dx = K.gemm(dy, ctx.wd, M, Cip, Cop)
         if weight.requires_grad:
-            K.conv_wgrad_into(dy, x, M, Co, k * k * Cip, cd, _grad_buffer(weight), _grad_buffer(bias) if bias.requires_grad else None)
+            gb = _grad_buffer(bias) if bias.requires_grad else None
+            if k == 1:      # [Co][Ci] IS the parameter layout: accumulate straight into .grad
+                K.conv_wgrad_into(dy, x, M, Co, Cip, cd, _grad_buffer(weight), gb)
+            else:           # gather-ordered persistent staging (coalesced atomics) + one unpack launch into OIHW .grad
+                stage = getattr(weight, "_clora_wgrad_stage", None)
+                if stage is None or stage.numel() != Co * 9 * Cip + Co or stage.device != dy.device:
+                    stage = torch.zeros(Co * 9 * Cip + Co, dtype=f32, device=dy.device)
+                    weight._clora_wgrad_stage = stage
+                K.conv_wgrad_staged(dy, x, M, Co, 9 * Cip, cd, stage, _grad_buffer(weight), gb, Cip)
         return dx, None, None, None, None, None, None, None, None
 
 

@@ -90,6 +90,13 @@ int clora_conv_wgrad_f16(const clora_half* dY, int ldy, const clora_half* X, int
  * (reference models.py:470); the kernel accumulates straight into it and drops the zero-padded input channels.
  * oihw_ci == 0: dW is [N, K] in the gather's (ky, kx, ci) column order. */
 
+/* grad_w[co][ci][tap] += stage[co][tap*Cip + ci], grad_b += stage_b, and stage / stage_b are reset to zero: folds a
+ * persistent gather-ordered wgrad staging buffer (clora_conv_wgrad_f16 with oihw_ci == 0) into the Conv2d parameter
+ * gradients of the hint encoder (reference models.py:470,529,594-597) without per-step fill / permute / add launches.
+ * (Direct OIHW atomics from the wgrad kernel put consecutive channels 36 bytes apart: measured 3x slower.) */
+int clora_conv_wgrad_unpack_f32(float* stage, float* stage_b, float* grad_w, float* grad_b, int Co, int Ci, int ksize,
+                                int Cip, void* stream);
+
 /* fp32 master weight [Co][Ci][ks][ks] -> fp16 GEMM operands of the step: fwd [Co][ks*ks][Cip] and (dgrad != NULL)
  * dgrad [Cip][ks*ks][Cop], zero padded.  What autocast's per-step weight cast does around the hint encoder
  * (reference train...:683), fused with the layout change the implicit GEMM wants. */

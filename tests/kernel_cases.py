@@ -84,6 +84,12 @@ def case_conv(dev, Bn, H, W, Ci, Co, stride=1, pad=1, ups=False, asym=False, see
         gb = torch.ones((Co,), dtype=f32, device=dev)
         K.conv_wgrad_into(dyn, xn, M, Co, 9 * Ci, cd, gW, gb)
         assert rel(gW - 1, w32.grad) < 1e-4 and rel(gb - 1, dy.float().sum((0, 2, 3))) < 1e-4
+        stage = torch.zeros(Co * 9 * Ci + Co, dtype=f32, device=dev)          # persistent staging + unpack (the product path)
+        gW.fill_(1.0), gb.fill_(1.0)
+        for rep in (1, 2):
+            K.conv_wgrad_staged(dyn, xn, M, Co, 9 * Ci, cd, stage, gW, gb, Ci)
+            assert rel(gW - 1, rep * w32.grad) < 1e-4 and rel(gb - 1, rep * dy.float().sum((0, 2, 3))) < 1e-4
+            assert float(stage.abs().max()) == 0.0
 
 
 def case_conv_padded_channels(dev, seed=9):
@@ -105,8 +111,12 @@ def case_conv_padded_channels(dev, seed=9):
     out = K.gemm(xn.reshape(M, Cip), wf, M, Co, 9 * Cip, conv=cd)
     assert rel(out, y.detach().permute(0, 2, 3, 1).reshape(M, Co)) < 1e-3
     gW = torch.zeros((Co, Ci, 3, 3), dtype=f32, device=dev)
-    K.conv_wgrad_into(dy.permute(0, 2, 3, 1).contiguous().reshape(M, Co), xn.reshape(M, Cip), M, Co, 9 * Cip, cd, gW, None)
+    dyn = dy.permute(0, 2, 3, 1).contiguous().reshape(M, Co)
+    K.conv_wgrad_into(dyn, xn.reshape(M, Cip), M, Co, 9 * Cip, cd, gW, None)
     assert rel(gW, w32.grad) < 1e-4
+    stage = torch.zeros(Co * 9 * Cip + Co, dtype=f32, device=dev)
+    K.conv_wgrad_staged(dyn, xn.reshape(M, Cip), M, Co, 9 * Cip, cd, stage, gW, None, Cip)
+    assert rel(gW, 2 * w32.grad) < 1e-4 and float(stage.abs().max()) == 0.0
 
 
 def _attn_ref(q, k, v, H, scale):

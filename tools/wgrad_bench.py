@@ -30,7 +30,14 @@ for H, Ci, Co, k, st in layers:
     M = B * Ho * Wo
     dy = torch.randn(M, Co, device=dev).half()
     us = timeit(lambda: K.conv_wgrad(dy, x, M, Co, Kd, cd, with_bias=True))
+    gW = torch.zeros((Co, Ci, k, k), dtype=torch.float32, device=dev)
+    gb = torch.zeros((Co,), dtype=torch.float32, device=dev)
+    stage = torch.zeros(Co * Kd + Co, dtype=torch.float32, device=dev)
+    us2 = timeit((lambda: K.conv_wgrad_staged(dy, x, M, Co, Kd, cd, stage, gW, gb, Ci)) if k == 3 else
+                 (lambda: K.conv_wgrad_into(dy, x, M, Co, Kd, cd, gW, gb)))
     tot += us
+    tot2 = globals().get("tot2", 0.0) + us2
+    globals()["tot2"] = tot2
     mb = (dy.numel() + x.numel()) * 2 / 1e6
-    print(f"M{M:8d} N{Co:5d} K{Kd:5d} {us:8.1f} us  {2.0*M*Co*Kd/us/1e6:7.1f} TF  min-bytes {mb:6.1f} MB -> {mb/us:5.2f} TB/s", flush=True)
-print(f"total {tot/1e3:.3f} ms")
+    print(f"M{M:8d} N{Co:5d} K{Kd:5d} product-path {us2:8.1f} us | {us:8.1f} us  {2.0*M*Co*Kd/us/1e6:7.1f} TF  min-bytes {mb:6.1f} MB -> {mb/us:5.2f} TB/s", flush=True)
+print(f"total {tot/1e3:.3f} ms   (product path: staged + unpack / direct for 1x1: {tot2/1e3:.3f} ms)")
