@@ -196,8 +196,9 @@ __global__ __launch_bounds__(256) void lora_wgrad_kernel(WgradJobs jobs) {
     const clora_lora_wgrad_job_t& p = jobs.j[job];
     if ((int)blockIdx.y >= jobs.nblk[job] || (int)blockIdx.x * 512 >= p.N) return;     // block-uniform exit
     const half_t* __restrict__ A = (const half_t*)p.A;
+    const half_t* __restrict__ A2 = (const half_t*)p.A2;
     const float* __restrict__ T = p.T;
-    const int lda = p.lda, ldt = p.ldt, toff = p.toff, M = p.M, N = p.N, R = p.R, a_rows = p.a_rows;
+    const int lda = p.lda, lda2 = p.lda2, ldt = p.ldt, toff = p.toff, M = p.M, N = p.N, R = p.R, a_rows = p.a_rows;
     const int rows_per_block = jobs.rpb[job];
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l = threadIdx.x & 63;
     const int n = (blockIdx.x * 64 + l) * 8;
@@ -222,8 +223,8 @@ __global__ __launch_bounds__(256) void lora_wgrad_kernel(WgradJobs jobs) {
             if (nok && m < m_end) {
                 const int ar = a_rows > 0 ? m % a_rows : m;
                 a[u] = ld8(A + (size_t)ar * lda + n);
-                if (p.A2) {                                  // adapter input = fp16(A + A2), as the reference forms it
-                    const half8 a2 = ld8((const half_t*)p.A2 + (size_t)m * p.lda2 + n);
+                if (A2) {                                    // adapter input = fp16(A + A2), as the reference forms it
+                    const half8 a2 = ld8(A2 + (size_t)m * lda2 + n);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) a[u][e] = (half_t)((float)a[u][e] + (float)a2[e]);
                 }
