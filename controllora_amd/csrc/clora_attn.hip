@@ -274,26 +274,6 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
     }
 }
 
-// ------------------------------------------------------------------------------------------ delta
-// delta[b,h,q] = sum_d dO[q,d] * O[q,d]
-__global__ __launch_bounds__(256) void attn_delta_kernel(AttnArgs p) {
-    const size_t total = (size_t)p.B * p.Nq * p.H;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int h = (int)(i % p.H);
-        const size_t row = i / p.H;  // b*Nq + q
-        const half_t* po = p.o + row * p.ldo + h * p.D;
-        const half_t* pd = p.dO + row * p.lddo + h * p.D;
-        float acc = 0.f;
-        for (int d = 0; d < p.D; d += 8) {
-            const half8 a = ld8(po + d), bb = ld8(pd + d);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) acc += (float)a[e] * (float)bb[e];
-        }
-        const int b = (int)(row / p.Nq), q = (int)(row % p.Nq);
-        p.delta[((size_t)b * p.H + h) * p.Nq + q] = acc;
-    }
-}
-
 // ------------------------------------------------------------------------------------------ dQ
 template <int DP, int DT, int BKV>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
@@ -321,7 +301,23 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
         }
         const size_t si = ((size_t)b * p.H + h) * p.Nq + q;
         Lq[qg] = (q < p.Nq) ? p.lse_in[si] * kLog2e : 1.0e30f;
-        Dq[qg] = (q < p.Nq) ? p.delta[si] : 0.f;
+        // delta[q] = sum_d dO[q,d] * O[q,d], computed here from the dO fragment this lane already holds (the four
+        // lanes li, li+16, li+32, li+48 own the four 8-wide d-groups of a row) and published for the dK/dV kernel,
+        // which runs after this one on the same stream: no separate delta launch.
+        float dl = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int d = ks * 32 + g * 8;
+            if (q < p.Nq && d < D) {
+                const half8 ov = ld8(p.o + ((size_t)b * p.Nq + q) * p.ldo + h * D + d);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) dl += (float)dof[qg][ks][e] * (float)ov[e];
+            }
+        }
+        dl += __shfl_xor(dl, 16);
+        dl += __shfl_xor(dl, 32);
+        Dq[qg] = dl;
+        if (g == 0 && q < p.Nq) p.delta[si] = dl;
     }
     const float c = p.scale * kLog2e;
 #pragma unroll
@@ -634,12 +630,7 @@ extern "C" int clora_attn_bwd_f16(const clora_half* q, int ldq, const clora_half
             (void)hipMemsetAsync(workspace, 0, need, s);
         }
     }
-    const size_t total = (size_t)B * Nq * H;
-    int blocks = (int)((total + 255) / 256);
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(attn_delta_kernel, dim3(blocks), dim3(256), 0, s, a);
-    int rc = clora_check_launch();
-    if (rc != CLORA_OK) return rc;
+    // delta = rowsum(dO * O) is produced by the dQ kernel's prologue and consumed by the dK/dV kernel launched after it
 #define COMMA_64 , 64
 #define COMMA_32 , 32
     CLORA_ATTN_DISPATCH(launch_bwd, COMMA_64);

@@ -20,5 +20,5 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_sh
     torch.cuda.synchronize()
 rows = [e for e in prof.key_averages(group_by_input_shape=True) if e.key.startswith("aten::") and e.self_device_time_total > 0]
 rows.sort(key=lambda e: -e.self_device_time_total)
-for e in rows[:30]:
+for e in rows[:int(os.environ.get('TOPN', '30'))]:
     print(f"{e.self_device_time_total/1e3:8.3f} ms {e.count:5d}x  {e.key:28s} {str(e.input_shapes)[:150]}")
