@@ -95,3 +95,33 @@ def test_short_run_checkpoint_resume_and_artifacts(tmp_path):
     m = M.ControlLoRA.from_pretrained(str(out))
     ups = [p for n, p in m.named_parameters() if n.endswith("to_q_lora.up.weight")]
     assert any(float(p.abs().max()) > 0 for p in ups)                                                # zero-init `up` has moved
+
+
+def test_checkpoint_directory_loading(tmp_path):
+    """`--pretrained_model_name_or_path <dir>`: diffusers-layout `unet/` and `vae/` folders (config.json +
+    diffusion_pytorch_model.safetensors / .bin, newer VAE attention key names accepted) load into the product models."""
+    from safetensors.torch import save_file
+    from controllora_amd import loading, unet as U, vae as V
+    u = U.UNet2DConditionModel(**loading.SMALL_UNET)
+    U.init_random_(u, seed=5)
+    v = V.AutoencoderKL(**loading.SMALL_VAE)
+    V.init_random_(v, seed=6)
+    (tmp_path / "unet").mkdir(), (tmp_path / "vae").mkdir()
+    ucfg = {k: (list(x) if isinstance(x, tuple) else x) for k, x in loading.SMALL_UNET.items()}
+    (tmp_path / "unet" / "config.json").write_text(json.dumps(dict(ucfg, _class_name="UNet2DConditionModel", sample_size=8)))
+    save_file({k: t.contiguous() for k, t in u.state_dict().items()}, str(tmp_path / "unet" / "diffusion_pytorch_model.safetensors"))
+    vcfg = {k: (list(x) if isinstance(x, tuple) else x) for k, x in loading.SMALL_VAE.items()}
+    (tmp_path / "vae" / "config.json").write_text(json.dumps(dict(vcfg, scaling_factor=0.18215)))
+    renamed = {}
+    for k, t in v.state_dict().items():            # write the VAE with the newer diffusers attention key spelling, as .bin
+        for new, old in loading._VAE_RENAMES.items():
+            k = k.replace(old, new)
+        renamed[k] = t.clone()
+    torch.save(renamed, tmp_path / "vae" / "diffusion_pytorch_model.bin")
+    u2 = loading.load_unet(str(tmp_path), "cpu")
+    v2 = loading.load_vae(str(tmp_path), "cpu")
+    assert all(torch.equal(a, b) for a, b in zip(u.state_dict().values(), u2.state_dict().values()))
+    assert all(torch.equal(v.state_dict()[k], t) for k, t in v2.state_dict().items())
+    (tmp_path / "unet" / "diffusion_pytorch_model.safetensors").unlink()
+    with pytest.raises(FileNotFoundError):
+        loading.load_unet(str(tmp_path), "cpu")
