@@ -116,6 +116,7 @@ def main():
     ap.add_argument("--no-ddim", action="store_true", help="skip the secondary inference measurement")
     ap.add_argument("--no-graph", action="store_true", help="issue the step eagerly instead of replaying hipGraphs")
     ap.add_argument("--ddim-batch", type=int, default=16)
+    ap.add_argument("--no-full-step", action="store_true", help="skip the secondary 'whole reference step' line (VAE + CLIP inside)")
     ap.add_argument("--backend", default="nccl", help='torch.distributed backend ("nccl" is RCCL on ROCm; "gloo" only for '
                     "exercising the N>1 control flow on a box with fewer GPUs than ranks)")
     args = ap.parse_args()
@@ -232,6 +233,41 @@ def main():
         del out, cond, uncond, lat0
         torch.cuda.empty_cache()
 
+    # informational third line: the WHOLE reference step (train...:751-796) -- VAE encode x0.18215, noise / timesteps /
+    # add_noise, CLIP text encode (stock transformers model: frozen glue outside the hot path), then the captured hot
+    # path -- so the cost of what SURVEY section 8f ranks "next" is visible beside the headline number.  N=1, rank 0.
+    full = None
+    if world == 1 and rank == 0 and graphed and not args.no_full_step:
+        from controllora_amd import loading, text
+        vae = loading.load_vae("random:sd15", dev)
+        enc = text.load_text_encoder("random:sd15", dev)
+        gpix = torch.Generator(device=dev).manual_seed(3)
+        pixel = (torch.rand(args.batch, 3, args.res, args.res, device=dev, generator=gpix) * 2 - 1).half()
+        ids = torch.randint(0, 49408, (args.batch, 77), device=dev, generator=gpix)
+
+        def full_step():
+            with torch.no_grad():
+                lat = vae.encode(pixel).latent_dist.sample() * vae.scaling_factor
+                nz = torch.randn_like(lat)
+                ts = torch.randint(0, 1000, (args.batch,), device=dev)
+                ny = DDPMScheduler().add_noise(lat, nz, ts).half()
+                ehs_ = enc(ids)[0].half()
+            trainer.step_graphed(ny, ts, ehs_, batch["guide"], nz)
+
+        for _ in range(2):
+            full_step()
+        torch.cuda.synchronize()
+        tf0 = time.perf_counter()
+        nfull = max(5, args.steps // 2)
+        for _ in range(nfull):
+            full_step()
+        torch.cuda.synchronize()
+        fms = (time.perf_counter() - tf0) / nfull * 1e3
+        full = {"what": "VAE encode + CLIP text encode + noise/add_noise + hot path (random-init SD-1.5-shaped VAE / CLIP)",
+                "ms_per_step": round(fms, 3), "images_per_s": round(args.batch / fms * 1e3, 3), "steps": nfull}
+        del vae, enc
+        torch.cuda.empty_cache()
+
     cpu = None
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
         cpu = cpu_baseline()
@@ -248,7 +284,7 @@ def main():
                        "global_batch": args.batch * world, "parallelism": f"dp{world}", "hipgraph": graphed,
                        "allreduce_bytes": trainer.flat.numel * 4},
             "loss": round(loss, 5), "steps_skipped_by_scaler": skipped,
-            "roofline": roofline, "ddim50": ddim, "cpu_baseline": cpu}))
+            "roofline": roofline, "ddim50": ddim, "full_step_with_vae_clip": full, "cpu_baseline": cpu}))
     if world > 1:
         torch.distributed.destroy_process_group()
 
