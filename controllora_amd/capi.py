@@ -52,7 +52,7 @@ class LoraWgradJob(C.Structure):
                 ("a_rows", C.c_int), ("A2", C.c_void_p), ("lda2", C.c_int)]
 
 
-LORA_MAX_JOBS = 8
+LORA_MAX_JOBS = 16
 _P, _I, _Z, _F = C.c_void_p, C.c_int, C.c_size_t, C.c_float
 _PROTOS = {
     "clora_gemm_f16": [_P, _I, _P, _P, _I, _I, _I, _I, C.POINTER(ConvDesc), C.POINTER(Epilogue), _I, _P, _Z, _P],

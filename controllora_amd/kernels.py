@@ -6,6 +6,7 @@ No math happens here: the wrappers validate shapes/dtypes, allocate outputs / wo
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -346,6 +347,45 @@ def lora_wgrad_multi(jobs, device):
             ws = workspace(sum(wsb(j.M, j.N, j.R) for j in chunk), device)
             arr = (capi.LoraWgradJob * len(chunk))(*chunk)
             _call("clora_lora_wgrad_multi_f16", arr, len(chunk), ptr(ws), ws.numel(), nbytes=sum(2.0 * j.M * j.N for j in chunk))
+
+
+# ---- deferred adapter weight gradients.  dU / dD are leaves of the backward pass (only the optimizer reads them), so
+# the autograd functions queue their reduction jobs instead of launching them one site at a time; the queue is flushed
+# ONCE at the end of the backward pass, 16 jobs per launch: ~110 small launch pairs per step become ~25 large ones.
+# Tensors the jobs read are kept alive until the flush.  Jobs that target the same gradient buffer never share a launch.
+_wgrad_queue = {"jobs": [], "refs": [], "armed": False, "enabled": os.environ.get("CLORA_DEFER_WGRAD", "1") != "0"}
+
+
+def lora_wgrad_defer(jobs, device, *keepalive):
+    if not _wgrad_queue["enabled"] or PROFILER is not None:
+        lora_wgrad_multi(jobs, device)
+        return
+    _wgrad_queue["jobs"].extend(jobs)
+    _wgrad_queue["refs"].extend(keepalive)
+    _wgrad_queue["device"] = device
+    if not _wgrad_queue["armed"]:
+        try:       # flush automatically when the running backward pass ends, whoever called .backward()
+            torch.autograd.Variable._execution_engine.queue_callback(lora_wgrad_flush)
+            _wgrad_queue["armed"] = True
+        except RuntimeError:
+            lora_wgrad_flush()     # not inside a backward pass: nothing to wait for
+
+
+def lora_wgrad_flush():
+    jobs, _wgrad_queue["jobs"] = _wgrad_queue["jobs"], []
+    _wgrad_queue["armed"] = False
+    if jobs:
+        batches = []               # greedy packing: a batch never holds two jobs with the same destination
+        for j in jobs:
+            for b in batches:
+                if len(b[0]) < capi.LORA_MAX_JOBS and j.G not in b[1] and b[2] == (4 if j.R <= 4 else (8 if j.R <= 8 else 16)):
+                    b[0].append(j); b[1].add(j.G)
+                    break
+            else:
+                batches.append(([j], {j.G}, 4 if j.R <= 4 else (8 if j.R <= 8 else 16)))
+        for b in batches:
+            lora_wgrad_multi(b[0], _wgrad_queue["device"])
+    _wgrad_queue["refs"].clear()
 
 
 def lora_up(base, T, toff, U, M, N, scale, out=None, u_tr=False):

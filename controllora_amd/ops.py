@@ -425,7 +425,7 @@ class _LoraProjFn(torch.autograd.Function):
         if djobs:
             K.lora_down_multi(djobs)              # dT of every adapter of this GEMM: one launch
         if wjobs:
-            K.lora_wgrad_multi(wjobs, dy.device)  # dU and dD of every adapter: one reduction + one fold launch
+            K.lora_wgrad_defer(wjobs, dy.device, dy, T, dT, *xas)   # dU / dD: queued, flushed once at the end of backward
         for item in later:
             if item[0] == "dx":
                 _, xi, s, D = item
@@ -531,8 +531,8 @@ class _ControlAddFn(torch.autograd.Function):
                 wj.append((ctrl, dT, 0, _grad_buffer(D), 1, D.shape[1], Cc, 1.0, xr))
             Dc = Dd
         if R <= 16:
-            K.lora_wgrad_multi([K.wgrad_job(a_, t_, to_, g_, gn, gj, M, n_, R, scale=sc_, a_rows=ar_)
-                                for a_, t_, to_, g_, gn, gj, n_, sc_, ar_ in wj], dy.device)
+            K.lora_wgrad_defer([K.wgrad_job(a_, t_, to_, g_, gn, gj, M, n_, R, scale=sc_, a_rows=ar_)
+                                for a_, t_, to_, g_, gn, gj, n_, sc_, ar_ in wj], dy.device, dy, T, dT, h, ctrl)
         else:
             for a_, t_, to_, g_, gn, gj, n_, sc_, ar_ in wj:
                 K.lora_wgrad(a_, t_, to_, g_, gn, gj, M, n_, R, scale=sc_, a_rows=ar_)
@@ -580,8 +580,8 @@ class _ControlTermFn(torch.autograd.Function):
         if D.requires_grad:
             wj.append((ctrl, dT, _grad_buffer(D), 1, D.shape[1], Cc, 1.0, xr))
         if R <= 16 and wj:
-            K.lora_wgrad_multi([K.wgrad_job(a_, t_, 0, g_, gn, gj, M, n_, R, scale=sc_, a_rows=ar_)
-                                for a_, t_, g_, gn, gj, n_, sc_, ar_ in wj], dc.device)
+            K.lora_wgrad_defer([K.wgrad_job(a_, t_, 0, g_, gn, gj, M, n_, R, scale=sc_, a_rows=ar_)
+                                for a_, t_, g_, gn, gj, n_, sc_, ar_ in wj], dc.device, dc, T, dT, ctrl)
         else:
             for a_, t_, g_, gn, gj, n_, sc_, ar_ in wj:
                 K.lora_wgrad(a_, t_, 0, g_, gn, gj, M, n_, R, scale=sc_, a_rows=ar_)
@@ -628,7 +628,8 @@ class _LoraApplyFn(torch.autograd.Function):
         if D.requires_grad:
             wj.append((x, dT, _grad_buffer(D), 1, D.shape[1], D.shape[1], 1.0))
         if R <= 16 and wj:
-            K.lora_wgrad_multi([K.wgrad_job(a_, t_, 0, g_, gn, gj, M, n_, R, scale=sc_) for a_, t_, g_, gn, gj, n_, sc_ in wj], dy.device)
+            K.lora_wgrad_defer([K.wgrad_job(a_, t_, 0, g_, gn, gj, M, n_, R, scale=sc_) for a_, t_, g_, gn, gj, n_, sc_ in wj],
+                               dy.device, dy, T, dT, x)
         else:
             for a_, t_, g_, gn, gj, n_, sc_ in wj:
                 K.lora_wgrad(a_, t_, 0, g_, gn, gj, M, n_, R, scale=sc_)

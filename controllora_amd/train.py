@@ -105,6 +105,7 @@ class ControlLoRATrainer:
         n = pred_c.numel()
         K.mse(pred_c, target.to(f16).contiguous(), self.loss_sum, dpred, 2.0 / n / self.accum, self.state[3:4])
         pred_c.backward(dpred)
+        K.lora_wgrad_flush()                                        # queued adapter weight gradients (no-op if already flushed)
         return pred
 
     def optimizer_step(self):

@@ -159,7 +159,7 @@ int clora_lora_down_f16(const clora_half* X, int ldx, const float* D, int ldd, f
 /* Several independent problems of the same kind in ONE launch (a v1 self-attention site has three adapter
  * down-projections in the forward pass and six weight-gradient reductions in the backward pass; each is
  * launch-latency bound on its own).  R <= 16 per job; wgrad jobs of one call share the rank class (<=4, <=8, <=16). */
-#define CLORA_LORA_MAX_JOBS 8
+#define CLORA_LORA_MAX_JOBS 16
 typedef struct {
     const clora_half* X; int ldx; const float* D; int ldd; float* T; int ldt; int toff;
     int M, K, R, accumulate, x_rows, d_kmajor; float d_scale;
