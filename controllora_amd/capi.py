@@ -42,7 +42,14 @@ class LoraDownJob(C.Structure):
     """mirror of clora_lora_down_job_t"""
     _fields_ = [("X", C.c_void_p), ("ldx", C.c_int), ("D", C.c_void_p), ("ldd", C.c_int), ("T", C.c_void_p), ("ldt", C.c_int),
                 ("toff", C.c_int), ("M", C.c_int), ("K", C.c_int), ("R", C.c_int), ("accumulate", C.c_int), ("x_rows", C.c_int),
-                ("d_kmajor", C.c_int), ("d_scale", C.c_float), ("X2", C.c_void_p), ("ldx2", C.c_int)]
+                ("d_kmajor", C.c_int), ("d_scale", C.c_float), ("X2", C.c_void_p), ("ldx2", C.c_int), ("x2_rows", C.c_int)]
+
+
+class LoraUpJob(C.Structure):
+    """mirror of clora_lora_up_job_t"""
+    _fields_ = [("base", C.c_void_p), ("ldb", C.c_int), ("T", C.c_void_p), ("ldt", C.c_int), ("toff", C.c_int), ("U", C.c_void_p),
+                ("ldu", C.c_int), ("u_transposed", C.c_int), ("Y", C.c_void_p), ("ldy", C.c_int), ("M", C.c_int), ("N", C.c_int),
+                ("R", C.c_int), ("scale", C.c_float)]
 
 
 class LoraWgradJob(C.Structure):
@@ -73,6 +80,7 @@ _PROTOS = {
     "clora_lora_down_multi_f16": [C.POINTER(LoraDownJob), _I, _P],
     "clora_lora_wgrad_multi_f16": [C.POINTER(LoraWgradJob), _I, _P, _Z, _P],
     "clora_lora_up_f16": [_P, _I, _P, _I, _I, _P, _I, _I, _P, _I, _I, _I, _I, _F, _P],
+    "clora_lora_up_multi_f16": [C.POINTER(LoraUpJob), _I, _P],
     "clora_lora_wgrad_f16": [_P, _I, _P, _I, _I, _P, _I, _I, _I, _I, _I, _F, _I, _P, _Z, _P],
     "clora_add_f16": [_P, _P, _P, _Z, _P],
     "clora_silu_f16": [_P, _P, _Z, _P],

@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void lora_down_kernel(DownJobs jobs) {
     constexpr int G = 4;                                   // k-steps in flight
     const int npass = p.X2 ? 2 : 1;                        // second input: (X + X2) . D^T by linearity, same accumulator
     for (int pass = 0; pass < npass; ++pass) {
-    if (pass == 1) { X = (const half_t*)p.X2; xoff = (size_t)(mok ? m : 0) * p.ldx2; }
+    if (pass == 1) { X = (const half_t*)p.X2; xoff = (size_t)(mok ? (p.x2_rows > 0 ? m % p.x2_rows : m) : 0) * p.ldx2; }
     for (int k0 = kbeg; k0 < kend; k0 += 32 * G) {
         half8 a[G];
         floatx4 d0[G], d1[G];
@@ -128,7 +128,12 @@ struct UpArgs {
     float scale;
 };
 
-__global__ __launch_bounds__(256) void lora_up_kernel(UpArgs p) {
+struct UpJobs {
+    UpArgs j[CLORA_LORA_MAX_JOBS];
+};
+
+__global__ __launch_bounds__(256) void lora_up_kernel(UpJobs jobs) {
+    const UpArgs& p = jobs.j[blockIdx.y];
     const int NC = p.N / 8;
     const size_t total = (size_t)p.M * NC;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
@@ -334,7 +339,7 @@ extern "C" int clora_lora_down_f16(const clora_half* X, int ldx, const float* D,
         clora_lora_down_job_t j;
         j.X = X; j.ldx = ldx; j.D = d_kmajor ? D + r0 : (D ? D + (size_t)r0 * ldd : D); j.ldd = ldd; j.T = T; j.ldt = ldt;
         j.toff = toff + r0; j.M = M; j.K = K; j.R = (R - r0 < 16) ? R - r0 : 16; j.accumulate = accumulate;
-        j.x_rows = x_rows; j.d_kmajor = d_kmajor; j.d_scale = d_scale; j.X2 = nullptr; j.ldx2 = 0;
+        j.x_rows = x_rows; j.d_kmajor = d_kmajor; j.d_scale = d_scale; j.X2 = nullptr; j.ldx2 = 0; j.x2_rows = 0;
         const int rc = clora_lora_down_multi_f16(&j, 1, stream);
         if (rc != CLORA_OK) return rc;
     }
@@ -351,7 +356,28 @@ extern "C" int clora_lora_up_f16(const clora_half* base, int ldb, const float* T
     a.u_tr = u_transposed;
     size_t blocks = ((size_t)M * (N / 8) + 255) / 256;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(lora_up_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    UpJobs uj;
+    uj.j[0] = a;
+    hipLaunchKernelGGL(lora_up_kernel, dim3((unsigned)blocks, 1), dim3(256), 0, (hipStream_t)stream, uj);
+    return clora_check_launch();
+}
+
+extern "C" int clora_lora_up_multi_f16(const clora_lora_up_job_t* jobs, int njobs, void* stream) {
+    if (!jobs || njobs <= 0 || njobs > CLORA_LORA_MAX_JOBS) return CLORA_ERR_ARG;
+    UpJobs uj;
+    size_t blocks = 1;
+    for (int i = 0; i < njobs; ++i) {
+        const clora_lora_up_job_t& j = jobs[i];
+        if (!j.T || !j.U || !j.Y || j.M <= 0 || j.N <= 0 || j.R <= 0 || (j.N & 7) || (j.ldy & 7) || (j.base && (j.ldb & 7))) return CLORA_ERR_ARG;
+        UpArgs& a = uj.j[i];
+        a.base = (const half_t*)j.base; a.T = j.T; a.U = j.U; a.Y = (half_t*)j.Y;
+        a.ldb = j.ldb; a.ldt = j.ldt; a.toff = j.toff; a.ldu = j.ldu; a.ldy = j.ldy; a.M = j.M; a.N = j.N; a.R = j.R;
+        a.scale = j.scale; a.u_tr = j.u_transposed;
+        const size_t b = ((size_t)j.M * (j.N / 8) + 255) / 256;
+        if (b > blocks) blocks = b;
+    }
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(lora_up_kernel, dim3((unsigned)blocks, njobs), dim3(256), 0, (hipStream_t)stream, uj);
     return clora_check_launch();
 }
 

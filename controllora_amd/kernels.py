@@ -310,13 +310,27 @@ def lora_down(X, D, T, toff, M, K, accumulate=False, x_rows=0, ldx=None, kmajor=
     return T
 
 
-def down_job(X, D, T, toff, M, K, accumulate=False, x_rows=0, ldx=None, kmajor=False, R=None, d_scale=1.0, X2=None):
+def down_job(X, D, T, toff, M, K, accumulate=False, x_rows=0, ldx=None, kmajor=False, R=None, d_scale=1.0, X2=None, x2_rows=0):
     """one problem of lora_down_multi (same arguments as lora_down; rank <= 16); X2: second input, T = (X + X2) . D^T"""
     assert D.dtype == f32 and D.stride(1) == 1 and T.dtype == f32 and T.stride(1) == 1
     rank = R if R is not None else (D.shape[1] if kmajor else D.shape[0])
     return capi.LoraDownJob(ptr(X, f16), ldx if ldx is not None else X.stride(0), ptr(D), D.stride(0), ptr(T), T.stride(0), toff,
                             M, K, rank, int(accumulate), x_rows, int(kmajor), float(d_scale),
-                            ptr(X2, f16) if X2 is not None else None, X2.stride(0) if X2 is not None else 0)
+                            ptr(X2, f16) if X2 is not None else None, X2.stride(0) if X2 is not None else 0, x2_rows)
+
+
+def up_job(base, T, toff, U, Y, M, N, scale, u_tr=False):
+    """one problem of lora_up_multi: Y = base + fp16(scale * fp16(T[:, toff:toff+R] . U^T))"""
+    assert U.dtype == f32 and U.stride(1) == 1 and T.dtype == f32 and Y.dtype == f16
+    return capi.LoraUpJob(ptr(base, f16) if base is not None else None, base.stride(0) if base is not None else 0, ptr(T), T.stride(0),
+                          toff, ptr(U), U.stride(0), int(u_tr), ptr(Y), Y.stride(0), M, N, U.shape[0] if u_tr else U.shape[1], float(scale))
+
+
+def lora_up_multi(jobs):
+    for i in range(0, len(jobs), capi.LORA_MAX_JOBS):
+        chunk = jobs[i:i + capi.LORA_MAX_JOBS]
+        arr = (capi.LoraUpJob * len(chunk))(*chunk)
+        _call("clora_lora_up_multi_f16", arr, len(chunk), nbytes=sum(2.0 * j.M * j.N for j in chunk))
 
 
 def lora_down_multi(jobs):

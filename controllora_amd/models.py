@@ -184,6 +184,12 @@ class _ControlMixin:
 
     def inject_control_states(self, control_states):
         self.control_states = control_states
+        self._control_term = None          # a term precomputed for the previous control states is stale now
+
+    def inject_control_term(self, term, scale=1.0):
+        """ControlLoRA.forward evaluates `scale * to_control(control)` for all sites of a level in one batched launch
+        pair (ops.control_terms) and hands each site its slice; used when the call's `scale` matches."""
+        self._control_term, self._control_term_scale = term, float(scale)
 
     def _control_tokens(self, hidden_states):
         """models.py:202-206 / :337-341: flatten NCHW -> [B, HW, C] once and cache on self (quirk C5).  The hint
@@ -235,8 +241,10 @@ class ControlLoRACrossAttnProcessor(_ControlMixin, LoRACrossAttnProcessor):
         else:
             # hidden + control term feeds ONLY the q adapter (models.py:237-238); Lq(h + c) = Lq(h) + Lq(c), so the sum is
             # never formed: h keeps one consumer (no autograd gradient add) and the q/k/v downs share their read of h
-            ctrl = self._control_tokens(hidden_states)
-            c = ops.control_term(_flat2(ctrl), self.to_control.down.weight, self.to_control.up.weight, scale, B * N)
+            c = getattr(self, "_control_term", None)
+            if c is None or self._control_term_scale != float(scale):
+                ctrl = self._control_tokens(hidden_states)
+                c = ops.control_term(_flat2(ctrl), self.to_control.down.weight, self.to_control.up.weight, scale, B * N)
             q_in = (h2, c)
         out = self._attend(attn, h2, q_in, e2, B, N, Nk, scale, lambda a: a, residual, own_out_always=True)  # quirk C2
         return out.reshape(B, N, C_)
@@ -471,6 +479,10 @@ class ControlLoRA(nn.Module):
         return model
 
     # ---- forward (H4, reference models.py:810-835)
+    @staticmethod
+    def _inject_control_terms(procs, c):
+        _batched_control_terms(procs, c)
+
     def forward(self, x: torch.Tensor, return_dict: bool = True) -> Union[ControlLoRAOutput, Tuple]:
         orig_dtype = x.dtype
         B, Cin, H, W = x.shape
@@ -490,6 +502,7 @@ class ControlLoRA(nn.Module):
             # as contiguous fp16 adds.  The RETURNED tuple keeps the reference's NCHW shape as a zero-copy view.
             for p in procs:
                 p.inject_control_states(c)
+            self._inject_control_terms(procs, c)
             ctrl = c.reshape(B, H, W, -1).permute(0, 3, 1, 2)
             if orig_dtype != f16:
                 ctrl = ctrl.to(orig_dtype)
@@ -497,6 +510,18 @@ class ControlLoRA(nn.Module):
         if not return_dict:
             return tuple(outs)
         return ControlLoRAOutput(control_states=tuple(outs))
+
+
+def _batched_control_terms(procs, c):
+    """v1 sites whose control term depends on the control map only (no concat_hidden, no post_add / chained adapters,
+    rank <= 16): evaluate `to_control(control)` for all of them at once (reference models.py:214-218, 10 sites/level)."""
+    sites = [p for p in procs if isinstance(p, ControlLoRACrossAttnProcessor) and not p.concat_hidden
+             and not p._needs_generic_path() and p.to_control.down.weight.shape[0] <= 16]
+    if len(sites) < 2 or len({tuple(p.to_control.down.weight.shape) + tuple(p.to_control.up.weight.shape) for p in sites}) != 1:
+        return
+    terms = ops.control_terms(c.reshape(-1, c.shape[-1]), [(p.to_control.down.weight, p.to_control.up.weight) for p in sites], 1.0)
+    for p, t in zip(sites, terms):
+        p.inject_control_term(t, 1.0)
 
 
 def map_processors_to_unet(unet, control_lora) -> dict:

@@ -358,8 +358,9 @@ class _LoraProjFn(torch.autograd.Function):
             rs = D.shape[0]
             assert len(xis) <= 2
             if rs <= 16:                              # both inputs of a summed adapter input go through ONE job
-                djobs.append(K.down_job(xas[xis[0]], D.detach(), T, s * r, M, D.shape[1],
-                                        X2=xas[xis[1]] if len(xis) > 1 else None))
+                x2 = xas[xis[1]] if len(xis) > 1 else None          # may hold fewer rows (control batch 1 broadcast, quirk C6)
+                djobs.append(K.down_job(xas[xis[0]], D.detach(), T, s * r, M, D.shape[1], X2=x2,
+                                        x2_rows=x2.shape[0] if (x2 is not None and x2.shape[0] != M) else 0))
             else:
                 for n_in, xi in enumerate(xis):       # separate launches: stream order makes the accumulation safe
                     K.lora_down(xas[xi], D.detach(), T, s * r, M, D.shape[1], accumulate=n_in > 0)
@@ -415,8 +416,10 @@ class _LoraProjFn(torch.autograd.Function):
                     for xi in xis:
                         later.append((xas[xi], dT, s * r, _grad_buffer(D), 1, D.shape[1], D.shape[1], rs, 1.0, None))
                 else:                                 # ONE job over fp16(xa_0 + xa_1): jobs of a launch must not share G
-                    wjobs.append(K.wgrad_job(xas[xis[0]], dT, s * r, _grad_buffer(D), 1, D.shape[1], M, D.shape[1], rs,
-                                             A2=xas[xis[1]] if len(xis) > 1 else None))
+                    a2 = xas[xis[1]] if len(xis) > 1 else None
+                    if a2 is not None and a2.shape[0] != M:        # broadcast second input (control batch < UNet batch)
+                        a2 = a2.repeat(M // a2.shape[0], 1)
+                    wjobs.append(K.wgrad_job(xas[xis[0]], dT, s * r, _grad_buffer(D), 1, D.shape[1], M, D.shape[1], rs, A2=a2))
             for xi in xis:
                 if xi == 0:
                     own.append((s, D))
@@ -431,6 +434,9 @@ class _LoraProjFn(torch.autograd.Function):
                 _, xi, s, D = item
                 if ctx.needs_input_grad[4 + xi]:
                     g = K.lora_up(None, dT, s * r, D.detach(), M, D.shape[1], 1.0, u_tr=True)
+                    rows = xas[xi].shape[0]
+                    if rows != M:                                   # the input was broadcast over the batch: sum it back
+                        g = g.reshape(M // rows, rows, -1).float().sum(0).to(f16)
                     d_xas[xi] = g if d_xas[xi] is None else K.add(d_xas[xi], g)
             else:
                 A_, T_, to_, G_, gsn, gsj, N_, rs_, sc_, lda_ = item
@@ -595,6 +601,59 @@ class _ControlTermFn(torch.autograd.Function):
 
 def control_term(ctrl, D, U, scale, M):
     return _ControlTermFn.apply(ctrl, D, U, float(scale), int(M))
+
+
+class _ControlTermsFn(torch.autograd.Function):
+    """The control terms c_l = fp16(scale * fp16(U_l (D_l ctrl))) of ALL attention sites of one UNet level in one go
+    (they share the level's hint-encoder feature map `ctrl` [Mc, Cc]): one multi-job down launch + one multi-job up
+    launch instead of two per site.  The backward receives every dc_l at once -- autograd runs it after the whole UNet
+    backward, it only feeds the hint encoder -- so dT is one multi-job launch, the weight gradients join the deferred
+    queue, and d(ctrl) = [dT_1 | ... | dT_n] . [D_1; ...; D_n] is ONE rank-(n*r) expand: the n-way gradient
+    accumulation into the shared control map (n-1 autograd adds per level) disappears."""
+
+    @staticmethod
+    def forward(ctx, ctrl, scale, n, *params):
+        Mc, Cc = ctrl.shape
+        Ds, Us = params[0::2], params[1::2]
+        r, C_ = Ds[0].shape[0], Us[0].shape[0]
+        assert all(D.shape == (r, Cc) for D in Ds) and all(U.shape == (C_, r) for U in Us) and r <= 16
+        T = torch.empty((Mc, n * r), dtype=f32, device=ctrl.device)
+        K.lora_down_multi([K.down_job(ctrl, D.detach(), T, l * r, Mc, Cc) for l, D in enumerate(Ds)])
+        cs = [torch.empty((Mc, C_), dtype=f16, device=ctrl.device) for _ in range(n)]
+        K.lora_up_multi([K.up_job(None, T, l * r, U.detach(), cs[l], Mc, C_, scale) for l, U in enumerate(Us)])
+        ctx.save_for_backward(ctrl, T)
+        ctx.params, ctx.cfg = params, (scale, n, r, C_)
+        return tuple(cs)
+
+    @staticmethod
+    def backward(ctx, *dcs):
+        ctrl, T = ctx.saved_tensors
+        scale, n, r, C_ = ctx.cfg
+        Ds, Us = ctx.params[0::2], ctx.params[1::2]
+        Mc, Cc = ctrl.shape
+        live = [l for l in range(n) if dcs[l] is not None]
+        dcs = [d.contiguous() if d is not None else None for d in dcs]
+        dT = (torch.empty if len(live) == n else torch.zeros)((Mc, n * r), dtype=f32, device=ctrl.device)
+        K.lora_down_multi([K.down_job(dcs[l], Us[l].detach(), dT, l * r, Mc, C_, kmajor=True, R=r, d_scale=scale) for l in live])
+        wj = []
+        for l in live:
+            if Us[l].requires_grad:
+                wj.append(K.wgrad_job(dcs[l], T, l * r, _grad_buffer(Us[l]), r, 1, Mc, C_, r, scale=scale))
+            if Ds[l].requires_grad:
+                wj.append(K.wgrad_job(ctrl, dT, l * r, _grad_buffer(Ds[l]), 1, Cc, Mc, Cc, r))
+        if wj:
+            K.lora_wgrad_defer(wj, ctrl.device, ctrl, T, dT, *[d for d in dcs if d is not None])
+        dctrl = None
+        if ctx.needs_input_grad[0]:
+            Dcat = _stack_rows([D.detach() for D in Ds])
+            dctrl = K.lora_up(None, dT, 0, Dcat, Mc, Cc, 1.0, u_tr=True)
+        return (dctrl, None, None) + (None,) * (2 * n)
+
+
+def control_terms(ctrl, layers, scale=1.0):
+    """layers: [(down_weight, up_weight), ...] of the sites sharing `ctrl` -> tuple of control terms [Mc, C]"""
+    flat = [w for D, U in layers for w in (D, U)]
+    return _ControlTermsFn.apply(ctrl, float(scale), len(layers), *flat)
 
 
 class _LoraApplyFn(torch.autograd.Function):

@@ -164,6 +164,7 @@ typedef struct {
     const clora_half* X; int ldx; const float* D; int ldd; float* T; int ldt; int toff;
     int M, K, R, accumulate, x_rows, d_kmajor; float d_scale;
     const clora_half* X2; int ldx2;   /* optional second input [M, K]: T = (X + X2) . D^T without forming the sum */
+    int x2_rows;                      /* > 0: X2 has only x2_rows rows, row m reads X2[m % x2_rows] (control batch 1, quirk C6) */
 } clora_lora_down_job_t;
 typedef struct {
     const clora_half* A; int lda; const float* T; int ldt; int toff; float* G; int gs_n, gs_j;
@@ -179,6 +180,13 @@ int clora_lora_wgrad_multi_f16(const clora_lora_wgrad_job_t* jobs, int njobs, vo
  * "hidden + to_control(control)" of models.py:214-218,237-238 and the V2 pre/post adds (:369,:415). */
 int clora_lora_up_f16(const clora_half* base, int ldb, const float* T, int ldt, int toff, const float* U, int ldu,
                       int u_transposed, clora_half* Y, int ldy, int M, int N, int R, float scale, void* stream);
+/* several of them in one launch: the control terms of the 10 attention sites of a UNet level share one hint-encoder
+ * feature map, so ControlLoRA.forward (models.py:810-835) evaluates them together right after the hint encoder */
+typedef struct {
+    const clora_half* base; int ldb; const float* T; int ldt; int toff; const float* U; int ldu; int u_transposed;
+    clora_half* Y; int ldy; int M, N, R; float scale;
+} clora_lora_up_job_t;
+int clora_lora_up_multi_f16(const clora_lora_up_job_t* jobs, int njobs, void* stream);
 /* G[n*gs_n + j*gs_j] += scale * sum_m A[m, n] * T[m, toff+j]  (adapter weight gradients; two-stage
  * deterministic reduction through `workspace` of clora_lora_wgrad_workspace_bytes(M, N, R) bytes, no atomics). */
 size_t clora_lora_wgrad_workspace_bytes(int M, int N, int R);
