@@ -14,6 +14,16 @@ LIB = os.path.join(OUT_DIR, "libclora_emu.so")
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 
 
+def _host_isa_flags():
+    """F16C turns the emulated MFMA's fp16->fp32 conversions from library calls into one instruction (3.3x faster
+    emulated step); only used when this host advertises it."""
+    try:
+        flags = open("/proc/cpuinfo").read()
+    except OSError:
+        return []
+    return ["-mf16c", "-mavx2", "-mfma"] if all(f" {f}" in flags for f in ("f16c", "avx2", "fma")) else []
+
+
 def build(verbose: bool = False) -> str:
     os.makedirs(OUT_DIR, exist_ok=True)
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
@@ -24,7 +34,7 @@ def build(verbose: bool = False) -> str:
     for src in srcs + [os.path.join(HERE, "hipemu.cpp")]:
         obj = os.path.join(OUT_DIR, os.path.basename(src).rsplit(".", 1)[0] + ".emu.o")
         if not os.path.exists(obj) or os.path.getmtime(obj) < newest:
-            cmd = [CLANG, "-O2", "-g0", "-std=c++17", "-fPIC", "-I", HERE, "-Wno-unknown-pragmas", "-Wno-pass-failed",
+            cmd = [CLANG, "-O2", "-g0", *_host_isa_flags(), "-std=c++17", "-fPIC", "-I", HERE, "-Wno-unknown-pragmas", "-Wno-pass-failed",
                    "-x", "c++", "-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)
