@@ -139,3 +139,26 @@ def check_trainer_features(dev, golden_dir, real_backward=True):
         assert rel(a.flat.data, b.flat.data) < 1e-5 and rel(a.flat.exp_avg_sq, b.flat.exp_avg_sq) < 1e-3
     else:
         assert torch.equal(a.flat.data, b.flat.data) and torch.equal(a.flat.exp_avg_sq, b.flat.exp_avg_sq)
+
+
+def check_inference_broadcast(case, dev, tol=6e-3):
+    """Inference call pattern (reference apps/gradio_canny2image.py:66-92): the hint encoder sees ONE guide image, the
+    UNet a classifier-free-guidance batch of 2 -- the control states are repeated over the batch (quirk C6, reference
+    models.py:209-213).  Product forward (no_grad; batched / cached control terms, broadcast second adapter input)
+    against the oracle restatement, twice (the second call reuses the cached control states like a scheduler loop)."""
+    inp = cases.seeded_inputs()
+    o_unet, _, o_clora = cases.build_oracle_case(case)
+    unet, _, clora = build_product_case(case, dev)
+    guide = inp["guide"][:1]
+    lat = torch.cat([inp["latents"][:1]] * 2)
+    ehs = inp["ehs"][:2]
+    errs = []
+    with torch.no_grad():
+        o_clora(guide)
+        clora(guide.to(dev).to(f16))
+        for t in (801, 401):
+            ref = o_unet(lat, t, ehs).sample
+            out = unet(lat.to(dev).to(f16), t, ehs.to(dev).to(f16)).sample
+            errs.append(rel(out, ref))
+    assert max(errs) < tol, errs
+    return errs

@@ -84,3 +84,8 @@ def test_trainer_accumulation_lr_schedule_and_resume(golden_dir):
 def test_vae_encode_decode_matches_oracle():
     from tests import vae_cases
     print(vae_cases.check_vae("cpu", res=32, batch=1))
+
+
+@pytest.mark.parametrize("case", ["v1", "v2"])
+def test_inference_with_control_batch_broadcast(case):
+    print(case, E.check_inference_broadcast(case, "cpu"))

@@ -100,3 +100,8 @@ def test_trainer_accumulation_lr_schedule_and_resume(golden_dir):
 def test_vae_encode_decode_matches_oracle():
     from tests import vae_cases
     print(vae_cases.check_vae("cuda", res=64, batch=2))
+
+
+@pytest.mark.parametrize("case", ["v1", "v2", "sketch"])
+def test_inference_with_control_batch_broadcast(case):
+    print(case, E.check_inference_broadcast(case, "cuda"))
