@@ -84,15 +84,23 @@ _ws_cache = {}
 
 
 def workspace(nbytes: int, device) -> torch.Tensor:
-    """Grow-only per-device scratch (split-K slabs, GroupNorm partials). Reused across calls on one stream."""
+    """Grow-only per-device scratch (split-K slabs, GroupNorm partials). Reused across calls on one stream.
+    A captured hipGraph bakes the buffer's address into its kernel nodes, so a buffer that has been handed out is NEVER
+    freed (growing keeps the old one alive) and on a GPU the first allocation already covers the largest request the
+    library's planner can make -- a later, larger problem (batch-32 inference after a captured train step) must not
+    move the scratch under the graph."""
     key = str(device)
     w = _ws_cache.get(key)
     if w is None or w.numel() < nbytes:
-        w = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        floor = GEMM_WS_BYTES if torch.device(device).type == "cuda" else (1 << 20)
+        if w is not None:
+            _ws_retired.append(w)
+        w = torch.empty(max(nbytes, floor), dtype=torch.uint8, device=device)
         _ws_cache[key] = w
     return w
 
 
+_ws_retired = []
 GEMM_WS_BYTES = 256 << 20   # split-K slab budget handed to the library's launch planner
 
 # Autotuned launch configurations (tools/tune_gemm.py on an MI355X): exact-shape lookups for the GEMMs of the

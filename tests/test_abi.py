@@ -41,3 +41,15 @@ def test_no_cpu_fallback():
         x = torch.zeros(8, 8, dtype=torch.float16)
         with pytest.raises(capi.CloraError):          # product library + CPU tensors -> loud error, not a fallback
             K.silu(x)
+
+
+def test_workspace_is_never_freed_or_moved_under_a_graph():
+    """a captured hipGraph holds the scratch address: growing the workspace must keep the old buffer alive
+    (regression: batch-32 inference after a captured train step grew it and the replayed step faulted)"""
+    import torch
+    from controllora_amd import kernels as K
+    a = K.workspace(1000, "cpu")
+    pa = a.data_ptr()
+    b = K.workspace(a.numel() + 4096, "cpu")
+    assert b.numel() >= a.numel() + 4096 and any(t.data_ptr() == pa for t in K._ws_retired)
+    assert K.workspace(10, "cpu") is b                       # never shrinks
