@@ -224,14 +224,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
             mx = fmaxf(mx, __shfl_xor(mx, 16));
             mx = fmaxf(mx, __shfl_xor(mx, 32));
             const float mnew = fmaxf(mrun[qg], mx);
-            const float alpha = exp2f(mrun[qg] - mnew);
+            const float alpha = CLORA_EXP2(mrun[qg] - mnew);
             mrun[qg] = mnew;
             float ps = 0.f;
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float pv = exp2f(s[kt][qg][r] - mnew);
+                    const float pv = CLORA_EXP2(s[kt][qg][r] - mnew);
                     s[kt][qg][r] = pv;
                     ps += pv;
                 }
@@ -372,7 +372,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const bool ok = (kt * 16 + 4 * g + r) < rows;
-                    const float pv = ok ? exp2f(s[kt][qg][r] - Lq[qg]) : 0.f;
+                    const float pv = ok ? CLORA_EXP2(s[kt][qg][r] - Lq[qg]) : 0.f;
                     s[kt][qg][r] = pv * (dp[kt][qg][r] - Dq[qg]);  // dS^T
                 }
 #pragma unroll
@@ -482,7 +482,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs p) {
                 const float Lv = Ls[ql], Dv = Ds[ql];
 #pragma unroll
                 for (int kg = 0; kg < 2; ++kg) {
-                    const float pv = exp2f(s[qt][kg][r] * c - Lv);
+                    const float pv = CLORA_EXP2(s[qt][kg][r] * c - Lv);
                     s[qt][kg][r] = pv;                       // P
                     dp[qt][kg][r] = pv * (dp[qt][kg][r] - Dv);  // dS
                 }

@@ -52,6 +52,10 @@ __device__ __forceinline__ half4v clora_ds_read_tr16(const half_t* lptr) {
     return r;
 }
 #define CLORA_DS_READ_TR16(lptr) clora_ds_read_tr16(lptr)
+// bare v_exp_f32 (2^x, ~1 ulp).  exp2f() wraps it in a denormal-range fix-up (v_cmp / 2x v_cndmask / v_add / v_ldexp:
+// five extra VALU instructions per element); softmax probabilities below 2^-126 may flush to zero.
+#define CLORA_EXP2(x) __builtin_amdgcn_exp2f(x)
+#define CLORA_RCP(x) __builtin_amdgcn_rcpf(x)      // v_rcp_f32 (1 ulp) instead of the IEEE division sequence
 #endif
 
 __device__ __forceinline__ floatx4 mfma16(half8 a, half8 b, floatx4 c) {
@@ -71,10 +75,12 @@ __device__ __forceinline__ floatx4 zero4f() {
     return z;
 }
 
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
+// sigmoid through the bare hardware exp2 / rcp (1 ulp each; results are rounded to fp16 anyway)
+__device__ __forceinline__ float sigmoid_f(float x) { return CLORA_RCP(1.0f + CLORA_EXP2(-1.4426950408889634f * x)); }
+__device__ __forceinline__ float silu_f(float x) { return x * sigmoid_f(x); }
 // d/dx silu(x) = s + x*s*(1-s), s = sigmoid(x)
 __device__ __forceinline__ float dsilu_f(float x) {
-    float s = 1.0f / (1.0f + expf(-x));
+    float s = sigmoid_f(x);
     return s * (1.0f + x * (1.0f - s));
 }
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }

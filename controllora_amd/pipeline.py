@@ -29,3 +29,50 @@ def ddim_sample(unet, control_lora, guide, cond_emb, uncond_emb, steps=50, guida
         eps = eps_u + guidance_scale * (eps_c - eps_u)
         latents = sched.step(eps, t, latents)
     return latents
+
+
+class ControlLoRAPipeline:
+    """The `process()` body of the reference apps (apps/gradio_canny2image.py:66-92) without the UI and the annotator:
+    prompt(s) + one guide image -> images.  Text encode (cond / negative), hint-encode the guide ONCE (control batch 1 is
+    broadcast over the CFG batch, quirk C6), DDIM loop with classifier-free guidance on the HIP UNet, VAE decode.
+
+        pipe = ControlLoRAPipeline.from_pretrained("random:sd15", "path/to/control_lora")
+        images = pipe("a red circle", guide, num_samples=4, ddim_steps=50, scale=9.0, seed=1)   # uint8 [N, H, W, 3]
+    """
+
+    def __init__(self, unet, control_lora, vae, text_encoder, tokenizer):
+        self.unet, self.control_lora, self.vae, self.text_encoder, self.tokenizer = unet, control_lora, vae, text_encoder, tokenizer
+
+    @classmethod
+    def from_pretrained(cls, base: str, control_lora, device="cuda"):
+        from . import loading, models, text
+        dev = torch.device(device)
+        unet = loading.load_unet(base, dev)
+        if isinstance(control_lora, str):
+            control_lora = models.ControlLoRA.from_pretrained(control_lora)
+        control_lora = control_lora.to(dev)
+        unet.set_attn_processor(models.map_processors_to_unet(unet, control_lora))
+        return cls(unet, control_lora, loading.load_vae(base, dev), text.load_text_encoder(base, dev, small=base.endswith("small")),
+                   text.load_tokenizer(base))
+
+    @torch.no_grad()
+    def encode_prompt(self, prompts):
+        dev = next(self.text_encoder.parameters()).device
+        return self.text_encoder(self.tokenizer(list(prompts)).to(dev))[0].half()
+
+    @torch.no_grad()
+    def __call__(self, prompt, guide, a_prompt="", n_prompt="", num_samples=1, ddim_steps=50, scale=9.0, seed=None,
+                 output_type="uint8"):
+        """guide: float tensor [1 or N, 3, H, W] in [-1, 1] (H, W multiples of 64)"""
+        dev = next(self.text_encoder.parameters()).device
+        gen = torch.Generator(device=dev)
+        if seed is not None:
+            gen.manual_seed(int(seed))
+        cond = self.encode_prompt([prompt + (", " + a_prompt if a_prompt else "")] * num_samples)
+        uncond = self.encode_prompt([n_prompt] * num_samples)
+        lat = ddim_sample(self.unet, self.control_lora, guide.to(dev).half(), cond, uncond, steps=ddim_steps,
+                          guidance_scale=scale, generator=gen)
+        img = self.vae.decode(lat.half() / self.vae.scaling_factor).sample.float().clamp(-1, 1)
+        if output_type == "uint8":
+            return ((img.permute(0, 2, 3, 1) + 1.0) * 127.5).round().to(torch.uint8).cpu()
+        return img

@@ -105,3 +105,21 @@ def test_vae_encode_decode_matches_oracle():
 @pytest.mark.parametrize("case", ["v1", "v2", "sketch"])
 def test_inference_with_control_batch_broadcast(case):
     print(case, E.check_inference_broadcast(case, "cuda"))
+
+
+def test_pipeline_prompt_to_image(tmp_path):
+    """reference apps/gradio_canny2image.py:66-92 call pattern end to end on the small random model: text encode, hint
+    encode once, CFG DDIM loop, VAE decode; deterministic for a fixed seed."""
+    import json
+    from controllora_amd import models as M
+    from controllora_amd.pipeline import ControlLoRAPipeline
+    from oracle import cases
+    torch.manual_seed(0)
+    clora = M.ControlLoRA(**cases.SMALL_CLORA_V1)
+    pipe = ControlLoRAPipeline.from_pretrained("random:small", clora, "cuda")
+    guide = torch.rand(1, 3, 64, 64) * 2 - 1
+    a = pipe("red circle", guide, num_samples=2, ddim_steps=3, scale=7.5, seed=5)
+    b = pipe("red circle", guide, num_samples=2, ddim_steps=3, scale=7.5, seed=5)
+    assert a.shape == (2, 64, 64, 3) and a.dtype == torch.uint8 and torch.equal(a, b)
+    c = pipe("red circle", guide, num_samples=2, ddim_steps=3, scale=7.5, seed=6)
+    assert not torch.equal(a, c)
