@@ -70,8 +70,10 @@ __global__ __launch_bounds__(256) void geglu_bwd_kernel(const half_t* h, const h
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const float gf = (float)g[e], df = (float)d[e];
-            da[e] = (half_t)(df * gelu_f(gf));
-            dg[e] = (half_t)(df * (float)a[e] * dgelu_f(gf));
+            float cdf, pdf;
+            gelu_parts(gf, cdf, pdf);
+            da[e] = (half_t)(df * gf * cdf);
+            dg[e] = (half_t)(df * (float)a[e] * (cdf + gf * pdf));
         }
         st8(dh + m * 2 * F + j, da);
         st8(dh + m * 2 * F + F + j, dg);

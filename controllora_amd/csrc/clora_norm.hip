@@ -426,7 +426,7 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const half_t* x, half
     for (int j = 0; j < kSmCols; ++j)
         if (l + 64 * j < CH) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { f[j][e] = expf((float)v[j][e] * scale - mx); sum += f[j][e]; }
+            for (int e = 0; e < 8; ++e) { f[j][e] = CLORA_EXP2(((float)v[j][e] * scale - mx) * 1.4426950408889634f); sum += f[j][e]; }
         }
     const float inv = 1.0f / wave_sum(sum);
 #pragma unroll
