@@ -147,8 +147,12 @@ __device__ __forceinline__ void tile_store_cols_n(const TileRegs<ROWS, DP>& r, h
 }
 
 // ------------------------------------------------------------------------------------------ forward
+// __launch_bounds__(256, 2) for head dims <= 64: with a 256-register budget the compiler keeps the MFMA accumulators in
+// VGPRs; with the default (one block per CU, 512 registers) it parks them in AGPRs and the softmax / rescale VALU work
+// pays ~145 v_accvgpr_read/write moves per KV tile (a third of the loop's VALU instructions).  Larger head dims would
+// spill at 256 registers and keep the default.
 template <int DP, int DT>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
+__global__ __launch_bounds__(256, (DP <= 64 ? 2 : 1)) void attn_fwd_kernel(AttnArgs p) {
     constexpr int BKV = 64, LDK = DP + 8, LDV = BKV + 8, KS = DP / 32, DV = DT * 16;
     __shared__ __attribute__((aligned(16))) half_t smem[BKV * LDK + DV * LDV];
     half_t* Ks = smem;
@@ -276,7 +280,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
 
 // ------------------------------------------------------------------------------------------ dQ
 template <int DP, int DT, int BKV>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
+__global__ __launch_bounds__(256, (DP <= 64 ? 2 : 1)) void attn_bwd_dq_kernel(AttnArgs p) {
     constexpr int LDK = DP + 8, LDT = BKV + 8, KS = DP / 32, KT = BKV / 16, NP = BKV / 32;
     __shared__ __attribute__((aligned(16))) half_t smem[2 * BKV * LDK + DT * 16 * LDT];
     half_t* Ks = smem;
@@ -407,7 +411,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
 
 // ------------------------------------------------------------------------------------------ dK, dV
 template <int DP, int DT, int BQT>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs p) {
+__global__ __launch_bounds__(256, (DP <= 64 ? 2 : 1)) void attn_bwd_dkv_kernel(AttnArgs p) {
     constexpr int LDK = DP + 8, LDT = BQT + 8, KS = DP / 32, QT = BQT / 16, NP = BQT / 32;
     constexpr int HALVES = 2 * BQT * LDK + 2 * DT * 16 * LDT;
     __shared__ __attribute__((aligned(16))) half_t smem[HALVES + 4 * BQT];
