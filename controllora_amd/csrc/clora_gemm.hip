@@ -295,7 +295,13 @@ template <int BM, int BN, int NST> struct DmaOcc {
     static constexpr int v = fit < cap ? fit : cap;
 };
 
-template <int BM, int BN, int WM, int WN, int NST>
+// CONV: 0 = plain GEMM rows; 1 = generic gather (strided / asymmetric-pad / upsampled convs and their dgrads);
+// 2 = the common case -- 3x3, stride 1, Cin % 32 == 0 (every ResnetBlock conv and its dgrad): a BK=32 step then lies
+// inside ONE filter tap for the whole wave, so the tap walk and its address delta are scalar (SALU) work and each
+// DMA instruction costs a bit test, an add and a select.  The generic path spends ~35 VALU/branch instructions per DMA
+// instruction; with four of them per 16 MFMAs that made instruction issue, not the matrix pipe, the limiter of the conv
+// GEMMs (plain GEMMs ran at ~600 TFLOP/s, the same shapes as convs at 340-540).
+template <int BM, int BN, int WM, int WN, int NST, int CONV>
 __global__ __launch_bounds__(256, (DmaOcc<BM, BN, NST>::v)) void gemm_dma_kernel(GemmArgs p) {
     constexpr int BK = 32;
     constexpr int FM = BM / WM / 16, FN = BN / WN / 16;
@@ -322,7 +328,7 @@ __global__ __launch_bounds__(256, (DmaOcc<BM, BN, NST>::v)) void gemm_dma_kernel
     const int nk = (kend - kbeg + BK - 1) / BK;
 
     const int w = t >> 6, l = t & 63, g = l >> 4, li = l & 15;
-    const bool conv = p.conv.enabled != 0;
+    constexpr bool conv = CONV == 1;
     const half_t* zero_page = reinterpret_cast<const half_t*>(g_clora_zero16);
 
     // ---- loader: wave w, instruction i fills rows (w*IN + i)*16 .. +16 of the tile; lane -> (row l/4, slot l%4)
@@ -331,14 +337,25 @@ __global__ __launch_bounds__(256, (DmaOcc<BM, BN, NST>::v)) void gemm_dma_kernel
     bool a_ok[A_IN];
     size_t a_base[A_IN];
     int a_ty[A_IN], a_tx[A_IN];
+    unsigned a_mask[A_IN];                                  // CONV == 2: bit t = filter tap t of this row is in bounds
 #pragma unroll
     for (int i = 0; i < A_IN; ++i) {
         const int m = m0 + (w * A_IN + i) * 16 + lrow;
         a_ok[i] = m < p.M;
-        a_base[i] = 0; a_ty[i] = 0; a_tx[i] = 0;
+        a_base[i] = 0; a_ty[i] = 0; a_tx[i] = 0; a_mask[i] = 0;
         if (a_ok[i]) {
-            if (!conv) {
+            if (CONV == 0) {
                 a_base[i] = (size_t)m * p.lda;
+            } else if (CONV == 2) {
+                const int hw = p.conv.Hout * p.conv.Wout;
+                const int b = m / hw, rem = m - b * hw;
+                const int yo = rem / p.conv.Wout, xo = rem - yo * p.conv.Wout;
+                a_base[i] = (((size_t)b * p.conv.Hin + yo) * p.conv.Win + xo) * p.conv.Cin + kc * 8;   // centre pixel + lane chunk
+#pragma unroll
+                for (int tp = 0; tp < 9; ++tp) {
+                    const int ty = yo + p.conv.off + (tp / 3) * p.conv.kmul, tx = xo + p.conv.off + (tp % 3) * p.conv.kmul;
+                    if (ty >= 0 && ty < p.conv.lim_h && tx >= 0 && tx < p.conv.lim_w) a_mask[i] |= 1u << tp;
+                }
             } else {
                 const int hw = p.conv.Hout * p.conv.Wout;
                 const int b = m / hw, rem = m - b * hw;
@@ -360,10 +377,33 @@ __global__ __launch_bounds__(256, (DmaOcc<BM, BN, NST>::v)) void gemm_dma_kernel
     int k = kbeg + kc * 8;
     int tap = 0, ci = k;
     if (conv) { tap = k / p.conv.Cin; ci = k - tap * p.conv.Cin; }
+    // CONV == 2: wave-uniform walk (kq = first k of the stage, its tap and channel offset), kept in SGPRs
+    int kq = kbeg, qtap = 0, qci = 0;
+    if (CONV == 2) { qtap = kbeg / p.conv.Cin; qci = kbeg - qtap * p.conv.Cin; }
 
     auto issue_stage = [&](int buf) {
         half_t* As = smem + buf * STAGE;
         half_t* Bs = As + BM * BK;
+        if (CONV == 2) {
+            const bool kokq = kq < kend;                    // K = 9*Cin and the split size are multiples of 32: whole stages only
+            const int qky = qtap / 3, qkx = qtap - qky * 3;
+            const long delta = ((long)(p.conv.off + qky * p.conv.kmul) * p.conv.Win + (p.conv.off + qkx * p.conv.kmul)) * p.conv.Cin + qci;
+#pragma unroll
+            for (int i = 0; i < A_IN; ++i) {
+                const bool ok = kokq && ((a_mask[i] >> qtap) & 1u);
+                const half_t* src = ok ? p.A + (long)a_base[i] + delta : zero_page;
+                CLORA_GLDS16(src, As + (w * A_IN + i) * 16 * BK);
+            }
+#pragma unroll
+            for (int i = 0; i < B_IN; ++i) {
+                const half_t* src = (b_ok[i] && kokq) ? p.B + b_base[i] + kq + kc * 8 : zero_page;
+                CLORA_GLDS16(src, Bs + (w * B_IN + i) * 16 * BK);
+            }
+            kq += BK;
+            qci += BK;
+            if (qci >= p.conv.Cin) { qci = 0; ++qtap; }
+            return;
+        }
         const bool kok = k < kend;
         int ky = 0, kx = 0;
         if (conv) { ky = tap / p.conv.ksize; kx = tap - ky * p.conv.ksize; }
@@ -702,11 +742,26 @@ __global__ __launch_bounds__(256) void conv_weight_pack_kernel(const float* w, i
     }
 }
 
+// which gather the DMA main loop is instantiated for (see gemm_dma_kernel)
+int conv_mode(const GemmArgs& a) {
+    const clora_conv_t& c = a.conv;
+    if (!c.enabled) return 0;
+    const bool fast = c.ksize == 3 && c.mul == 1 && c.shift == 0 && c.need_even == 0 && (c.kmul == 1 || c.kmul == -1) &&
+                      (c.Cin % 32) == 0 && (a.k_per_split % 32) == 0 && c.lim_h == c.Hin && c.lim_w == c.Win;
+    return fast ? 2 : 1;
+}
+
 template <int BM, int BN, int WM, int WN, int NST = 3>
 int launch_gemm(GemmArgs& a, int splits, hipStream_t s, bool dma) {
     a.tiles_n = clora_cdiv(a.N, BN);
     const int tiles_m = clora_cdiv(a.M, BM);
-    if (dma) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, WM, WN, NST>), dim3(tiles_m * a.tiles_n, splits), dim3(256), 0, s, a);
+    const dim3 grid(tiles_m * a.tiles_n, splits);
+    if (dma) {
+        const int cm = conv_mode(a);
+        if (cm == 0) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, WM, WN, NST, 0>), grid, dim3(256), 0, s, a);
+        else if (cm == 1) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, WM, WN, NST, 1>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, WM, WN, NST, 2>), grid, dim3(256), 0, s, a);
+    }
     else hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN>), dim3(tiles_m * a.tiles_n, splits), dim3(256), 0, s, a);
     return clora_check_launch();
 }

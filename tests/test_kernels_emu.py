@@ -84,3 +84,10 @@ def test_softmax_rows(rows, cols):
 
 def test_conv_padded_channels_pack_and_oihw_grad():
     KC.case_conv_padded_channels("cpu")
+
+
+@pytest.mark.parametrize("tile,split", [(1, 1), (3, 2), (5, 3)])
+def test_conv_fast_path_uniform_taps(tile, split):
+    """3x3 stride-1 convs with Cin % 32 == 0 take the wave-uniform tap walk (CONV == 2) in forward and dgrad"""
+    KC.case_conv("cpu", 1, 6, 5, 32, 64, tile_cfg=tile)
+    KC.case_conv("cpu", 2, 4, 4, 64, 32, tile_cfg=tile)
