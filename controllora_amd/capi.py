@@ -14,7 +14,7 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "_build", "libclora.so")
+LIB_PATH = os.environ.get("CLORA_LIB_PATH") or os.path.join(_HERE, "_build", "libclora.so")   # override: A/B of kernel builds
 
 OK, ERR_ARG, ERR_LAUNCH, ERR_WORKSPACE = 0, -1, -2, -3
 _ERR = {ERR_ARG: "bad argument", ERR_LAUNCH: "kernel launch failed", ERR_WORKSPACE: "workspace too small"}

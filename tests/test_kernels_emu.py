@@ -91,3 +91,5 @@ def test_conv_fast_path_uniform_taps(tile, split):
     """3x3 stride-1 convs with Cin % 32 == 0 take the wave-uniform tap walk (CONV == 2) in forward and dgrad"""
     KC.case_conv("cpu", 1, 6, 5, 32, 64, tile_cfg=tile)
     KC.case_conv("cpu", 2, 4, 4, 64, 32, tile_cfg=tile)
+    for kw in (dict(stride=2, pad=1), dict(asym=True, stride=2, pad=0), dict(ups=True)):     # generic gather at Cin % 32 == 0
+        KC.case_conv("cpu", 1, 6, 6, 32, 32, tile_cfg=tile, **kw)

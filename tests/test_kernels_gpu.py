@@ -95,3 +95,11 @@ def test_softmax_rows(rows, cols):
 
 def test_conv_padded_channels_pack_and_oihw_grad():
     KC.case_conv_padded_channels(DEV)
+
+
+@pytest.mark.parametrize("kw", [dict(stride=2, pad=1), dict(asym=True, stride=2, pad=0), dict(ups=True)])
+def test_conv_fast_path_variants(kw):
+    """strided / asymmetric-pad / upsampled 3x3 gathers and their dgrads at Cin % 32 == 0 (generic gather path; the
+    wave-uniform fast path is reserved for stride-1: a tabulated-offset generalisation measured no faster than generic)"""
+    KC.case_conv(DEV, 2, 16, 16, 64, 96, **kw)
+    KC.case_conv(DEV, 1, 32, 32, 320, 320, **kw)
