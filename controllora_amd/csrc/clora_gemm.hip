@@ -291,7 +291,7 @@ __device__ __attribute__((aligned(16))) const unsigned g_clora_zero16[4] = {0u, 
 template <int BM, int BN, int NST> struct DmaOcc {
     static constexpr int lds = NST * (BM + BN) * 32 * 2;
     static constexpr int fit = (160 * 1024) / lds;
-    static constexpr int cap = (BM * BN >= 128 * 128) ? 3 : ((BM * BN >= 128 * 64) ? 4 : 6);
+    static constexpr int cap = (BM * BN >= 128 * 128) ? 3 : ((BM * BN >= 128 * 64) ? 4 : 5);   // 64x64 at 6 would spill (80 VGPRs)
     static constexpr int v = fit < cap ? fit : cap;
 };
 

@@ -28,7 +28,9 @@ for name, B, H, Ci, Co, tile, sk in cases:
     tot += us
     print(f"{name:28s} tile{tile} sk{sk} {us:8.1f} us {2.0*M*Co*9*Ci/us/1e6:7.1f} TF", flush=True)
 for name, M, N, Kd, tile, sk in [("ff1 16384x2560x320", 16384, 2560, 320, 1, 1), ("ff2 16384x320x1280", 16384, 320, 1280, 1, 1), ("big 8192^3", 8192, 8192, 8192, 1, 1),
-                                 ("ff1.s1 4096x5120x640", 4096, 5120, 640, 1, 1), ("qkv 16384x960x320 t2", 16384, 960, 320, 2, 1), ("out 4096x640x640 t3", 4096, 640, 640, 3, 1)]:
+                                 ("ff1.s1 4096x5120x640", 4096, 5120, 640, 1, 1), ("qkv 16384x960x320 t2", 16384, 960, 320, 2, 1), ("out 4096x640x640 t3", 4096, 640, 640, 3, 1),
+                                 ("proj 1024x1280x1280 t3", 1024, 1280, 1280, 3, 1), ("proj 1024x1280x1280 t6", 1024, 1280, 1280, 6, 1),
+                                 ("q 16384x320x320 t3", 16384, 320, 320, 3, 1), ("ff2.s2 1024x1280x5120 t3s4", 1024, 1280, 5120, 3, 4)]:
     A = torch.randn(M, Kd, device=dev).half()
     Bw = (torch.randn(N, Kd, device=dev) / math.sqrt(Kd)).half()
     out = torch.empty(M, N, device=dev, dtype=torch.float16)
