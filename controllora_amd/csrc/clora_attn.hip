@@ -14,8 +14,9 @@
 //     row reductions need only two shuffles (across the 4 lane groups);
 //   * a C-layout tile (lane: col = lane&15, rows 4*(lane>>4)+r) is fed back as the B operand of the
 //     next MFMA WITHOUT any shuffle or LDS round trip: two 16-row tiles give the 8 k-slots of a lane,
-//     and the A operand (V^T, K^T, Q^T, dO^T staged transposed in LDS) is read with the same slot
-//     assignment -- the hardware only pairs slot e of lane-group g of A with slot e of group g of B;
+//     and the A operand (V^T, K^T, Q^T, dO^T) is fetched with the same slot assignment from ROW-MAJOR LDS tiles by
+//     the transpose read ds_read_b64_tr_b16 (frag_tr) -- the hardware only pairs slot e of lane-group g of A with
+//     slot e of group g of B; no transposed copies, no 2-byte scatter stores;
 //   * head dims 40 / 80 / 160 are zero-padded to 64 / 96 / 160 along the contraction dim only.
 #include "clora_common.h"
 #include "../../include/clora.h"
@@ -38,40 +39,21 @@ constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kLn2 = 0.6931471805599453f;
 constexpr float kNegBig = -1.0e30f;
 
-// [ROWS x DP] row-major tile, zero padded, 16-byte coalesced along d
-template <int ROWS, int DP, int LD>
-__device__ __forceinline__ void stage_rows(half_t* dst, const half_t* src, int ld, int rows_valid, int D, int t) {
-    constexpr int CPR = DP / 8;
-    for (int c = t; c < ROWS * CPR; c += 256) {
-        const int row = c / CPR, col = (c - row * CPR) * 8;
-        half8 v = zero8();
-        if (row < rows_valid && col < D) v = ld8(src + (size_t)row * ld + col);
-        st8(dst + row * LD + col, v);
-    }
-}
-// transposed tile dst[d][row] for d < DROWS (lanes walk the rows so the 2-byte LDS writes do not conflict)
-template <int ROWS, int DROWS, int LDT>
-__device__ __forceinline__ void stage_cols(half_t* dst, const half_t* src, int ld, int rows_valid, int D, int t) {
-    constexpr int CPC = DROWS / 8;
-    for (int c = t; c < ROWS * CPC; c += 256) {
-        const int row = c % ROWS, col = (c / ROWS) * 8;
-        half8 v = zero8();
-        if (row < rows_valid && col < D) v = ld8(src + (size_t)row * ld + col);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) dst[(col + e) * LDT + row] = v[e];
-    }
-}
-// A operand from a transposed tile: 8 k-slots = rows {pair*32 + 4g .. +3} and {pair*32 + 16 + 4g .. +3}
-template <int LDT>
-__device__ __forceinline__ half8 frag_cols(const half_t* tile, int drow, int pair, int g) {
-    const half4v a = ld4(tile + drow * LDT + pair * 32 + 4 * g);
-    const half4v b = ld4(tile + drow * LDT + pair * 32 + 16 + 4 * g);
+// A operand (k-slots = rows {pair*32 + 4g .. +3} and {pair*32 + 16 + 4g .. +3}, operand row = column col0 + li) straight
+// from a ROW-MAJOR tile [row][col] with the gfx950 transpose read: the 16 lanes of group g
+// address the 4 rows {pair*32 + 4g .. +3} x 16 columns {col0 ..} (4 lanes per row, 4 columns each) and lane li receives
+// column col0 + li of those 4 rows; a second read 16 rows further down gives the other 4 k-slots.  The tile is written
+// with 16-byte stores (no transposed 2-byte scatter) and needs no second, transposed copy in LDS.
+template <int LD>
+__device__ __forceinline__ half8 frag_tr(const half_t* tile, int col0, int pair, int g, int l) {
+    const half_t* q = tile + (pair * 32 + 4 * g + ((l & 15) >> 2)) * LD + col0 + (l & 3) * 4;
+    const half4v a = CLORA_DS_READ_TR16(q), b = CLORA_DS_READ_TR16(q + 16 * LD);
     half8 r;
     r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; r[3] = a[3];
     r[4] = b[0]; r[5] = b[1]; r[6] = b[2]; r[7] = b[3];
     return r;
 }
-// B operand from two C-layout tiles (same slot assignment as frag_cols)
+// B operand from two C-layout tiles (same slot assignment as frag_tr)
 __device__ __forceinline__ half8 frag_from_acc(floatx4 lo, floatx4 hi) {
     half8 r;
     r[0] = (half_t)lo[0]; r[1] = (half_t)lo[1]; r[2] = (half_t)lo[2]; r[3] = (half_t)lo[3];
@@ -108,44 +90,6 @@ __device__ __forceinline__ void tile_store_rows(const TileRegs<ROWS, DP>& r, hal
         if (c < ROWS * CPR) { const int row = c / CPR, col = (c - row * CPR) * 8; st8(dst + row * LD + col, r.v[i]); }
     }
 }
-template <int ROWS, int DP, int LDT>
-__device__ __forceinline__ void tile_store_cols(const TileRegs<ROWS, DP>& r, half_t* dst, int t) {
-    constexpr int CPR = DP / 8;
-#pragma unroll
-    for (int i = 0; i < TileRegs<ROWS, DP>::N; ++i) {
-        const int c = t + 256 * i;
-        if (c < ROWS * CPR) {
-            const int row = c % ROWS, col = (c / ROWS) * 8;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) dst[(col + e) * LDT + row] = r.v[i][e];
-        }
-    }
-}
-
-// stores for tiles that were loaded with the ROW_FAST mapping (lane walks the rows)
-template <int ROWS, int DP, int LD>
-__device__ __forceinline__ void tile_store_rows_rf(const TileRegs<ROWS, DP>& r, half_t* dst, int t) {
-    constexpr int CPR = DP / 8;
-#pragma unroll
-    for (int i = 0; i < TileRegs<ROWS, DP>::N; ++i) {
-        const int c = t + 256 * i;
-        if (c < ROWS * CPR) { const int row = c % ROWS, col = (c / ROWS) * 8; st8(dst + row * LD + col, r.v[i]); }
-    }
-}
-template <int ROWS, int DP, int DROWS, int LDT>
-__device__ __forceinline__ void tile_store_cols_n(const TileRegs<ROWS, DP>& r, half_t* dst, int t) {
-    constexpr int CPR = DP / 8;
-#pragma unroll
-    for (int i = 0; i < TileRegs<ROWS, DP>::N; ++i) {
-        const int c = t + 256 * i;
-        const int row = c % ROWS, col = (c / ROWS) * 8;
-        if (c < ROWS * CPR && col < DROWS) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) dst[(col + e) * LDT + row] = r.v[i][e];
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------------ forward
 // __launch_bounds__(256, 2) for head dims <= 64: with a 256-register budget the compiler keeps the MFMA accumulators in
 // VGPRs; with the default (one block per CU, 512 registers) it parks them in AGPRs and the softmax / rescale VALU work
@@ -153,10 +97,10 @@ __device__ __forceinline__ void tile_store_cols_n(const TileRegs<ROWS, DP>& r, h
 // spill at 256 registers and keep the default.
 template <int DP, int DT>
 __global__ __launch_bounds__(256, (DP <= 64 ? 2 : 1)) void attn_fwd_kernel(AttnArgs p) {
-    constexpr int BKV = 64, LDK = DP + 8, LDV = BKV + 8, KS = DP / 32, DV = DT * 16;
-    __shared__ __attribute__((aligned(16))) half_t smem[BKV * LDK + DV * LDV];
+    constexpr int BKV = 64, LDK = DP + 8, LDV = DT * 16 + 8, KS = DP / 32, DV = DT * 16;
+    __shared__ __attribute__((aligned(16))) half_t smem[BKV * LDK + BKV * LDV];
     half_t* Ks = smem;
-    half_t* Vt = smem + BKV * LDK;
+    half_t* Vs = smem + BKV * LDK;                         // V row-major [key][d]; read transposed (frag_tr) for P.V
     const int t = threadIdx.x, w = t >> 6, l = t & 63, g = l >> 4, li = l & 15;
     const int b = blockIdx.y / p.H, h = blockIdx.y % p.H;
     const int q0 = blockIdx.x * 128 + w * 32;
@@ -186,18 +130,18 @@ __global__ __launch_bounds__(256, (DP <= 64 ? 2 : 1)) void attn_fwd_kernel(AttnA
     {
         const int rows0 = p.Nk < BKV ? p.Nk : BKV;
         tile_load<BKV, DP, false>(rk, kbase, p.ldk, rows0, D, t);
-        tile_load<BKV, DV, true>(rv, vbase, p.ldv, rows0, D, t);
+        tile_load<BKV, DV, false>(rv, vbase, p.ldv, rows0, D, t);
     }
     for (int kv0 = 0; kv0 < p.Nk; kv0 += BKV) {
         const int rows = (p.Nk - kv0 < BKV) ? p.Nk - kv0 : BKV;
         __syncthreads();                                   // previous tile fully consumed
         tile_store_rows<BKV, DP, LDK>(rk, Ks, t);
-        tile_store_cols<BKV, DV, LDV>(rv, Vt, t);
+        tile_store_rows<BKV, DV, LDV>(rv, Vs, t);
         __syncthreads();
         if (kv0 + BKV < p.Nk) {                            // prefetch the next tile while this one is processed
             const int nrows = (p.Nk - kv0 - BKV < BKV) ? p.Nk - kv0 - BKV : BKV;
             tile_load<BKV, DP, false>(rk, kbase + (size_t)(kv0 + BKV) * p.ldk, p.ldk, nrows, D, t);
-            tile_load<BKV, DV, true>(rv, vbase + (size_t)(kv0 + BKV) * p.ldv, p.ldv, nrows, D, t);
+            tile_load<BKV, DV, false>(rv, vbase + (size_t)(kv0 + BKV) * p.ldv, p.ldv, nrows, D, t);
         }
 
         floatx4 s[4][2];
@@ -249,7 +193,7 @@ __global__ __launch_bounds__(256, (DP <= 64 ? 2 : 1)) void attn_fwd_kernel(AttnA
             const half8 pb1 = frag_from_acc(s[2 * j][1], s[2 * j + 1][1]);
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
-                const half8 a = frag_cols<LDV>(Vt, dt * 16 + li, j, g);
+                const half8 a = frag_tr<LDV>(Vs, dt * 16, j, g, l);
                 oacc[dt][0] = mfma16(a, pb0, oacc[dt][0]);
                 oacc[dt][1] = mfma16(a, pb1, oacc[dt][1]);
             }
@@ -281,11 +225,10 @@ __global__ __launch_bounds__(256, (DP <= 64 ? 2 : 1)) void attn_fwd_kernel(AttnA
 // ------------------------------------------------------------------------------------------ dQ
 template <int DP, int DT, int BKV>
 __global__ __launch_bounds__(256, (DP <= 64 ? 2 : 1)) void attn_bwd_dq_kernel(AttnArgs p) {
-    constexpr int LDK = DP + 8, LDT = BKV + 8, KS = DP / 32, KT = BKV / 16, NP = BKV / 32;
-    __shared__ __attribute__((aligned(16))) half_t smem[2 * BKV * LDK + DT * 16 * LDT];
-    half_t* Ks = smem;
+    constexpr int LDK = DP + 8, KS = DP / 32, KT = BKV / 16, NP = BKV / 32;
+    __shared__ __attribute__((aligned(16))) half_t smem[2 * BKV * LDK];
+    half_t* Ks = smem;                                     // K row-major: A operand of S^T as is, of dQ^T through frag_tr
     half_t* Vs = smem + BKV * LDK;
-    half_t* Kt = smem + 2 * BKV * LDK;
     const int t = threadIdx.x, w = t >> 6, l = t & 63, g = l >> 4, li = l & 15;
     const int b = blockIdx.y / p.H, h = blockIdx.y % p.H;
     const int q0 = blockIdx.x * 128 + w * 32;
@@ -339,19 +282,18 @@ __global__ __launch_bounds__(256, (DP <= 64 ? 2 : 1)) void attn_bwd_dq_kernel(At
     TileRegs<BKV, DP> rk, rv;
     {
         const int rows0 = p.Nk < BKV ? p.Nk : BKV;
-        tile_load<BKV, DP, true>(rk, kbase, p.ldk, rows0, D, t);
+        tile_load<BKV, DP, false>(rk, kbase, p.ldk, rows0, D, t);
         tile_load<BKV, DP, false>(rv, vbase, p.ldv, rows0, D, t);
     }
     for (int kv0 = 0; kv0 < p.Nk; kv0 += BKV) {
         const int rows = (p.Nk - kv0 < BKV) ? p.Nk - kv0 : BKV;
         __syncthreads();
-        tile_store_rows_rf<BKV, DP, LDK>(rk, Ks, t);           // K once in registers -> row-major AND transposed tiles
-        tile_store_cols_n<BKV, DP, DT * 16, LDT>(rk, Kt, t);
+        tile_store_rows<BKV, DP, LDK>(rk, Ks, t);
         tile_store_rows<BKV, DP, LDK>(rv, Vs, t);
         __syncthreads();
         if (kv0 + BKV < p.Nk) {
             const int nrows = (p.Nk - kv0 - BKV < BKV) ? p.Nk - kv0 - BKV : BKV;
-            tile_load<BKV, DP, true>(rk, kbase + (size_t)(kv0 + BKV) * p.ldk, p.ldk, nrows, D, t);
+            tile_load<BKV, DP, false>(rk, kbase + (size_t)(kv0 + BKV) * p.ldk, p.ldk, nrows, D, t);
             tile_load<BKV, DP, false>(rv, vbase + (size_t)(kv0 + BKV) * p.ldv, p.ldv, nrows, D, t);
         }
 
@@ -385,7 +327,7 @@ __global__ __launch_bounds__(256, (DP <= 64 ? 2 : 1)) void attn_bwd_dq_kernel(At
             const half8 b1 = frag_from_acc(s[2 * j][1], s[2 * j + 1][1]);
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
-                const half8 a = frag_cols<LDT>(Kt, dt * 16 + li, j, g);
+                const half8 a = frag_tr<LDK>(Ks, dt * 16, j, g, l);
                 acc[dt][0] = mfma16(a, b0, acc[dt][0]);
                 acc[dt][1] = mfma16(a, b1, acc[dt][1]);
             }
@@ -412,13 +354,11 @@ __global__ __launch_bounds__(256, (DP <= 64 ? 2 : 1)) void attn_bwd_dq_kernel(At
 // ------------------------------------------------------------------------------------------ dK, dV
 template <int DP, int DT, int BQT>
 __global__ __launch_bounds__(256, (DP <= 64 ? 2 : 1)) void attn_bwd_dkv_kernel(AttnArgs p) {
-    constexpr int LDK = DP + 8, LDT = BQT + 8, KS = DP / 32, QT = BQT / 16, NP = BQT / 32;
-    constexpr int HALVES = 2 * BQT * LDK + 2 * DT * 16 * LDT;
+    constexpr int LDK = DP + 8, KS = DP / 32, QT = BQT / 16, NP = BQT / 32;
+    constexpr int HALVES = 2 * BQT * LDK;
     __shared__ __attribute__((aligned(16))) half_t smem[HALVES + 4 * BQT];
-    half_t* Qs = smem;
+    half_t* Qs = smem;                                     // Q, dO row-major: A operands of S / dP as is, of dK / dV through frag_tr
     half_t* dOs = smem + BQT * LDK;
-    half_t* Qt = smem + 2 * BQT * LDK;
-    half_t* dOt = Qt + DT * 16 * LDT;
     float* Ls = reinterpret_cast<float*>(smem + HALVES);
     float* Ds = Ls + BQT;
     const int t = threadIdx.x, w = t >> 6, l = t & 63, g = l >> 4, li = l & 15;
@@ -449,13 +389,11 @@ __global__ __launch_bounds__(256, (DP <= 64 ? 2 : 1)) void attn_bwd_dkv_kernel(A
         const half_t* dog = p.dO + ((size_t)b * p.Nq + qq) * p.lddo + h * D;
         __syncthreads();
         {
-            TileRegs<BQT, DP> rq, rdo;                       // each operand is fetched once and stored twice
-            tile_load<BQT, DP, true>(rq, qg_, p.ldq, rows, D, t);
-            tile_load<BQT, DP, true>(rdo, dog, p.lddo, rows, D, t);
-            tile_store_rows_rf<BQT, DP, LDK>(rq, Qs, t);
-            tile_store_cols_n<BQT, DP, DT * 16, LDT>(rq, Qt, t);
-            tile_store_rows_rf<BQT, DP, LDK>(rdo, dOs, t);
-            tile_store_cols_n<BQT, DP, DT * 16, LDT>(rdo, dOt, t);
+            TileRegs<BQT, DP> rq, rdo;
+            tile_load<BQT, DP, false>(rq, qg_, p.ldq, rows, D, t);
+            tile_load<BQT, DP, false>(rdo, dog, p.lddo, rows, D, t);
+            tile_store_rows<BQT, DP, LDK>(rq, Qs, t);
+            tile_store_rows<BQT, DP, LDK>(rdo, dOs, t);
         }
         if (t < BQT) {
             const size_t si = ((size_t)b * p.H + h) * p.Nq + qq + t;
@@ -499,8 +437,8 @@ __global__ __launch_bounds__(256, (DP <= 64 ? 2 : 1)) void attn_bwd_dkv_kernel(A
             const half8 d1 = frag_from_acc(dp[2 * j][1], dp[2 * j + 1][1]);
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
-                const half8 ao = frag_cols<LDT>(dOt, dt * 16 + li, j, g);
-                const half8 aq = frag_cols<LDT>(Qt, dt * 16 + li, j, g);
+                const half8 ao = frag_tr<LDK>(dOs, dt * 16, j, g, l);
+                const half8 aq = frag_tr<LDK>(Qs, dt * 16, j, g, l);
                 dvacc[dt][0] = mfma16(ao, p0, dvacc[dt][0]);
                 dvacc[dt][1] = mfma16(ao, p1, dvacc[dt][1]);
                 dkacc[dt][0] = mfma16(aq, d0, dkacc[dt][0]);
