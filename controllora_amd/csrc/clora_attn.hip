@@ -311,16 +311,26 @@ __global__ __launch_bounds__(256, (DP <= 64 ? 2 : 1)) void attn_bwd_dq_kernel(At
                 dp[kt][0] = mfma16(av, dof[0][ks], dp[kt][0]);
                 dp[kt][1] = mfma16(av, dof[1][ks], dp[kt][1]);
             }
+        if (rows == BKV) {                                 // full tile (all but the last one): no per-element key mask
 #pragma unroll
-        for (int kt = 0; kt < KT; ++kt)
+            for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-            for (int qg = 0; qg < 2; ++qg)
+                for (int qg = 0; qg < 2; ++qg)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const bool ok = (kt * 16 + 4 * g + r) < rows;
-                    const float pv = ok ? CLORA_EXP2(s[kt][qg][r] - Lq[qg]) : 0.f;
-                    s[kt][qg][r] = pv * (dp[kt][qg][r] - Dq[qg]);  // dS^T
-                }
+                    for (int r = 0; r < 4; ++r)
+                        s[kt][qg][r] = CLORA_EXP2(s[kt][qg][r] - Lq[qg]) * (dp[kt][qg][r] - Dq[qg]);  // dS^T
+        } else {
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                for (int qg = 0; qg < 2; ++qg)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const bool ok = (kt * 16 + 4 * g + r) < rows;
+                        const float pv = ok ? CLORA_EXP2(s[kt][qg][r] - Lq[qg]) : 0.f;
+                        s[kt][qg][r] = pv * (dp[kt][qg][r] - Dq[qg]);
+                    }
+        }
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
             const half8 b0 = frag_from_acc(s[2 * j][0], s[2 * j + 1][0]);
