@@ -50,7 +50,8 @@ def test_attention(B, H, Nq, Nk, D, fused):
 
 
 @pytest.mark.parametrize("B,HW,C,G,silu,train", [(2, 50, 320, 32, True, False), (1, 37, 64, 8, False, False),
-                                                 (2, 64, 32, 32, True, True), (1, 9, 2560, 32, True, False)])
+                                                 (2, 64, 32, 32, True, True), (1, 9, 2560, 32, True, False),
+                                                 (2, 300, 64, 8, True, False), (2, 256, 320, 32, False, False)])
 def test_groupnorm(B, HW, C, G, silu, train):
     KC.case_groupnorm("cpu", B, HW, C, G, silu, train_params=train)
 

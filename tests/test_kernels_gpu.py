@@ -61,7 +61,8 @@ def test_attention(B, H, Nq, Nk, D, fused):
 @pytest.mark.parametrize("B,HW,C,G,silu,train", [(2, 4096, 320, 32, True, False), (2, 1024, 960, 32, True, False),
                                                  (1, 64, 2560, 32, True, False), (2, 4096, 32, 32, True, True),
                                                  (1, 1024, 640, 32, False, False), (1, 37, 64, 8, False, True),
-                                                 (4, 256, 1280, 32, True, True), (4, 1024, 1920, 32, True, False)])
+                                                 (4, 256, 1280, 32, True, True), (4, 1024, 1920, 32, True, False),
+                                                 (4, 256, 1280, 32, True, False), (4, 64, 2560, 32, False, False), (4, 256, 640, 32, True, False)])
 def test_groupnorm(B, HW, C, G, silu, train):
     KC.case_groupnorm(DEV, B, HW, C, G, silu, train_params=train)
 
