@@ -140,8 +140,8 @@ def gemm(A: torch.Tensor, Bw: torch.Tensor, M: int, N: int, K: int, *, lda: Opti
         assert bias.dtype == f32 and bias.numel() == N
         e.bias = ptr(bias)
     if rowadd is not None:
-        assert rowadd.dtype == f16 and rowadd.shape[-1] == N and rowadd.is_contiguous()
-        e.rowadd, e.rows_per_batch, e.ld_rowadd = ptr(rowadd), rows_per_batch, N
+        assert rowadd.dtype == f16 and rowadd.dim() == 2 and rowadd.shape[1] == N and rowadd.stride(1) == 1 and rowadd.stride(0) % 8 == 0
+        e.rowadd, e.rows_per_batch, e.ld_rowadd = ptr(rowadd), rows_per_batch, rowadd.stride(0)
     if residual is not None:
         assert residual.dtype == f16 and residual.stride(-1) == 1
         e.residual, e.ldr = ptr(residual), (residual.stride(0) if residual.dim() == 2 else N)

@@ -271,10 +271,13 @@ class ResnetBlock2D(nn.Module):
         self.conv2 = Conv3x3(cout, cout)
         self.conv_shortcut = Conv1x1(cin, cout) if cin != cout else None
 
-    def forward(self, x, temb_act, H, W):
+    def forward(self, x, temb_act, H, W, temb_proj=None):
         B, N, Cin = x.shape
-        with torch.no_grad():  # the time embedding has no trainable ancestor
-            t = self.time_emb_proj(temb_act)
+        if temb_proj is not None:          # this block's column slice of the UNet's batched time-embedding projections
+            t = temb_proj
+        else:
+            with torch.no_grad():          # the time embedding has no trainable ancestor
+                t = self.time_emb_proj(temb_act)
         n, xr = self.norm1.fork(x, True) if (torch.is_grad_enabled() and x.requires_grad) else (self.norm1(x, True), x)
         h = self.conv1(n.reshape(B * N, Cin), B, H, W, rowadd=t)
         Cout = h.shape[1]
@@ -439,11 +442,34 @@ class UNet2DConditionModel(nn.Module):
             e = self.time_embedding.linear_2(K.silu(e))
             return K.silu(e)   # every resnet applies SiLU to emb before time_emb_proj
 
+    def _temb_projections(self, temb_act):
+        """All 22 `time_emb_proj` linears (M = batch rows each) as ONE GEMM against the row-concatenated weights; every
+        ResnetBlock2D then reads its column slice as the conv1 row-add.  The concatenation is cached on the weights'
+        versions like every other frozen pack."""
+        layers = getattr(self, "_temb_layers", None)
+        if layers is None:
+            layers = self._temb_layers = [m.time_emb_proj for m in self.modules() if isinstance(m, ResnetBlock2D)]
+        key = tuple(k for l in layers for k in l._key())
+        if getattr(self, "_temb_cat_key", None) != key:
+            w = torch.cat([l.weight.detach() for l in layers], 0)
+            b = torch.cat([l.bias.detach() for l in layers], 0)
+            self._temb_cat, self._temb_cat_key = ops.LinearPack(w, b), key
+            offs, o = {}, 0
+            for l in layers:
+                offs[id(l)] = (o, l.weight.shape[0])
+                o += l.weight.shape[0]
+            self._temb_offs = offs
+        with torch.no_grad():
+            allp = ops.frozen_linear(temb_act, self._temb_cat)
+        return {k: allp[:, o:o + n] for k, (o, n) in self._temb_offs.items()}
+
     def forward(self, sample, timestep, encoder_hidden_states, cross_attention_kwargs=None, return_dict=True):
         kw = cross_attention_kwargs or {}
         B, Cin, H, W = sample.shape
         dev = sample.device
         temb_act = self.time_embed(timestep, B, dev)
+        tp = self._temb_projections(temb_act)
+        tproj = lambda r: tp[id(r.time_emb_proj)]
         ehs = encoder_hidden_states.to(f16).contiguous()
         x = sample.new_zeros((B, H, W, self.conv_in.pack().Cip), dtype=f16)
         x[..., :Cin] = sample.permute(0, 2, 3, 1)
@@ -451,7 +477,7 @@ class UNet2DConditionModel(nn.Module):
         skips = [(x, H, W)]
         for blk in self.down_blocks:
             for j, r in enumerate(blk.resnets):
-                x = r(x, temb_act, H, W)
+                x = r(x, temb_act, H, W, tproj(r))
                 if blk.has_attn:
                     x = blk.attentions[j](x, ehs, kw)
                 skips.append((x, H, W))
@@ -459,13 +485,13 @@ class UNet2DConditionModel(nn.Module):
                 x = blk.downsamplers[0](x, H, W)
                 H, W = H // 2, W // 2
                 skips.append((x, H, W))
-        x = self.mid_block.resnets[0](x, temb_act, H, W)
+        x = self.mid_block.resnets[0](x, temb_act, H, W, tproj(self.mid_block.resnets[0]))
         x = self.mid_block.attentions[0](x, ehs, kw)
-        x = self.mid_block.resnets[1](x, temb_act, H, W)
+        x = self.mid_block.resnets[1](x, temb_act, H, W, tproj(self.mid_block.resnets[1]))
         for blk in self.up_blocks:
             for j, r in enumerate(blk.resnets):
                 s, _, _ = skips.pop()
-                x = r(ops.concat_channels(x, s), temb_act, H, W)
+                x = r(ops.concat_channels(x, s), temb_act, H, W, tproj(r))
                 if blk.has_attn:
                     x = blk.attentions[j](x, ehs, kw)
             if blk.upsamplers is not None:
