@@ -296,7 +296,8 @@ template <int BM, int BN, int NST> struct DmaOcc {
 };
 
 // CONV: 0 = plain GEMM rows; 1 = generic gather (strided / asymmetric-pad / upsampled convs and their dgrads);
-// 2 = the common case -- 3x3, stride 1, Cin % 32 == 0 (every ResnetBlock conv and its dgrad): a BK=32 step then lies
+// 2 = the common case -- 3x3, stride 1 or 2 without upsampling / parity holes, Cin % 32 == 0 (every ResnetBlock conv and
+// its dgrad, the down-samplers, the hint-encoder stages): a BK=32 step then lies
 // inside ONE filter tap for the whole wave, so the tap walk and its address delta are scalar (SALU) work and each
 // DMA instruction costs a bit test, an add and a select.  The generic path spends ~35 VALU/branch instructions per DMA
 // instruction; with four of them per 16 MFMAs that made instruction issue, not the matrix pipe, the limiter of the conv
@@ -350,10 +351,11 @@ __global__ __launch_bounds__(256, (DmaOcc<BM, BN, NST>::v)) void gemm_dma_kernel
                 const int hw = p.conv.Hout * p.conv.Wout;
                 const int b = m / hw, rem = m - b * hw;
                 const int yo = rem / p.conv.Wout, xo = rem - yo * p.conv.Wout;
-                a_base[i] = (((size_t)b * p.conv.Hin + yo) * p.conv.Win + xo) * p.conv.Cin + kc * 8;   // centre pixel + lane chunk
+                const int yc = yo * p.conv.mul, xc = xo * p.conv.mul;                      // stride: still linear in the tap
+                a_base[i] = (((size_t)b * p.conv.Hin + yc) * p.conv.Win + xc) * p.conv.Cin + kc * 8;   // centre pixel + lane chunk
 #pragma unroll
                 for (int tp = 0; tp < 9; ++tp) {
-                    const int ty = yo + p.conv.off + (tp / 3) * p.conv.kmul, tx = xo + p.conv.off + (tp % 3) * p.conv.kmul;
+                    const int ty = yc + p.conv.off + (tp / 3) * p.conv.kmul, tx = xc + p.conv.off + (tp % 3) * p.conv.kmul;
                     if (ty >= 0 && ty < p.conv.lim_h && tx >= 0 && tx < p.conv.lim_w) a_mask[i] |= 1u << tp;
                 }
             } else {
@@ -746,7 +748,7 @@ __global__ __launch_bounds__(256) void conv_weight_pack_kernel(const float* w, i
 int conv_mode(const GemmArgs& a) {
     const clora_conv_t& c = a.conv;
     if (!c.enabled) return 0;
-    const bool fast = c.ksize == 3 && c.mul == 1 && c.shift == 0 && c.need_even == 0 && (c.kmul == 1 || c.kmul == -1) &&
+    const bool fast = c.ksize == 3 && c.shift == 0 && c.need_even == 0 && (c.kmul == 1 || c.kmul == -1) &&
                       (c.Cin % 32) == 0 && (a.k_per_split % 32) == 0 && c.lim_h == c.Hin && c.lim_w == c.Win;
     return fast ? 2 : 1;
 }
