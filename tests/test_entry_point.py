@@ -125,3 +125,25 @@ def test_checkpoint_directory_loading(tmp_path):
     (tmp_path / "unet" / "diffusion_pytorch_model.safetensors").unlink()
     with pytest.raises(FileNotFoundError):
         loading.load_unet(str(tmp_path), "cpu")
+
+
+def test_image_guide_dataset_transform():
+    """reference preprocess_train (train_text_to_image_control_lora.py:606-630): short side resized to `resolution`
+    (bilinear), Normalize(0.5, 0.5), ONE random crop shared by image and guide, caption tokenised"""
+    from PIL import Image
+    import numpy as np
+    rng = np.random.default_rng(0)
+    rows = []
+    for w, h in ((96, 64), (64, 80), (64, 64)):
+        a = rng.integers(0, 255, (h, w, 3), dtype=np.uint8)
+        rows.append({"image": Image.fromarray(a), "guide": Image.fromarray(255 - a), "text": ["a cat", "a dog"]})
+    ds = data.ImageGuideDataset(rows, "image", "guide", "text", 32, text.HashTokenizer())
+    for i in range(3):
+        ex = ds[i]
+        assert ex["pixel_values"].shape == (3, 32, 32) and ex["guide_values"].shape == (3, 32, 32)
+        assert float(ex["pixel_values"].abs().max()) <= 1.0
+        # guide = inverted image and both got the SAME crop: they stay (almost exactly) opposite in [-1, 1]
+        assert float((ex["pixel_values"] + ex["guide_values"]).abs().max()) < 0.05
+        assert ex["caption"] in ("a cat", "a dog") and ex["input_ids"].shape == (77,)
+    b = data.collate([ds[0], ds[1]])
+    assert b["pixel_values"].shape == (2, 3, 32, 32) and b["input_ids"].shape == (2, 77)

@@ -87,8 +87,8 @@ def test_conv_padded_channels_pack_and_oihw_grad():
     KC.case_conv_padded_channels("cpu")
 
 
-@pytest.mark.parametrize("tile,split", [(1, 1), (3, 2), (5, 3)])
-def test_conv_fast_path_uniform_taps(tile, split):
+@pytest.mark.parametrize("tile", [1, 3, 5])
+def test_conv_fast_path_uniform_taps(tile):
     """3x3 stride-1 convs with Cin % 32 == 0 take the wave-uniform tap walk (CONV == 2) in forward and dgrad"""
     KC.case_conv("cpu", 1, 6, 5, 32, 64, tile_cfg=tile)
     KC.case_conv("cpu", 2, 4, 4, 64, 32, tile_cfg=tile)
