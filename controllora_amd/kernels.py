@@ -393,6 +393,13 @@ def lora_wgrad_defer(jobs, device, *keepalive):
             lora_wgrad_flush()     # not inside a backward pass: nothing to wait for
 
 
+def lora_wgrad_discard():
+    """drop queued jobs without running them (a backward pass that raised must not leak its jobs into the next step)"""
+    _wgrad_queue["jobs"].clear()
+    _wgrad_queue["refs"].clear()
+    _wgrad_queue["armed"] = False
+
+
 def lora_wgrad_flush():
     jobs, _wgrad_queue["jobs"] = _wgrad_queue["jobs"], []
     _wgrad_queue["armed"] = False

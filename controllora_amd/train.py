@@ -95,6 +95,7 @@ class ControlLoRATrainer:
 
     # -- pieces (kept separate so tests can check each against the oracle)
     def forward_backward(self, noisy_latents, timesteps, encoder_hidden_states, guide, target):
+        K.lora_wgrad_discard()                                      # nothing may be pending from an aborted step
         if self._micro == 0:
             self.flat.zero_grad()
         self.loss_sum.zero_()
