@@ -56,7 +56,7 @@ def synthetic_batch(B, res, dev, seed):
     )
 
 
-def build_models(dev, seed=0):
+def build_models(dev, seed=0, config="fill50k.json"):
     from controllora_amd import models as M, unet as U
     unet = U.UNet2DConditionModel()
     unet.to(dev)
@@ -70,7 +70,7 @@ def build_models(dev, seed=0):
             else:
                 p.fill_(1.0)
     torch.manual_seed(seed)
-    clora = M.ControlLoRA.from_config(os.path.join(ROOT, "configs", "fill50k.json")).to(dev)
+    clora = M.ControlLoRA.from_config(os.path.join(ROOT, "configs", config)).to(dev)
     unet.set_attn_processor(M.map_processors_to_unet(unet, clora))
     return unet, clora
 
@@ -116,6 +116,8 @@ def main():
     ap.add_argument("--no-ddim", action="store_true", help="skip the secondary inference measurement")
     ap.add_argument("--no-graph", action="store_true", help="issue the step eagerly instead of replaying hipGraphs")
     ap.add_argument("--ddim-batch", type=int, default=16)
+    ap.add_argument("--config", default="fill50k.json", help="ControlLoRA config under configs/ (BASELINE configs[1] = fill50k.json; "
+                    "mpii-pose-v2.json with --batch 8 is BASELINE configs[3])")
     ap.add_argument("--no-full-step", action="store_true", help="skip the secondary 'whole reference step' line (VAE + CLIP inside)")
     ap.add_argument("--backend", default="nccl", help='torch.distributed backend ("nccl" is RCCL on ROCm; "gloo" only for '
                     "exercising the N>1 control flow on a box with fewer GPUs than ranks)")
@@ -140,7 +142,7 @@ def main():
     from controllora_amd.schedulers import DDPMScheduler
     from controllora_amd.train import ControlLoRATrainer
 
-    unet, clora = build_models(dev)
+    unet, clora = build_models(dev, config=args.config)
     trainer = ControlLoRATrainer(unet, clora, process_group=pg, world_size=world)
     batch = synthetic_batch(args.batch, args.res, dev, 42 + rank)         # data-parallel: different samples per rank
     noisy = DDPMScheduler().add_noise(batch["latents"], batch["noise"], batch["timesteps"]).half()
@@ -278,7 +280,7 @@ def main():
             "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16", "data": "synthetic",
-            "config": {"workload": f"configs/fill50k.json on SD-1.5 topology (seeded random weights), {args.res}x{args.res}, "
+            "config": {"workload": f"configs/{args.config} on SD-1.5 topology (seeded random weights), {args.res}x{args.res}, "
                                    f"bs={args.batch}/GPU, fp16; hot path = hint encoder + UNet fwd/bwd + adapter AdamW; "
                                    f"latents/text embeddings synthetic (VAE/CLIP outside the hot path)",
                        "global_batch": args.batch * world, "parallelism": f"dp{world}", "hipgraph": graphed,
