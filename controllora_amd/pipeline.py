@@ -6,17 +6,18 @@ from __future__ import annotations
 
 import torch
 
-from .schedulers import DDIMScheduler
+from .schedulers import DDIMScheduler, DPMSolverMultistepScheduler
 
 
 @torch.no_grad()
 def ddim_sample(unet, control_lora, guide, cond_emb, uncond_emb, steps=50, guidance_scale=9.0, latents=None,
-                generator=None):
-    """guide [Bc,3,H,W] (control batch 1 broadcasts over the CFG batch, quirk C6); cond/uncond [B,77,768]."""
+                generator=None, sampler="ddim"):
+    """guide [Bc,3,H,W] (control batch 1 broadcasts over the CFG batch, quirk C6); cond/uncond [B,77,768].
+    sampler: "ddim" (BASELINE inference config) or "dpm" (DPM-Solver++(2M), what the reference apps select)."""
     B = cond_emb.shape[0]
     dev = cond_emb.device
     H, W = guide.shape[2] // 8, guide.shape[3] // 8
-    sched = DDIMScheduler()
+    sched = DDIMScheduler() if sampler == "ddim" else DPMSolverMultistepScheduler()
     sched.set_timesteps(steps)
     if latents is None:
         latents = torch.randn((B, 4, H, W), device=dev, dtype=torch.float16, generator=generator) * sched.init_noise_sigma
@@ -62,7 +63,7 @@ class ControlLoRAPipeline:
 
     @torch.no_grad()
     def __call__(self, prompt, guide, a_prompt="", n_prompt="", num_samples=1, ddim_steps=50, scale=9.0, seed=None,
-                 output_type="uint8"):
+                 output_type="uint8", sampler="ddim"):
         """guide: float tensor [1 or N, 3, H, W] in [-1, 1] (H, W multiples of 64)"""
         dev = next(self.text_encoder.parameters()).device
         gen = torch.Generator(device=dev)
@@ -71,7 +72,7 @@ class ControlLoRAPipeline:
         cond = self.encode_prompt([prompt + (", " + a_prompt if a_prompt else "")] * num_samples)
         uncond = self.encode_prompt([n_prompt] * num_samples)
         lat = ddim_sample(self.unet, self.control_lora, guide.to(dev).half(), cond, uncond, steps=ddim_steps,
-                          guidance_scale=scale, generator=gen)
+                          guidance_scale=scale, generator=gen, sampler=sampler)
         img = self.vae.decode(lat.half() / self.vae.scaling_factor).sample.float().clamp(-1, 1)
         if output_type == "uint8":
             return ((img.permute(0, 2, 3, 1) + 1.0) * 127.5).round().to(torch.uint8).cpu()

@@ -113,3 +113,34 @@ def test_ddim_timesteps():
     s = unet_ref.DDPMSchedule()
     ts = s.ddim_timesteps(50)
     assert ts[0] == 981 and ts[-1] == 1 and len(ts) == 50
+
+
+def test_dpm_solver_pp_identities():
+    """DPM-Solver++(2M) (the sampler of the reference apps) restated without upstream diffusers: pin what must hold.
+    (1) its first-order update is the DDIM(eta=0) update between the same two timesteps;
+    (2) a model whose epsilon is consistent with ONE fixed x0 is integrated exactly by the first AND second order updates."""
+    import torch
+    from controllora_amd.schedulers import DDIMScheduler, DPMSolverMultistepScheduler
+    torch.manual_seed(0)
+    x = torch.randn(2, 4, 8, 8, dtype=torch.float64)
+    eps = torch.randn_like(x)
+    dpm = DPMSolverMultistepScheduler(solver_order=1)
+    dpm.set_timesteps(20)
+    t, prev = dpm.timesteps[3], dpm.timesteps[4]
+    ddim = DDIMScheduler()
+    a_t, a_p = float(ddim.alphas_cumprod[t]), float(ddim.alphas_cumprod[prev])
+    x0 = (x - (1 - a_t) ** 0.5 * eps) / a_t ** 0.5
+    ref = a_p ** 0.5 * x0 + (1 - a_p) ** 0.5 * eps
+    assert float((dpm.step(eps, t, x) - ref).abs().max()) < 1e-6
+    for order in (1, 2):
+        s = DPMSolverMultistepScheduler(solver_order=order)
+        s.set_timesteps(12)
+        target = torch.randn(1, 4, 8, 8, dtype=torch.float64)
+        t0 = s.timesteps[0]
+        lat = float(s._alpha[t0]) * target + float(s._sigma[t0]) * torch.randn_like(target)
+        for t in s.timesteps:
+            e = (lat - float(s._alpha[t]) * target) / float(s._sigma[t])       # the exact-x0 "model"
+            lat = s.step(e, t, lat)
+            nxt = s.timesteps[s.timesteps.index(t) + 1] if t != s.timesteps[-1] else 0
+            # every update keeps the trajectory on {alpha x0 + sigma eps}: the same eps explains the new latent
+            assert float((lat - float(s._alpha[nxt]) * target - float(s._sigma[nxt]) * e).abs().max()) < 1e-9
