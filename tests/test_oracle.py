@@ -143,4 +143,4 @@ def test_dpm_solver_pp_identities():
             lat = s.step(e, t, lat)
             nxt = s.timesteps[s.timesteps.index(t) + 1] if t != s.timesteps[-1] else 0
             # every update keeps the trajectory on {alpha x0 + sigma eps}: the same eps explains the new latent
-            assert float((lat - float(s._alpha[nxt]) * target - float(s._sigma[nxt]) * e).abs().max()) < 1e-9
+            assert float((lat - float(s._alpha[nxt]) * target - float(s._sigma[nxt]) * e).abs().max()) < 1e-5   # the update runs in fp32
