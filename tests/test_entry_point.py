@@ -147,3 +147,26 @@ def test_image_guide_dataset_transform():
         assert ex["caption"] in ("a cat", "a dog") and ex["input_ids"].shape == (77,)
     b = data.collate([ds[0], ds[1]])
     assert b["pixel_values"].shape == (2, 3, 32, 32) and b["input_ids"].shape == (2, 77)
+
+
+def test_canny_annotator_and_app_helpers():
+    """the CPU side of the app entry point (apps/canny2image.py): Canny finds the outline of a square and nothing else,
+    hysteresis keeps weak pixels only when connected to strong ones, resize rounds to multiples of 64"""
+    import importlib.util
+    import numpy as np
+    spec = importlib.util.spec_from_file_location("canny2image", os.path.join(os.path.dirname(os.path.dirname(__file__)), "apps", "canny2image.py"))
+    app = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(app)
+    img = np.zeros((64, 64, 3), np.uint8)
+    img[16:48, 16:48] = 200
+    e = app.canny(img, 100, 200)
+    assert e.dtype == np.uint8 and set(np.unique(e)) == {0, 255}
+    ys, xs = np.nonzero(e)
+    assert ys.min() >= 14 and ys.max() <= 49 and xs.min() >= 14 and xs.max() <= 49       # edges hug the square
+    assert e[30:34, 30:34].sum() == 0 and e[:10].sum() == 0                               # flat regions stay empty
+    assert 100 <= (e > 0).sum() <= 300                                                    # a thin outline, not a band
+    weak = np.zeros((32, 32, 3), np.uint8)
+    weak[:, 16:] = 30                                                                     # gradient 120 (L1 Sobel): weak only
+    assert app.canny(weak, 100, 200).sum() == 0
+    assert app.resize_image(np.zeros((100, 150, 3), np.uint8), 128).shape == (128, 192, 3)
+    assert app.hwc3(np.zeros((4, 4), np.uint8)).shape == (4, 4, 3)
