@@ -123,3 +123,24 @@ def test_pipeline_prompt_to_image(tmp_path):
     assert a.shape == (2, 64, 64, 3) and a.dtype == torch.uint8 and torch.equal(a, b)
     c = pipe("red circle", guide, num_samples=2, ddim_steps=3, scale=7.5, seed=6)
     assert not torch.equal(a, c)
+
+
+def test_canny2image_app_process():
+    """apps/canny2image.py `process()` (reference apps/gradio_canny2image.py:66-92): image -> Canny -> control -> samples"""
+    import importlib.util
+    import os
+    import numpy as np
+    from controllora_amd import models as M
+    from controllora_amd.pipeline import ControlLoRAPipeline
+    from oracle import cases
+    spec = importlib.util.spec_from_file_location("canny2image", os.path.join(os.path.dirname(os.path.dirname(__file__)), "apps", "canny2image.py"))
+    app = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(app)
+    torch.manual_seed(0)
+    pipe = ControlLoRAPipeline.from_pretrained("random:small", M.ControlLoRA(**cases.SMALL_CLORA_V1), "cuda")
+    img = np.zeros((80, 100, 3), np.uint8)
+    img[20:60, 30:70] = 220
+    out = app.process(pipe, img, "a square", "best quality", "lowres", 2, 64, 4, 7.5, 3, 0.0, 100, 200)
+    assert len(out) == 3 and all(o.dtype == np.uint8 for o in out)
+    assert out[0].shape == (64, 64, 3) or out[0].shape == (64, 128, 3)       # resized to multiples of 64
+    assert out[1].shape == out[0].shape and (out[0] < 255).any()             # inverted edge map shows the square
