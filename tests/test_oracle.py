@@ -144,3 +144,18 @@ def test_dpm_solver_pp_identities():
             nxt = s.timesteps[s.timesteps.index(t) + 1] if t != s.timesteps[-1] else 0
             # every update keeps the trajectory on {alpha x0 + sigma eps}: the same eps explains the new latent
             assert float((lat - float(s._alpha[nxt]) * target - float(s._sigma[nxt]) * e).abs().max()) < 1e-5   # the update runs in fp32
+
+
+def test_velocity_target_and_add_noise_are_consistent():
+    """v-prediction target (reference train...:776-777): with x_t = a x0 + s eps and v = a eps - s x0 (a^2 + s^2 = 1),
+    x0 = a x_t - s v and eps = s x_t + a v"""
+    import torch
+    from controllora_amd.schedulers import DDPMScheduler
+    torch.manual_seed(1)
+    sch = DDPMScheduler()
+    x0, eps = torch.randn(3, 4, 8, 8, dtype=torch.float64), torch.randn(3, 4, 8, 8, dtype=torch.float64)
+    t = torch.tensor([0, 500, 999])
+    xt, v = sch.add_noise(x0, eps, t), sch.get_velocity(x0, eps, t)
+    a = sch.alphas_cumprod.double()[t].sqrt().reshape(-1, 1, 1, 1)
+    s = (1 - sch.alphas_cumprod.double()[t]).sqrt().reshape(-1, 1, 1, 1)
+    assert float((a * xt - s * v - x0).abs().max()) < 1e-6 and float((s * xt + a * v - eps).abs().max()) < 1e-6
