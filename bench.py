@@ -9,16 +9,27 @@ gradient], fused clip + AdamW.  Workload = BASELINE.json configs[1]: configs/fil
 with seeded random weights (no checkpoint offline), 512x512, batch 4 per GPU, fp16.  VAE-encode / CLIP are
 outside the named hot path: latents and text embeddings are synthetic inputs.
 
-Prints ONE JSON line (rank 0) with metric/value plus `roofline` (dominant kernel family, HIP-event timed in a
-separate profiling step after the timed region) and `cpu_baseline` (the CPU oracle, N=1 only).
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment re-executes itself under `torch.distributed.run` with N
+ranks (one per GPU, RCCL); launched BY `torch.distributed.run` (the driver's way) it just joins.  `n_gpus` in the
+line is the number of ranks that actually joined (`torch.distributed.get_world_size()`).
+
+Prints ONE JSON line (rank 0) with metric/value plus `roofline` (dominant kernel family: algorithmic flops of its
+launches in one step / its kernel time per GRAPH-REPLAYED step, taken from a `rocprofv3 --kernel-trace` of this same
+command run as a child process; HIP-event timings of an eager step are reported beside it) and `cpu_baseline` (the
+CPU oracle, N=1 only).
 """
 from __future__ import annotations
 
 import argparse
+import glob
 import json
 import math
 import os
+import shutil
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 
 import torch
@@ -104,6 +115,91 @@ def cpu_baseline(steps=2):
                       f"{steps} steps after 1 warm-up, {sec:.2f} s/step"}
 
 
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` (no launcher): re-exec under torch.distributed.run, one rank per GPU (driver contract)."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on these hosts (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run(args):
+    """Exercise the N>1 control flow without GPUs (`--backend gloo --dry-run`): rendezvous, the flat-buffer all-reduce
+    (sum of ranks, divisor folded into the optimizer), barrier + MAX-over-ranks timing, rank-0 JSON line."""
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group(args.backend)
+        world = torch.distributed.get_world_size()
+    n = 6047040                                   # fill50k.json trainable parameters = the all-reduce payload
+    g = torch.full((n,), float(rank + 1))
+    if world > 1:
+        torch.distributed.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        if world > 1:
+            torch.distributed.all_reduce(g)
+            g.div_(world)
+    if world > 1:
+        torch.distributed.barrier()
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if world > 1:
+        torch.distributed.all_reduce(el, op=torch.distributed.ReduceOp.MAX)
+    ok = True
+    if world > 1 and args.steps > 0:
+        # after one all-reduce(sum)/N every rank holds mean(1..N); further rounds keep it there
+        ok = bool(torch.allclose(g, torch.full_like(g, (world + 1) / 2.0)))
+    if rank == 0:
+        print(json.dumps({"metric": "dry-run (no GPU work): flat-buffer all-reduce control flow", "dry_run": True, "value": None,
+                          "n_gpus": world, "rccl_ranks": world, "backend": args.backend, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(float(el) / max(1, args.steps) * 1e3, 3), "allreduce_bytes": n * 4, "allreduce_ok": ok}))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+    return 0 if ok else 1
+
+
+GEMM_FAMILY = ("gemm_dma_kernel", "splitk_finish_kernel", "gemm_")       # kernels behind clora_gemm_f16_ex
+
+
+def rocprof_child_trace(args, steps=6, warmup=2):
+    """`rocprofv3 --kernel-trace` over THIS command (same config / batch / res, hipGraph replay, nothing but the train
+    steps) as a child process; returns per-kernel time per step or None when rocprofv3 is unavailable / fails."""
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    out = tempfile.mkdtemp(prefix="clora_kt_", dir="/tmp")
+    cmd = [exe, "--kernel-trace", "-d", out, "-o", "kt", "--", sys.executable, os.path.abspath(__file__), "--trace-child",
+           "--steps", str(steps), "--warmup", str(warmup), "--batch", str(args.batch), "--res", str(args.res), "--config", args.config]
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    try:
+        r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    except Exception as e:                                   # noqa: BLE001
+        return {"error": repr(e)}
+    dbs = glob.glob(os.path.join(out, "**", "*.db"), recursive=True)
+    if r.returncode != 0 or not dbs:
+        return {"error": f"rocprofv3 rc={r.returncode}", "tail": r.stdout.decode(errors="replace")[-400:]}
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import rocprof_summary
+    rows = rocprof_summary.load(dbs[0])
+    # the child runs 2 eager warm-up steps inside capture() + `warmup` + `steps` replays: all issue the same kernels
+    n_steps = 2 + warmup + steps
+    res = {"steps_in_trace": n_steps, "total_kernel_ms_per_step": sum(r_["total_ms"] for r_ in rows) / n_steps,
+           "launches_per_step": round(sum(r_["calls"] for r_ in rows) / n_steps),
+           "kernels": rows, "db": dbs[0]}
+    shutil.rmtree(out, ignore_errors=True)
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -121,7 +217,18 @@ def main():
     ap.add_argument("--no-full-step", action="store_true", help="skip the secondary 'whole reference step' line (VAE + CLIP inside)")
     ap.add_argument("--backend", default="nccl", help='torch.distributed backend ("nccl" is RCCL on ROCm; "gloo" only for '
                     "exercising the N>1 control flow on a box with fewer GPUs than ranks)")
+    ap.add_argument("--dry-run", action="store_true", help="with --backend gloo: exercise the multi-rank control flow (spawn, "
+                    "rendezvous, flat all-reduce, rank-0 line) without touching a GPU")
+    ap.add_argument("--trace-child", action="store_true", help=argparse.SUPPRESS)    # run by rocprof_child_trace()
+    ap.add_argument("--no-rocprof", action="store_true", help="skip the rocprofv3 child run (roofline falls back to HIP events)")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus))
+    if args.dry_run:
+        sys.exit(dry_run(args))
+    if args.trace_child:
+        args.no_cpu_baseline = args.no_roofline = args.no_ddim = args.no_full_step = True
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -137,6 +244,7 @@ def main():
         else:
             torch.distributed.init_process_group(args.backend)
         pg = torch.distributed.group.WORLD
+        world = torch.distributed.get_world_size()       # the ranks that actually joined
 
     from controllora_amd import kernels as K
     from controllora_amd.schedulers import DDPMScheduler
@@ -178,38 +286,82 @@ def main():
     loss = trainer.loss(noisy.numel())
     skipped = float(trainer.state[6])
 
+    allreduce_ms = None
+    if world > 1:                                  # the exchange step on its own: 10 flat-buffer all-reduces, HIP events
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        scratch = torch.zeros_like(trainer.flat.grad)
+        torch.distributed.all_reduce(scratch, group=pg)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(10):
+            torch.distributed.all_reduce(scratch, group=pg)
+        e1.record()
+        torch.cuda.synchronize()
+        allreduce_ms = round(e0.elapsed_time(e1) / 10, 4)
+        del scratch
+
+    if args.trace_child:
+        return
+
     roofline = None
     if not args.no_roofline and rank != 0:
         eager_step()                           # the profiled step contains the all-reduce: every rank takes part
     if not args.no_roofline and rank == 0:
+        # (1) algorithmic flops / bytes per launch family + HIP-event durations of ONE eager step (events on the launch stream)
         K.PROFILER = K.KernelProfiler()
         eager_step()
         agg = K.PROFILER.summary()
         K.PROFILER = None
-        total_ms = sum(a["ms"] for a in agg.values())
+        ev_total_ms = sum(a["ms"] for a in agg.values())
         dom_name, dom = max(agg.items(), key=lambda kv: kv[1]["ms"])
-        fam = {k: {"calls": v["calls"], "ms": round(v["ms"], 3),
-                   "TFLOPs": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["flops"] else None}
+        fam = {k: {"calls": v["calls"], "event_ms": round(v["ms"], 3),
+                   "event_TFLOPs": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["flops"] else None}
                for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])[:8]}
-        ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
-        # HBM-side traffic per launch of the dominant family: PMC counters cannot be read from inside the process, so
-        # this is the committed result of the two `rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE` passes over this same
-        # command (tools/pmc_summary.py; FETCH_SIZE x2 as calibrated on gfx950), averaged over the family's kernels.
+        ev_ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+        # (2) the same family's kernel time per GRAPH-REPLAYED step: rocprofv3 --kernel-trace of this command as a child
+        # process (N=1 only).  The bench line's roofline uses THIS duration; the event figures are kept beside it.
+        trace = None
+        if world == 1 and not args.no_rocprof and graphed:
+            trace = rocprof_child_trace(args)
+        src, fam_ms, fam_launches, kt = "hip_events(eager step)", dom["ms"], dom["calls"], None
+        if trace and "kernels" in trace and dom_name.startswith("clora_gemm"):
+            rows = [r_ for r_ in trace["kernels"] if any(t in r_["kernel"] for t in GEMM_FAMILY)]
+            n_st = trace["steps_in_trace"]
+            fam_ms = sum(r_["total_ms"] for r_ in rows) / n_st
+            fam_launches = round(sum(r_["calls"] for r_ in rows) / n_st)
+            src = f"rocprofv3 --kernel-trace child run ({n_st} steps, hipGraph replay), kernels matching {GEMM_FAMILY}"
+            kt = {"total_kernel_ms_per_step": round(trace["total_kernel_ms_per_step"], 3),
+                  "launches_per_step": trace["launches_per_step"],
+                  "top": [{"kernel": r_["kernel"][:60], "calls_per_step": round(r_["calls"] / n_st, 1),
+                           "ms_per_step": round(r_["total_ms"] / n_st, 3), "avg_us": r_["avg_us"]} for r_ in trace["kernels"][:12]]}
+        elif trace:
+            kt = {"error": trace.get("error"), "tail": trace.get("tail")}
+        ach = dom["flops"] / (fam_ms * 1e-3) / 1e12
+        # HBM-side traffic per launch of the dominant family: PMC counters need their own rocprofv3 --pmc passes
+        # (tools/pmc_traffic.sh -> tools/pmc_summary.py); the committed result of the latest passes is reported with
+        # "static": true and the commit / round it was measured at -- it does not move with this run.
         traffic, traffic_src = None, None
-        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if dom_name.startswith("clora_gemm") and os.path.exists(pmc_path):
-            pmc = json.load(open(pmc_path))
-            ks = [v for k, v in pmc["kernels"].items() if "gemm_dma_kernel" in k]
+        pmc_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+        if dom_name.startswith("clora_gemm") and pmc_files:
+            pmc = json.load(open(pmc_files[-1]))
+            ks = [v for k, v in pmc["kernels"].items() if any(t in k for t in GEMM_FAMILY)]
             n = sum(v["launches"] for v in ks)
             traffic = round(sum(v["launches"] * (v["fetch_bytes_per_launch_corrected"] + (v["write_bytes_per_launch_raw"] or 0.0))
                                 for v in ks) / n)
-            traffic_src = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc, L2<->fabric bytes incl. Infinity-Cache hits)"
+            traffic_src = {"static": True, "file": os.path.relpath(pmc_files[-1], ROOT), "measured_at": pmc.get("measured_at"),
+                           "how": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command (L2<->fabric bytes, "
+                                  "FETCH_SIZE x2 gfx950 correction calibrated in place)"}
         roofline = {"bound": "mfma", "kernel": dom_name, "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-                    "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
+                    "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "duration_source": src,
+                    "family_ms_per_step": round(fam_ms, 3), "launches": fam_launches,
+                    "avg_launch_us": round(fam_ms * 1e3 / max(1, fam_launches), 1),
+                    "algorithmic_TFLOP_per_step": round(dom["flops"] / 1e12, 3),
                     "algorithmic_bytes_per_launch": round(dom["bytes"] / dom["calls"]),
-                    "launches": dom["calls"], "avg_launch_us": round(dom["ms"] * 1e3 / dom["calls"], 1),
-                    "kernel_ms_per_step": round(total_ms, 2), "families": fam,
+                    "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
+                    "event_timed": {"achieved": round(ev_ach, 1), "frac": round(ev_ach / MFMA_PEAK_TFLOPS, 4),
+                                    "family_ms": round(dom["ms"], 3), "all_kernels_ms": round(ev_total_ms, 2),
+                                    "note": "HIP events around each eager launch: includes launch gaps, upper bound on kernel time"},
+                    "families": fam, "kernel_trace": kt,
                     "whole_step_frac_of_mfma_peak": round(
                         images_per_s / world * hot_path_tflop_per_image(args.res) / MFMA_PEAK_TFLOPS, 4),
                     "whole_step_algorithmic_TFLOPs": round(images_per_s / world * hot_path_tflop_per_image(args.res), 1)}
@@ -284,7 +436,9 @@ def main():
                                    f"bs={args.batch}/GPU, fp16; hot path = hint encoder + UNet fwd/bwd + adapter AdamW; "
                                    f"latents/text embeddings synthetic (VAE/CLIP outside the hot path)",
                        "global_batch": args.batch * world, "parallelism": f"dp{world}", "hipgraph": graphed,
-                       "allreduce_bytes": trainer.flat.numel * 4},
+                       "allreduce_bytes": trainer.flat.numel * 4,
+                       "rccl_ranks": torch.distributed.get_world_size() if world > 1 else 1,
+                       "allreduce_ms": allreduce_ms},
             "loss": round(loss, 5), "steps_skipped_by_scaler": skipped,
             "roofline": roofline, "ddim50": ddim, "full_step_with_vae_clip": full, "cpu_baseline": cpu}))
     if world > 1:

@@ -188,7 +188,7 @@ __global__ void optim_prep_kernel(float* st, float max_norm, float beta1, float 
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const float sumsq = st[0];
     const bool badv = st[1] != 0.f || !(sumsq <= 3.0e38f);
-    const float inv = 1.0f / st[3];
+    const float inv = 1.0f / (st[3] * (st[11] > 0.f ? st[11] : 1.0f));   // loss scale x data-parallel world size
     if (!badv) {
         const float norm = sqrtf(sumsq) * inv;
         float coef = 1.0f;

@@ -375,34 +375,43 @@ def lora_wgrad_multi(jobs, device):
 # the autograd functions queue their reduction jobs instead of launching them one site at a time; the queue is flushed
 # ONCE at the end of the backward pass, 16 jobs per launch: ~110 small launch pairs per step become ~25 large ones.
 # Tensors the jobs read are kept alive until the flush.  Jobs that target the same gradient buffer never share a launch.
-_wgrad_queue = {"jobs": [], "refs": [], "armed": False, "enabled": os.environ.get("CLORA_DEFER_WGRAD", "1") != "0"}
+_wgrad_queue = {"jobs": [], "refs": [], "task": None, "enabled": os.environ.get("CLORA_DEFER_WGRAD", "1") != "0"}
+
+
+def _graph_task_id():
+    f = getattr(torch._C, "_current_graph_task_id", None)
+    return f() if f is not None else -1
 
 
 def lora_wgrad_defer(jobs, device, *keepalive):
     if not _wgrad_queue["enabled"] or PROFILER is not None:
         lora_wgrad_multi(jobs, device)
         return
+    task = _graph_task_id()
+    if task < 0:                   # not inside a backward pass: nothing to wait for
+        lora_wgrad_multi(jobs, device)
+        return
+    if _wgrad_queue["task"] != task:
+        # first deferral of THIS backward pass.  Anything still queued belongs to an earlier pass that raised before
+        # its end-of-backward callback ran: those jobs point at freed tensors -- drop them, never launch them.
+        lora_wgrad_discard()
+        _wgrad_queue["task"] = task
+        torch.autograd.Variable._execution_engine.queue_callback(lora_wgrad_flush)   # runs when this pass ends
     _wgrad_queue["jobs"].extend(jobs)
     _wgrad_queue["refs"].extend(keepalive)
     _wgrad_queue["device"] = device
-    if not _wgrad_queue["armed"]:
-        try:       # flush automatically when the running backward pass ends, whoever called .backward()
-            torch.autograd.Variable._execution_engine.queue_callback(lora_wgrad_flush)
-            _wgrad_queue["armed"] = True
-        except RuntimeError:
-            lora_wgrad_flush()     # not inside a backward pass: nothing to wait for
 
 
 def lora_wgrad_discard():
     """drop queued jobs without running them (a backward pass that raised must not leak its jobs into the next step)"""
     _wgrad_queue["jobs"].clear()
     _wgrad_queue["refs"].clear()
-    _wgrad_queue["armed"] = False
+    _wgrad_queue["task"] = None
 
 
 def lora_wgrad_flush():
     jobs, _wgrad_queue["jobs"] = _wgrad_queue["jobs"], []
-    _wgrad_queue["armed"] = False
+    _wgrad_queue["task"] = None
     if jobs:
         batches = []               # greedy packing: a batch never holds two jobs with the same destination
         for j in jobs:

@@ -199,6 +199,13 @@ class _ControlMixin:
             b, _, hh, ww = ctrl.shape
             ctrl = ctrl.permute(0, 2, 3, 1).reshape(b, hh * ww, -1)
             self.control_states = ctrl
+        b1, b2 = ctrl.shape[0], hidden_states.shape[0]
+        if b1 != b2 and b1 != 1:
+            # the reference repeat-interleaves the control batch (models.py:209-213, 343-347: c0,c0,c1,c1,...) in the
+            # concat path and cannot broadcast at all in the plain path; the kernels broadcast by tiling, which is
+            # only the same thing for a control batch of 1 (quirk C6, the inference call pattern)
+            raise NotImplementedError(f"control batch {b1} vs UNet batch {b2}: only equal batches or a control batch of 1 "
+                                      "are supported")
         return ctrl.contiguous()
 
     def process_control_states(self, hidden_states, scale=1.0, is_out=False):

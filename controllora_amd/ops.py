@@ -391,7 +391,7 @@ class _LoraProjFn(torch.autograd.Function):
         dT = (torch.empty if all(i is not None and i[2] == r for i in info) else torch.zeros)((M, S * r), dtype=f32, device=dy.device)
         d_xas: List[Optional[torch.Tensor]] = [None] * n_xa
         own = []                                  # (segment, D) of adapters fed by x itself -> dgrad GEMM epilogue
-        djobs, wjobs, later = [], [], []
+        djobs, wjobs, later, keep = [], [], [], []
         pi = 0
         for s, m in enumerate(info):
             if m is None:
@@ -419,6 +419,7 @@ class _LoraProjFn(torch.autograd.Function):
                     a2 = xas[xis[1]] if len(xis) > 1 else None
                     if a2 is not None and a2.shape[0] != M:        # broadcast second input (control batch < UNet batch)
                         a2 = a2.repeat(M // a2.shape[0], 1)
+                        keep.append(a2)                               # the temporary must outlive the deferred launch
                     wjobs.append(K.wgrad_job(xas[xis[0]], dT, s * r, _grad_buffer(D), 1, D.shape[1], M, D.shape[1], rs, A2=a2))
             for xi in xis:
                 if xi == 0:
@@ -428,7 +429,7 @@ class _LoraProjFn(torch.autograd.Function):
         if djobs:
             K.lora_down_multi(djobs)              # dT of every adapter of this GEMM: one launch
         if wjobs:
-            K.lora_wgrad_defer(wjobs, dy.device, dy, T, dT, *xas)   # dU / dD: queued, flushed once at the end of backward
+            K.lora_wgrad_defer(wjobs, dy.device, dy, T, dT, *xas, *keep)   # dU / dD: queued, flushed once at the end of backward
         for item in later:
             if item[0] == "dx":
                 _, xi, s, D = item

@@ -21,11 +21,14 @@ def ddim_sample(unet, control_lora, guide, cond_emb, uncond_emb, steps=50, guida
     sched.set_timesteps(steps)
     if latents is None:
         latents = torch.randn((B, 4, H, W), device=dev, dtype=torch.float16, generator=generator) * sched.init_noise_sigma
+    # the scheduler state stays fp32 between steps (16 KB per image): only the UNet input is rounded to fp16, so the
+    # 50 updates do not each add an fp16 rounding of the latents (denoised-latent parity, tests/full_cases.py)
+    latents = latents.float()
     if control_lora is not None:
         control_lora(guide)
     ehs = torch.cat([uncond_emb, cond_emb], 0)
     for t in sched.timesteps:
-        eps = unet(torch.cat([latents, latents], 0), t, ehs).sample
+        eps = unet(torch.cat([latents, latents], 0).half(), t, ehs).sample
         eps_u, eps_c = eps.float().chunk(2)
         eps = eps_u + guidance_scale * (eps_c - eps_u)
         latents = sched.step(eps, t, latents)

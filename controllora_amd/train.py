@@ -83,8 +83,9 @@ class ControlLoRATrainer:
                        dynamic=dynamic_scale, interval=growth_interval)
         self.state = torch.zeros(16, dtype=f32, device=dev)
         self.state[3] = init_scale
+        self.state[11] = float(world_size)       # the optimizer kernels turn the all-reduce SUM into the mean
         self.loss_sum = torch.zeros(1, dtype=f32, device=dev)
-        self.pg, self.world = process_group, world_size
+        self.pg, self.world, self._reduced = process_group, world_size, False
         # gradient accumulation (train...:174-178, `accelerator.accumulate`): micro-batch losses are divided by the
         # number of accumulation steps and the optimizer runs on the last micro-batch only
         self.accum, self._micro = max(1, int(gradient_accumulation_steps)), 0
@@ -98,6 +99,7 @@ class ControlLoRATrainer:
         K.lora_wgrad_discard()                                      # nothing may be pending from an aborted step
         if self._micro == 0:
             self.flat.zero_grad()
+            self._reduced = False
         self.loss_sum.zero_()
         self.control_lora(guide)                                    # injects control states into the 32 processors
         pred = self.unet(noisy_latents, timesteps, encoder_hidden_states).sample
@@ -120,8 +122,9 @@ class ControlLoRATrainer:
         self.global_step += 1
         g = self.flat.grad
         if self.world > 1:
-            torch.distributed.all_reduce(g, group=self.pg)           # RCCL over xGMI: one flat 24 MB buffer
-            g.mul_(1.0 / self.world)
+            torch.distributed.all_reduce(g, group=self.pg)           # RCCL over xGMI: one flat 24 MB buffer (SUM;
+            #                                                          the 1/N of the mean is folded into optim_prep)
+            self._reduced = True
         self._optimizer_kernels()
         return True
 
@@ -166,10 +169,11 @@ class ControlLoRATrainer:
             if src is not None and src.data_ptr() != dst.data_ptr():
                 dst.copy_(src, non_blocking=True)
         assert self.accum == 1, "the captured step assumes one micro-batch per optimizer step"
+        self._reduced = False
         self._g_fb.replay()
         if self.world > 1:
             torch.distributed.all_reduce(self.flat.grad, group=self.pg)
-            self.flat.grad.mul_(1.0 / self.world)
+            self._reduced = True
         if self.lr_lambda is not None:
             self.state[10:11].fill_(max(float(self.lr_lambda(self.global_step)), 1e-30))
         self.global_step += 1
@@ -191,6 +195,7 @@ class ControlLoRATrainer:
             self.flat.exp_avg.copy_(sd["exp_avg"])
             self.flat.exp_avg_sq.copy_(sd["exp_avg_sq"])
             self.state.copy_(sd["state"])
+            self.state[11] = float(self.world)       # the divisor belongs to THIS run's world size, not the checkpoint's
         self.global_step, self._micro = int(sd["global_step"][0]), 0
 
     def save_state(self, directory: str) -> None:
@@ -211,8 +216,9 @@ class ControlLoRATrainer:
 
     def unscaled_grads(self) -> torch.Tensor:
         """flat gradient in the internal buffer order (see FlatParams._ordered)"""
-        return self.flat.grad / self.state[3]
+        return self.flat.grad / (self.state[3] * (self.world if self._reduced else 1))
 
     def unscaled_grads_module_order(self) -> torch.Tensor:
         """flat gradient in ``control_lora.parameters()`` order (what the reference / oracle would concatenate)"""
-        return torch.cat([p.grad.reshape(-1) for p in self.control_lora.parameters() if p.requires_grad]) / self.state[3]
+        return torch.cat([p.grad.reshape(-1) for p in self.control_lora.parameters() if p.requires_grad]) / (
+            self.state[3] * (self.world if self._reduced else 1))

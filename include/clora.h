@@ -217,7 +217,9 @@ int clora_cast_f16_to_f32(const clora_half* x, float* y, size_t n, void* stream)
  * state (device fp32[16]): [0] sum of squares of the (still scaled) grads  [1] non-finite count
  *   [2] optimizer step count  [3] loss scale  [4] growth tracker  [5] grad multiplier = clip/scale (out)
  *   [6] skip flag (out)  [7] 1-beta1^t  [8] 1-beta2^t  [9] unscaled grad norm (out, -1 when skipped)
- *   [10] learning-rate multiplier written by the host LR schedule (lr_scheduler, train...:660-665); 0 = unset = 1 */
+ *   [10] learning-rate multiplier written by the host LR schedule (lr_scheduler, train...:660-665); 0 = unset = 1
+ *   [11] gradient divisor = data-parallel world size: the flat buffer holds the all-reduce SUM over ranks and the mean
+ *        (train...:790 DDP semantics) is taken here, folded into the unscale factor; 0 = unset = 1 */
 int clora_grad_sumsq_f32(const float* g, size_t n, float* state, void* stream);
 int clora_optim_prep_f32(float* state, float max_norm, float beta1, float beta2, int dynamic_scale,
                          float growth_factor, float backoff_factor, int growth_interval, void* stream);

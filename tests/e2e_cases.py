@@ -162,3 +162,111 @@ def check_inference_broadcast(case, dev, tol=6e-3):
             errs.append(rel(out, ref))
     assert max(errs) < tol, errs
     return errs
+
+
+def check_pre_post_chain(kind, dev, B=2, side=4, C=64, heads=4, ctx=48, ctrl_c=32, tol_y=4e-3, tol_dh=1e-2, tol_dc=2e-2, tol_w=3e-2):
+    """pre_loras / post_loras chaining (reference models.py:232-243, 249-265, 276-282; mix_lora_and_control_lora.py:111-123):
+    the product processors (unfused generic path) vs the oracle restatement -- site output, d(hidden), d(control) and
+    every adapter weight gradient of the main / pre / post processors; self- and cross-attention sites."""
+    from oracle import controllora_ref as cr
+    torch.manual_seed(0)
+    N = side * side
+    worst = {}
+    for self_attn in (True, False):
+        cad = None if self_attn else ctx
+        o_attn = unet_ref.CrossAttention(C, cad, heads=heads, dim_head=C // heads)
+        cases.seeded_weights_(o_attn, seed=5)
+        p_attn = U.CrossAttention(C, cad, heads=heads, dim_head=C // heads)
+        with torch.no_grad():
+            for k, v in p_attn.state_dict().items():
+                v.copy_(o_attn.state_dict()[k].to(v.dtype))
+        p_attn.to(dev)
+        if kind == "v1":
+            o_main, p_main = cr.ControlLoRAProcRef(C, cad, rank=4), M.ControlLoRACrossAttnProcessor(C, cad, rank=4)
+        else:
+            o_main = cr.ControlLoRAProcV2Ref(C, cad, rank=4, control_channels=ctrl_c)
+            p_main = M.ControlLoRACrossAttnProcessorV2(C, cad, rank=4, control_channels=ctrl_c)
+        o_pre, p_pre = cr.LoRAProcRef(C, cad, rank=4), M.LoRACrossAttnProcessor(C, cad, rank=4)
+        o_post, p_post = cr.LoRAProcRef(C, cad, rank=8, post_add=True), M.LoRACrossAttnProcessor(C, cad, rank=8, post_add=True)
+        for o, p_, sd in ((o_main, p_main, 1), (o_pre, p_pre, 2), (o_post, p_post, 3)):
+            cases.seeded_weights_(o, seed=sd)
+            p_.load_state_dict(o.state_dict())
+            p_.to(dev)
+        o_main.inject_pre_lora(o_pre); o_main.inject_post_lora(o_post)
+        p_main.inject_pre_lora(p_pre); p_main.inject_post_lora(p_post)
+        h = torch.randn(B, N, C).half()
+        e = None if self_attn else torch.randn(B, 5, ctx).half()
+        ctrl = torch.randn(B, C if kind == "v1" else ctrl_c, side, side).half()
+        go = torch.randn(B, N, C).half()
+        for q in o_attn.parameters():                      # oracle: fp32 math on fp16-rounded inputs / frozen weights
+            q.data = q.data.half().float()
+        ho = h.float().requires_grad_(True)
+        co = ctrl.float().requires_grad_(True)
+        o_main.inject_control_states(co)
+        yo = o_main(o_attn, ho, None if e is None else e.float(), None, 0.7)
+        yo.backward(go.float())
+        hp = h.clone().to(dev).requires_grad_(True)
+        cp = ctrl.permute(0, 2, 3, 1).reshape(B, N, -1).contiguous().to(dev).requires_grad_(True)
+        p_main.inject_control_states(cp)
+        yp = p_main(p_attn, hp, None if e is None else e.to(dev), None, 0.7)
+        yp.backward(go.to(dev))
+        errs = {"y": rel(yp, yo.detach()), "dh": rel(hp.grad, ho.grad),
+                "dctrl": rel(cp.grad, co.grad.permute(0, 2, 3, 1).reshape(B, N, -1)), "dw": 0.0}
+        assert errs["y"] < tol_y and errs["dh"] < tol_dh and errs["dctrl"] < tol_dc, errs
+        for (n, a), (_, b_) in zip(list(p_main.named_parameters()) + list(p_pre.named_parameters()) + list(p_post.named_parameters()),
+                                   list(o_main.named_parameters()) + list(o_pre.named_parameters()) + list(o_post.named_parameters())):
+            if b_.grad is not None and float(b_.grad.norm()) > 0:
+                e_ = rel(a.grad, b_.grad)
+                errs["dw"] = max(errs["dw"], e_)
+                assert e_ < tol_w, (n, e_)
+        for k, v in errs.items():
+            worst[k] = max(worst.get(k, 0.0), v)
+    return worst
+
+
+def check_site_real_shape(dev, hidden=320, side=32, B=2, rank=4, control_rank=256, control_channels=256, concat=True,
+                          cross=False, scale=1.0, tol=4e-3, tol_g=1.2e-2):
+    """ONE attention site at a REAL SD-1.5 shape with the danbooru-sketch adapter geometry (reference
+    configs/danbooru-sketch.json: lora_control_rank 256, lora_concat_hidden, control channels 256; models.py:185-188,
+    209-218): rank-256 `to_control` goes through the large-rank down / up / wgrad kernels (no batched path).
+    Product processor on the HIP kernels vs the oracle processor: output, d(hidden), d(control), weight grads."""
+    from oracle import controllora_ref as cr
+    torch.manual_seed(0)
+    N, heads = side * side, 8
+    cad = 768 if cross else None
+    o_attn = unet_ref.CrossAttention(hidden, cad, heads=heads, dim_head=hidden // heads)
+    cases.seeded_weights_(o_attn, seed=5)
+    p_attn = U.CrossAttention(hidden, cad, heads=heads, dim_head=hidden // heads)
+    with torch.no_grad():
+        for k, v in p_attn.state_dict().items():
+            v.copy_(o_attn.state_dict()[k].to(v.dtype))
+        for q in o_attn.parameters():
+            q.data = q.data.half().float()
+    p_attn.to(dev)
+    kw = dict(rank=rank, control_rank=control_rank, concat_hidden=concat, control_channels=control_channels)
+    o_p, p_p = cr.ControlLoRAProcRef(hidden, cad, **kw), M.ControlLoRACrossAttnProcessor(hidden, cad, **kw)
+    cases.seeded_weights_(o_p, seed=9, up_std=0.02)
+    p_p.load_state_dict(o_p.state_dict())
+    p_p.to(dev)
+    g = torch.Generator().manual_seed(2)
+    h = torch.randn(B, N, hidden, generator=g).half()
+    e = torch.randn(B, 77, 768, generator=g).half() if cross else None
+    ctrl = torch.randn(B, control_channels, side, side, generator=g).half()
+    go = (torch.randn(B, N, hidden, generator=g) * 0.1).half()
+    ho, co = h.float().requires_grad_(True), ctrl.float().requires_grad_(True)
+    o_p.inject_control_states(co)
+    yo = o_p(o_attn, ho, None if e is None else e.float(), None, scale)
+    yo.backward(go.float())
+    hp = h.clone().to(dev).requires_grad_(True)
+    cp = ctrl.permute(0, 2, 3, 1).reshape(B, N, -1).contiguous().to(dev).requires_grad_(True)
+    p_p.inject_control_states(cp)
+    yp = p_p(p_attn, hp, None if e is None else e.to(dev), None, scale)
+    yp.backward(go.to(dev))
+    errs = {"y": rel(yp, yo.detach()), "dh": rel(hp.grad, ho.grad),
+            "dctrl": rel(cp.grad, co.grad.permute(0, 2, 3, 1).reshape(B, N, -1))}
+    for (n, a), (_, b_) in zip(p_p.named_parameters(), o_p.named_parameters()):
+        errs["dw:" + n] = rel(a.grad, b_.grad)
+    assert errs["y"] < tol, errs
+    bad = {k: v for k, v in errs.items() if k != "y" and v > tol_g}
+    assert not bad, (bad, errs)
+    return errs

@@ -1,0 +1,147 @@
+"""Parity on BASELINE.json's OWN configurations: the full SD-1.5 topology at real widths
+(320/640/1280 channels, head dims 40/80/160, 2560-channel concat resnets, the tuned GEMM table) -- product path on
+the GPU against the CPU oracle (fp32 restatement of reference train_text_to_image_control_lora.py:751-796 and
+apps/gradio_canny2image.py:66-92).  BASELINE configs[0] geometry: 256x256, batch 1.
+
+The oracle's frozen UNet weights and all inputs are fp16-rounded values held in fp32 (SURVEY.md section 8c "Tolerance
+reading"): the two sides then differ by accumulation order and by the product's fp16 activation storage only.
+Everything is seeded, nothing is read from /root/reference (absent on the GPU box)."""
+import os
+
+import torch
+
+from controllora_amd import models as M
+from controllora_amd import unet as U
+from controllora_amd.train import ControlLoRATrainer
+from oracle import cases, unet_ref
+from oracle.controllora_ref import ControlLoRARef, map_processors_to_unet, randomize_adapters_
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+f16 = torch.float16
+
+
+def rel(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-20))
+
+
+_ORACLE_UNET = {}
+
+
+def oracle_unet_sd15():
+    """SD-1.5-shaped oracle UNet with seeded weights, rounded to fp16 values (859.5 M parameters, built once per
+    process: ~15 s)."""
+    if "u" not in _ORACLE_UNET:
+        u = unet_ref.UNet2DConditionModel()
+        unet_ref.init_unet_weights_(u, seed=0)
+        with torch.no_grad():
+            for p in u.parameters():
+                p.copy_(p.half().float())
+                p.requires_grad_(False)
+        _ORACLE_UNET["u"] = u
+    return _ORACLE_UNET["u"]
+
+
+_PRODUCT_UNET = {}
+
+
+def product_unet_sd15(dev):
+    if "u" not in _PRODUCT_UNET:
+        u = U.UNet2DConditionModel()
+        U.load_from_oracle_(u, oracle_unet_sd15())
+        _PRODUCT_UNET["u"] = u.to(dev)
+    return _PRODUCT_UNET["u"]
+
+
+def build_pair(config_name, dev, up_std=0.02):
+    """(oracle unet, oracle clora, product unet, product clora) for configs/<config_name>, identical weights."""
+    o_unet = oracle_unet_sd15()
+    torch.manual_seed(1)
+    o_clora = ControlLoRARef.from_config(os.path.join(ROOT, "configs", config_name))
+    randomize_adapters_(o_clora, seed=1, std=up_std)          # non-zero `up`: zero-init would hide adapter bugs
+    o_unet.set_attn_processor(map_processors_to_unet(o_unet, o_clora))
+    p_unet = product_unet_sd15(dev)
+    p_clora = M.ControlLoRA.from_config(os.path.join(ROOT, "configs", config_name))
+    p_clora.load_state_dict(o_clora.state_dict())             # strict: same key set as the reference-keyed oracle
+    p_clora.to(dev)
+    p_unet.set_attn_processor(M.map_processors_to_unet(p_unet, p_clora))
+    return o_unet, o_clora, p_unet, p_clora
+
+
+def inputs(res=256, batch=1, seed=42):
+    g = torch.Generator().manual_seed(seed)
+    L = res // 8
+    guide = (torch.rand(batch, 3, res, res, generator=g) > 0.9).float() * 2 - 1       # sparse +-1 edge-map-like guide
+    return dict(guide=guide.half().float(),
+                latents=torch.randn(batch, 4, L, L, generator=g).half().float(),
+                noise=torch.randn(batch, 4, L, L, generator=g).half().float(),
+                timesteps=torch.randint(0, 1000, (batch,), generator=g),
+                ehs=torch.randn(batch, 77, 768, generator=g).half().float())
+
+
+def train_step_parity(config_name, dev, res=256, batch=1):
+    """One reference train step (train...:757-790) on the SD-1.5 topology: returns rel-L2 of the control maps, the UNet
+    prediction, the loss and the flat gradient of every trainable parameter (adapters + hint encoder)."""
+    o_unet, o_clora, p_unet, p_clora = build_pair(config_name, dev)
+    inp = inputs(res, batch)
+    gold = cases.oracle_train_step(o_unet, o_clora, o_clora, inp)
+    noisy = unet_ref.DDPMSchedule().add_noise(inp["latents"], inp["noise"], inp["timesteps"]).to(dev).to(f16)
+    trainer = ControlLoRATrainer(p_unet, p_clora, init_scale=1024.0, dynamic_scale=False)
+    pred = trainer.forward_backward(noisy, inp["timesteps"].to(dev), inp["ehs"].to(dev).to(f16),
+                                    inp["guide"].to(dev).to(f16), inp["noise"].to(dev))
+    out = {"pred": pred, "loss": torch.tensor([trainer.loss(pred.numel())]),
+           "grads": trainer.unscaled_grads_module_order()}
+    for i, c in enumerate(p_clora(inp["guide"].to(dev).to(f16)).control_states):
+        out[f"control_{i}"] = c
+    errs = {k: rel(v, gold[k]) for k, v in out.items()}
+    errs["n_trainable"] = trainer.flat.numel
+    errs["loss_value"] = float(gold["loss"])
+    # per-group gradient parity: hint encoder vs adapters (a broken adapter path must not hide behind the larger group)
+    names = [n for n, p in p_clora.named_parameters() if p.requires_grad]
+    sizes = [p.numel() for n, p in p_clora.named_parameters() if p.requires_grad]
+    gp, go = out["grads"].float().cpu(), gold["grads"].float()
+    off, acc = 0, {"adapters": [[], []], "hint": [[], []]}
+    for n, k in zip(names, sizes):
+        grp = "adapters" if n.startswith("lora_layers") else "hint"
+        acc[grp][0].append(gp[off:off + k]); acc[grp][1].append(go[off:off + k])
+        off += k
+    for grp, (a, b) in acc.items():
+        errs[f"grads_{grp}"] = rel(torch.cat(a), torch.cat(b))
+    return errs
+
+
+@torch.no_grad()
+def oracle_ddim(o_unet, o_clora, guide, cond, uncond, steps, guidance_scale, latents):
+    """CPU restatement of the inference call pattern (apps/gradio_canny2image.py:83-89: hint-encode ONE guide image,
+    the pipeline's scheduler loop with classifier-free guidance, UNet batch 2x, uncond first; DDIM eta=0 = BASELINE
+    inference config)."""
+    sch = unet_ref.DDPMSchedule()
+    o_clora(guide)
+    ehs = torch.cat([uncond, cond], 0)
+    x = latents.clone()
+    traj = []
+    for t in sch.ddim_timesteps(steps):
+        eps = o_unet(torch.cat([x, x], 0), t, ehs).sample
+        eu, ec = eps.chunk(2)
+        eps = eu + guidance_scale * (ec - eu)
+        x = sch.ddim_step(eps, t, x, steps)
+        traj.append(x.clone())
+    return x, traj
+
+
+def ddim_parity(o_unet, o_clora, p_unet, p_clora, dev, res, steps, guidance_scale=9.0, nb=1, ctx_dim=768, ctx_len=77, seed=5,
+                graph=False):
+    """denoised-latent parity: product `pipeline.ddim_sample` vs the oracle loop; rel-L2 of the final latents (the
+    quantity north_star states 1e-3 for) and of the per-step trajectory."""
+    from controllora_amd.pipeline import ddim_sample
+    g = torch.Generator().manual_seed(seed)
+    L = res // 8
+    guide = ((torch.rand(1, 3, res, res, generator=g) > 0.9).float() * 2 - 1)
+    cond = torch.randn(nb, ctx_len, ctx_dim, generator=g).half().float()
+    uncond = torch.randn(nb, ctx_len, ctx_dim, generator=g).half().float()
+    lat0 = torch.randn(nb, 4, L, L, generator=g).half().float()
+    ref, traj = oracle_ddim(o_unet, o_clora, guide, cond, uncond, steps, guidance_scale, lat0)
+    kw = dict(graph=True) if graph else {}
+    out = ddim_sample(p_unet, p_clora, guide.to(dev).half(), cond.to(dev).half(), uncond.to(dev).half(), steps=steps,
+                      guidance_scale=guidance_scale, latents=lat0.to(dev).half(), **kw)
+    return {"latents": rel(out, ref), "steps": steps, "latent_norm": float(ref.norm())}

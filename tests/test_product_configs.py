@@ -1,0 +1,54 @@
+"""Product-side pin of the 8 shipped configs (VERDICT r01 "What's missing" 6): `controllora_amd.models.ControlLoRA`
+built from every configs/*.json has exactly the reference's state-dict key set, tensor shapes and parameter count
+(reference models.py:618-808; numbers from the README / SURVEY.md section 8a H3).  With /root/reference present (build
+container) the comparison runs against the reference's OWN class imported in place; everywhere (GPU box included)
+against the committed counts and the reference-pinned oracle."""
+import os
+
+import pytest
+import torch
+
+from controllora_amd import models as M
+from oracle import controllora_ref as cr
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HAVE_REF = os.path.isdir("/root/reference")
+
+CONFIGS = [("base", 6047040, 400), ("fill50k", 6047040, 400), ("diffusiondb-canny", 6047040, 400), ("mpii-pose", 6047040, 400),
+           ("post-add", 6048576, 400), ("danbooru-sketch", 19810304, 376),
+           ("mpii-pose-v2", 5000704, 312), ("diffusiondb-canny-v2", 5000704, 312)]
+
+
+def _shapes(m):
+    return {k: tuple(v.shape) for k, v in m.state_dict().items()}
+
+
+@pytest.mark.parametrize("name,n_params,n_keys", CONFIGS)
+def test_product_controllora_keys_shapes_counts(name, n_params, n_keys):
+    path = os.path.join(ROOT, "configs", f"{name}.json")
+    prod = M.ControlLoRA.from_config(path)
+    assert sum(p.numel() for p in prod.parameters()) == n_params
+    ps = _shapes(prod)
+    assert len(ps) == n_keys
+    assert ps == _shapes(cr.ControlLoRARef.from_config(path))
+    # lora_layers layout the training script indexes (train...:470): 4 ids x [10, 10, 10, 2] processors
+    assert [len(l) for l in prod.lora_layers] == [10, 10, 10, 2]
+    if HAVE_REF and os.path.exists(f"/root/reference/configs/{name}.json"):
+        from oracle.diffusers_shim import import_reference_models
+        ref = import_reference_models().ControlLoRA.from_config(f"/root/reference/configs/{name}.json")
+        assert ps == _shapes(ref)
+        # strict load both ways: a reference checkpoint drops into the product and back
+        prod.load_state_dict(ref.state_dict())
+        ref.load_state_dict(prod.state_dict())
+
+
+@pytest.mark.parametrize("name", ["fill50k", "mpii-pose-v2", "danbooru-sketch"])
+def test_product_save_load_roundtrip_full_config(name, tmp_path):
+    prod = M.ControlLoRA.from_config(os.path.join(ROOT, "configs", f"{name}.json"))
+    with torch.no_grad():
+        for p in prod.parameters():
+            p.add_(0.01)
+    prod.save_pretrained(str(tmp_path), safe_serialization=True)
+    again = M.ControlLoRA.from_pretrained(str(tmp_path))
+    for (k, a), (_, b) in zip(prod.state_dict().items(), again.state_dict().items()):
+        assert torch.equal(a, b), k

@@ -6,7 +6,14 @@ import sqlite3
 import sys
 
 
-def main(db, out, steps=None):
+def short(n):
+    n = re.sub(r"\(anonymous namespace\)::", "", n)
+    n = re.sub(r"void ", "", n)
+    return n[:110]
+
+
+def load(db):
+    """per-kernel rows (name, calls, total / avg / min / max time) of a rocprofv3 --kernel-trace rocpd database"""
     con = sqlite3.connect(db)
     cur = con.cursor()
     cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
@@ -15,14 +22,13 @@ def main(db, out, steps=None):
     rows = cur.execute(f"select {name_col}, count(*), sum({dur}), avg({dur}), min({dur}), max({dur}) from kernels "
                        f"group by {name_col} order by 3 desc").fetchall()
     total = sum(r[2] for r in rows)
+    return [dict(kernel=short(r[0]), calls=r[1], total_ms=round(r[2] / 1e6, 3), avg_us=round(r[3] / 1e3, 2),
+                 min_us=round(r[4] / 1e3, 2), max_us=round(r[5] / 1e3, 2), pct=round(100.0 * r[2] / total, 2)) for r in rows]
 
-    def short(n):
-        n = re.sub(r"\(anonymous namespace\)::", "", n)
-        n = re.sub(r"void ", "", n)
-        return n[:110]
 
-    table = [dict(kernel=short(r[0]), calls=r[1], total_ms=round(r[2] / 1e6, 3), avg_us=round(r[3] / 1e3, 2),
-                  min_us=round(r[4] / 1e3, 2), max_us=round(r[5] / 1e3, 2), pct=round(100.0 * r[2] / total, 2)) for r in rows]
+def main(db, out, steps=None):
+    table = load(db)
+    total = sum(t["total_ms"] for t in table) * 1e6
     with open(out + ".json", "w") as f:
         json.dump(dict(total_kernel_ms=round(total / 1e6, 3), steps=steps, kernels=table), f, indent=1)
     with open(out + ".md", "w") as f:

@@ -132,6 +132,9 @@ def main(argv=None):
             logger.warning("--%s is accepted for compatibility and has no effect on this path", flag)
     if args.mixed_precision == "bf16":
         logger.warning("--mixed_precision=bf16: the gfx950 kernels compute in fp16 with fp32 accumulation; using fp16")
+    elif args.mixed_precision in (None, "no") and main_proc:
+        logger.warning("--mixed_precision=%s: this path always computes in fp16 (fp32 accumulation, fp32 master weights) "
+                       "with dynamic loss scaling; the reference would train in fp32 here", args.mixed_precision)
     if args.seed is not None:
         torch.manual_seed(args.seed + rank)            # per-rank noise / timestep streams, identical model init below
     if main_proc and args.output_dir is not None:
@@ -145,11 +148,14 @@ def main(argv=None):
     vae = loading.load_vae(name, dev)
     unet = loading.load_unet(name, dev)
     noise_scheduler = DDPMScheduler()
-    torch.manual_seed(0 if args.seed is None else args.seed)   # same adapter init on every rank (also broadcast by the trainer)
-    control_lora = M.ControlLoRA.from_config(args.control_lora_config).to(dev)
+    # Adapter init: with --seed every rank draws the same init from a forked stream (and the per-rank noise / timestep
+    # stream seeded above is left untouched); without --seed the run stays unseeded like the reference -- rank 0's init
+    # reaches the other ranks through the trainer's broadcast of the flat parameter buffer.
+    with torch.random.fork_rng(devices=[]):
+        if args.seed is not None:
+            torch.manual_seed(args.seed)
+        control_lora = M.ControlLoRA.from_config(args.control_lora_config).to(dev)
     unet.set_attn_processor(M.map_processors_to_unet(unet, control_lora))
-    if args.seed is not None:
-        torch.manual_seed(args.seed + rank)
 
     if args.scale_lr:
         args.learning_rate = args.learning_rate * args.gradient_accumulation_steps * args.train_batch_size * world
@@ -168,8 +174,10 @@ def main(argv=None):
     trainer = ControlLoRATrainer(
         unet, control_lora, lr=args.learning_rate, betas=(args.adam_beta1, args.adam_beta2), weight_decay=args.adam_weight_decay,
         eps=args.adam_epsilon, max_grad_norm=args.max_grad_norm, world_size=world,
-        init_scale=65536.0 if args.mixed_precision in ("fp16", "bf16") else 1.0,
-        dynamic_scale=args.mixed_precision in ("fp16", "bf16"), gradient_accumulation_steps=args.gradient_accumulation_steps,
+        # The kernels compute in fp16 whatever --mixed_precision says (the reference's flag defaults to None because
+        # precision normally comes from `accelerate launch --mixed_precision fp16`): a seed gradient of 2/n ~ 1e-5 is
+        # subnormal in fp16, so loss scaling with the dynamic GradScaler is ALWAYS on for this path.
+        init_scale=65536.0, dynamic_scale=True, gradient_accumulation_steps=args.gradient_accumulation_steps,
         lr_lambda=data.lr_lambda(args.lr_scheduler, args.lr_warmup_steps, args.max_train_steps))
 
     global_step, first_epoch, resume_step = 0, 0, 0
