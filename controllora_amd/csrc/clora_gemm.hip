@@ -8,10 +8,12 @@
 // frozen weight always presented K-contiguous as B[N,K] (packed once at load time; the transposed /
 // tap-flipped dgrad copy is a second packed tensor -- HBM is 288 GB, the UNet is 1.7 GB).
 //
-// Tiling: 256 threads = 4 waves, BMxBN output tile, BK = 32 (one v_mfma_f32_16x16x32_f16 k-step),
-// register-staged global->LDS double buffer (one barrier per k-step), 80-byte LDS rows (conflict-free
-// ds_read_b128 fragments), accumulators staged through LDS in the epilogue so C / residual traffic is
-// 16-byte coalesced.  split-K (grid.y) writes fp32 slabs that a second kernel reduces + finishes.
+// Tiling (gemm_dma_kernel, the product path): 256 threads = 4 waves, BMxBN output tile (256x128 ... 64x64), ring stages
+// of BK = 32 or 64 (v_mfma_f32_16x16x32_f16 k-steps) filled by LDS-DMA (`global_load_lds_dwordx4`, no staging VGPRs)
+// into an NST-deep ring with counted `s_waitcnt vmcnt` and ONE raw barrier per stage, source-side XOR swizzle
+// (conflict-free ds_read_b128 fragments from unpadded rows), XCD-aware tile order, accumulators staged through LDS in
+// the epilogue so C / residual traffic is 16-byte coalesced.  split-K (grid.y) writes fp32 slabs that a second kernel
+// reduces + finishes.  gemm_kernel below is the round-1 register-staged loop, kept for A/B runs (tile_cfg 11..13).
 #include "clora_common.h"
 #include "../../include/clora.h"
 
@@ -285,31 +287,47 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
 // Out-of-range / padding chunks are fetched from a 16-byte zero page.
 __device__ __attribute__((aligned(16))) const unsigned g_clora_zero16[4] = {0u, 0u, 0u, 0u};
 
-// blocks per CU the LDS ring allows (48 / 36 / 24 KB): the register allocator is told to leave room for them
-// (NST = 3: 48 / 36 / 24 KB -> 3 / 4 / 6 blocks; the deep rings for grids that cannot fill a CU with blocks anyway
-//  -- 5 x 16 KB, 6 x 12 KB, 8 x 8 KB -- leave 2 blocks per CU but 2-3x the bytes in flight per block)
-template <int BM, int BN, int NST> struct DmaOcc {
-    static constexpr int lds = NST * (BM + BN) * 32 * 2;
+// blocks per CU the LDS ring allows, capped by what the accumulators leave room for in the register file: the register
+// allocator is told to leave room for them.  (NST = 3, BK = 32: 48 / 36 / 24 KB -> 3 / 4 / 6 blocks; the deep rings for
+// grids that cannot fill a CU with blocks anyway -- 5 x 16 KB, 6 x 12 KB, 8 x 8 KB -- leave 2 blocks per CU but 2-3x the
+// bytes in flight per block; the 256x128 tile holds 128 accumulator registers per lane -> 2 blocks.)
+template <int BM, int BN, int NST, int BK> struct DmaOcc {
+    static constexpr int lds = NST * (BM + BN) * BK * 2;
     static constexpr int fit = (160 * 1024) / lds;
-    static constexpr int cap = (BM * BN >= 128 * 128) ? 3 : ((BM * BN >= 128 * 64) ? 4 : 5);   // 64x64 at 6 would spill (80 VGPRs)
-    static constexpr int v = fit < cap ? fit : cap;
+    static constexpr int cap = (BM * BN >= 256 * 128) ? 2 : ((BM * BN >= 128 * 128) ? 3 : ((BM * BN >= 128 * 64) ? 4 : 5));   // 64x64 at 6 would spill (80 VGPRs)
+    static constexpr int v = fit < 1 ? 1 : (fit < cap ? fit : cap);
 };
 
 // CONV: 0 = plain GEMM rows; 1 = generic gather (strided / asymmetric-pad / upsampled convs and their dgrads);
-// 2 = the common case -- 3x3, stride 1 or 2 without upsampling / parity holes, Cin % 32 == 0 (every ResnetBlock conv and
-// its dgrad, the down-samplers, the hint-encoder stages): a BK=32 step then lies
+// 2 = the common case -- 3x3, stride 1 or 2 without upsampling / parity holes, Cin % BK == 0 (every ResnetBlock conv and
+// its dgrad, the down-samplers, the hint-encoder stages): a BK step then lies
 // inside ONE filter tap for the whole wave, so the tap walk and its address delta are scalar (SALU) work and each
 // DMA instruction costs a bit test, an add and a select.  The generic path spends ~35 VALU/branch instructions per DMA
 // instruction; with four of them per 16 MFMAs that made instruction issue, not the matrix pipe, the limiter of the conv
 // GEMMs (plain GEMMs ran at ~600 TFLOP/s, the same shapes as convs at 340-540).
-template <int BM, int BN, int WM, int WN, int NST, int CONV>
-__global__ __launch_bounds__(256, (DmaOcc<BM, BN, NST>::v)) void gemm_dma_kernel(GemmArgs p) {
-    constexpr int BK = 32;
+//
+// BK: k-depth of one ring stage = one barrier.  BK = 32: 64-byte LDS rows, one DMA wave-instruction copies 16 rows x 64 B.
+// BK = 64: 128-byte LDS rows, one DMA wave-instruction copies 8 rows x 128 B -- whole cache lines per row (half the
+// address-unit work per byte, cdna_hip_programming.md "x through LDS in full lines") and half the barriers per MFMA.
+// Swizzle (applied on the SOURCE side, the DMA image is lane-linear): the lane that fills 16-byte slot `pos` of row r
+// fetches logical k-chunk pos ^ key(r), key(r) = (r >> 2) & 3 for 64-byte rows and r & 7 for 128-byte rows; fragment
+// reads apply the same involution (both conflict-free for ds_read_b128's lane groups: tools/lds_bank_check.py).
+// FLAGS bit 0 (ORD): 0 = refill the ring first, then read the fragments; 1 = fragment reads first (their latency overlaps
+// the DMA issue).  FLAGS bit 1 (64-byte rows only): key(r) = (-(r >> 2)) & 3 -- conflict-free for ds_read_b128's REAL lane
+// groups ({0-3,12-15,20-27}, ...: MI355X_MICROARCH.md section LDS), where the round-1 key is 2-way (tools/lds_bank_check.py).
+template <int BM, int BN, int WM, int WN, int NST, int CONV, int BK = 32, int FLAGS = 0>
+__global__ __launch_bounds__(256, (DmaOcc<BM, BN, NST, BK>::v)) void gemm_dma_kernel(GemmArgs p) {
+    constexpr int ORD = FLAGS & 1;
+    constexpr bool ALTKEY = (FLAGS & 2) != 0;
     constexpr int FM = BM / WM / 16, FN = BN / WN / 16;
-    constexpr int A_IN = BM / 64, B_IN = BN / 64;          // DMA wave-instructions per stage per wave
+    constexpr int CH = BK / 8;                              // 16-byte chunks per LDS row
+    constexpr int RPI = 64 / CH;                            // rows one DMA wave-instruction fills (16 or 8)
+    constexpr int KS = BK / 32;                             // MFMA k-substeps per stage
+    constexpr int A_IN = BM / RPI / 4, B_IN = BN / RPI / 4; // DMA wave-instructions per stage per wave
     constexpr int STAGE = (BM + BN) * BK;                   // halves
-    constexpr int C_LD = BN + 8;
-    constexpr int SMEM = (NST * STAGE > BM * C_LD) ? NST * STAGE : BM * C_LD;
+    constexpr int SMEM_RING = NST * STAGE;
+    constexpr int SMEM_EPI = 64 * (BN + 4) * 2;             // fp32 staging of 64 output rows, in halves
+    constexpr int SMEM = SMEM_RING > SMEM_EPI ? SMEM_RING : SMEM_EPI;
     __shared__ __attribute__((aligned(16))) half_t smem[SMEM];
 
     const int t = threadIdx.x;
@@ -332,16 +350,16 @@ __global__ __launch_bounds__(256, (DmaOcc<BM, BN, NST>::v)) void gemm_dma_kernel
     constexpr bool conv = CONV == 1;
     const half_t* zero_page = reinterpret_cast<const half_t*>(g_clora_zero16);
 
-    // ---- loader: wave w, instruction i fills rows (w*IN + i)*16 .. +16 of the tile; lane -> (row l/4, slot l%4)
-    const int lrow = l >> 2, pos = l & 3;
-    const int kc = pos ^ ((lrow >> 2) & 3);                 // logical k-chunk this lane fetches (same for all its rows)
+    // ---- loader: wave w, instruction i fills rows (w*IN + i)*RPI .. +RPI of the tile; lane -> (row l/CH, slot l%CH)
+    const int lrow = l / CH, pos = l % CH;
+    const int kc = BK == 32 ? (pos ^ ((ALTKEY ? -(lrow >> 2) : (lrow >> 2)) & 3)) : (pos ^ (lrow & 7));   // logical k-chunk this lane fetches (same for all its rows)
     bool a_ok[A_IN];
     size_t a_base[A_IN];
     int a_ty[A_IN], a_tx[A_IN];
     unsigned a_mask[A_IN];                                  // CONV == 2: bit t = filter tap t of this row is in bounds
 #pragma unroll
     for (int i = 0; i < A_IN; ++i) {
-        const int m = m0 + (w * A_IN + i) * 16 + lrow;
+        const int m = m0 + (w * A_IN + i) * RPI + lrow;
         a_ok[i] = m < p.M;
         a_base[i] = 0; a_ty[i] = 0; a_tx[i] = 0; a_mask[i] = 0;
         if (a_ok[i]) {
@@ -372,7 +390,7 @@ __global__ __launch_bounds__(256, (DmaOcc<BM, BN, NST>::v)) void gemm_dma_kernel
     size_t b_base[B_IN];
 #pragma unroll
     for (int i = 0; i < B_IN; ++i) {
-        const int n = n0 + (w * B_IN + i) * 16 + lrow;
+        const int n = n0 + (w * B_IN + i) * RPI + lrow;
         b_ok[i] = n < p.N;
         b_base[i] = (size_t)n * p.K;
     }
@@ -387,19 +405,19 @@ __global__ __launch_bounds__(256, (DmaOcc<BM, BN, NST>::v)) void gemm_dma_kernel
         half_t* As = smem + buf * STAGE;
         half_t* Bs = As + BM * BK;
         if (CONV == 2) {
-            const bool kokq = kq < kend;                    // K = 9*Cin and the split size are multiples of 32: whole stages only
+            const bool kokq = kq < kend;                    // K = 9*Cin and the split size are multiples of BK: whole stages only
             const int qky = qtap / 3, qkx = qtap - qky * 3;
             const long delta = ((long)(p.conv.off + qky * p.conv.kmul) * p.conv.Win + (p.conv.off + qkx * p.conv.kmul)) * p.conv.Cin + qci;
 #pragma unroll
             for (int i = 0; i < A_IN; ++i) {
                 const bool ok = kokq && ((a_mask[i] >> qtap) & 1u);
                 const half_t* src = ok ? p.A + (long)a_base[i] + delta : zero_page;
-                CLORA_GLDS16(src, As + (w * A_IN + i) * 16 * BK);
+                CLORA_GLDS16(src, As + (w * A_IN + i) * RPI * BK);
             }
 #pragma unroll
             for (int i = 0; i < B_IN; ++i) {
                 const half_t* src = (b_ok[i] && kokq) ? p.B + b_base[i] + kq + kc * 8 : zero_page;
-                CLORA_GLDS16(src, Bs + (w * B_IN + i) * 16 * BK);
+                CLORA_GLDS16(src, Bs + (w * B_IN + i) * RPI * BK);
             }
             kq += BK;
             qci += BK;
@@ -423,12 +441,12 @@ __global__ __launch_bounds__(256, (DmaOcc<BM, BN, NST>::v)) void gemm_dma_kernel
                         src = p.A + (a_base[i] + (size_t)(ty >> p.conv.shift) * p.conv.Win + (tx >> p.conv.shift)) * p.conv.Cin + ci;
                 }
             }
-            CLORA_GLDS16(src, As + (w * A_IN + i) * 16 * BK);
+            CLORA_GLDS16(src, As + (w * A_IN + i) * RPI * BK);
         }
 #pragma unroll
         for (int i = 0; i < B_IN; ++i) {
             const half_t* src = (b_ok[i] && kok) ? p.B + b_base[i] + k : zero_page;
-            CLORA_GLDS16(src, Bs + (w * B_IN + i) * 16 * BK);
+            CLORA_GLDS16(src, Bs + (w * B_IN + i) * RPI * BK);
         }
         k += BK;
         if (conv) {
@@ -438,7 +456,10 @@ __global__ __launch_bounds__(256, (DmaOcc<BM, BN, NST>::v)) void gemm_dma_kernel
     };
 
     const int wm = w / WN, wn = w % WN;
-    const int fsw = ((g ^ (li >> 2)) & 3) * 8;               // swizzled slot of logical chunk g for rows == li (mod 16)
+    // swizzled 16-byte slot of logical chunk (ks*4 + g) for fragment rows == li (mod 16)
+    int fsw[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) fsw[ks] = (BK == 32 ? ((g ^ (ALTKEY ? -(li >> 2) : (li >> 2))) & 3) : ((ks * 4 + g) ^ (li & 7))) * 8;
     floatx4 acc[FM][FN];
 #pragma unroll
     for (int i = 0; i < FM; ++i)
@@ -453,20 +474,25 @@ __global__ __launch_bounds__(256, (DmaOcc<BM, BN, NST>::v)) void gemm_dma_kernel
     for (int kt = 0; kt < nk; ++kt) {
         CLORA_WAIT_VMCNT((NST - 2) * (A_IN + B_IN));          // stage kt has landed (loads retire in order)
         CLORA_RAW_BARRIER();                                   // ... for every wave, and stage kt-1 is fully consumed
-        issue_stage(wr);
-        wr = (wr + 1 == NST) ? 0 : wr + 1;
+        if (ORD == 0) { issue_stage(wr); wr = (wr + 1 == NST) ? 0 : wr + 1; }
         const half_t* As = smem + rd * STAGE;
         const half_t* Bs = As + BM * BK;
         rd = (rd + 1 == NST) ? 0 : rd + 1;
-        half8 af[FM], bf[FN];
+        half8 af[KS][FM], bf[KS][FN];
 #pragma unroll
-        for (int i = 0; i < FM; ++i) af[i] = ld8(As + (wm * FM * 16 + i * 16 + li) * BK + fsw);
+        for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
-        for (int j = 0; j < FN; ++j) bf[j] = ld8(Bs + (wn * FN * 16 + j * 16 + li) * BK + fsw);
+            for (int i = 0; i < FM; ++i) af[ks][i] = ld8(As + (wm * FM * 16 + i * 16 + li) * BK + fsw[ks]);
 #pragma unroll
-        for (int i = 0; i < FM; ++i)
+            for (int j = 0; j < FN; ++j) bf[ks][j] = ld8(Bs + (wn * FN * 16 + j * 16 + li) * BK + fsw[ks]);
+        }
+        if (ORD == 1) { issue_stage(wr); wr = (wr + 1 == NST) ? 0 : wr + 1; }
 #pragma unroll
-            for (int j = 0; j < FN; ++j) acc[i][j] = mfma16(af[i], bf[j], acc[i][j]);
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) acc[i][j] = mfma16(af[ks][i], bf[ks][j], acc[i][j]);
     }
     CLORA_WAIT_VMCNT(0);                                       // trailing zero-page stages: LDS is reused below
 
@@ -486,23 +512,25 @@ __global__ __launch_bounds__(256, (DmaOcc<BM, BN, NST>::v)) void gemm_dma_kernel
     }
     // ---- epilogue: fp32 accumulators -> LDS (64 rows per pass) -> per row-chunk: bias / time-embedding / rank-r
     // adapter update (float4 operand loads) -> fp16 -> + residual -> 16-byte coalesced stores.  Doing the fused
-    // math AFTER the LDS hop keeps it out of the main loop's register budget (3 blocks per CU).
+    // math AFTER the LDS hop keeps it out of the main loop's register budget.
     constexpr int PR = 64, F_LD = BN + 4, NPASS = BM / PR;
-    static_assert(PR * F_LD * 2 <= SMEM, "fp32 staging must fit in the ring buffer");
+    static_assert(PR * F_LD * 2 <= SMEM, "fp32 staging must fit in the LDS allocation");
     float* Cf = reinterpret_cast<float*>(smem);
     constexpr int CPR = BN / 8;
 #pragma unroll
     for (int ph = 0; ph < NPASS; ++ph) {
         __syncthreads();                                       // ring (or previous pass) fully consumed
         const int wrow0 = wm * FM * 16;                        // first tile row of this wave
-        if (wrow0 >= ph * PR && wrow0 < (ph + 1) * PR) {
 #pragma unroll
-            for (int i = 0; i < FM; ++i)
+        for (int i = 0; i < FM; ++i) {
+            const int frow = wrow0 + i * 16;                   // this fragment's 16 rows lie inside one 64-row pass
+            if (frow >= ph * PR && frow < (ph + 1) * PR) {
 #pragma unroll
                 for (int j = 0; j < FN; ++j)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        Cf[(wrow0 - ph * PR + i * 16 + 4 * g + r) * F_LD + wn * FN * 16 + j * 16 + li] = acc[i][j][r];
+                        Cf[(frow - ph * PR + 4 * g + r) * F_LD + wn * FN * 16 + j * 16 + li] = acc[i][j][r];
+            }
         }
         __syncthreads();
         for (int c = t; c < PR * CPR; c += 256) {
@@ -745,24 +773,24 @@ __global__ __launch_bounds__(256) void conv_weight_pack_kernel(const float* w, i
 }
 
 // which gather the DMA main loop is instantiated for (see gemm_dma_kernel)
-int conv_mode(const GemmArgs& a) {
+int conv_mode(const GemmArgs& a, int bk) {
     const clora_conv_t& c = a.conv;
     if (!c.enabled) return 0;
     const bool fast = c.ksize == 3 && c.shift == 0 && c.need_even == 0 && (c.kmul == 1 || c.kmul == -1) &&
-                      (c.Cin % 32) == 0 && (a.k_per_split % 32) == 0 && c.lim_h == c.Hin && c.lim_w == c.Win;
+                      (c.Cin % bk) == 0 && (a.k_per_split % bk) == 0 && c.lim_h == c.Hin && c.lim_w == c.Win;
     return fast ? 2 : 1;
 }
 
-template <int BM, int BN, int WM, int WN, int NST = 3>
+template <int BM, int BN, int WM, int WN, int NST = 3, int BK = 32, int FLAGS = 0>
 int launch_gemm(GemmArgs& a, int splits, hipStream_t s, bool dma) {
     a.tiles_n = clora_cdiv(a.N, BN);
     const int tiles_m = clora_cdiv(a.M, BM);
     const dim3 grid(tiles_m * a.tiles_n, splits);
     if (dma) {
-        const int cm = conv_mode(a);
-        if (cm == 0) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, WM, WN, NST, 0>), grid, dim3(256), 0, s, a);
-        else if (cm == 1) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, WM, WN, NST, 1>), grid, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, WM, WN, NST, 2>), grid, dim3(256), 0, s, a);
+        const int cm = conv_mode(a, BK);
+        if (cm == 0) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, WM, WN, NST, 0, BK, FLAGS>), grid, dim3(256), 0, s, a);
+        else if (cm == 1) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, WM, WN, NST, 1, BK, FLAGS>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, WM, WN, NST, 2, BK, FLAGS>), grid, dim3(256), 0, s, a);
     }
     else hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN>), dim3(tiles_m * a.tiles_n, splits), dim3(256), 0, s, a);
     return clora_check_launch();
@@ -831,25 +859,55 @@ extern "C" int clora_gemm_f16_ex(const clora_half* A, int lda, const clora_half*
         const int ksteps = clora_cdiv(K, 32);
         splits = split_k > ksteps ? ksteps : split_k;
     }
-    bool dma = true;                       // tile_cfg 11..13 = the register-staged v1 main loop (A/B comparisons)
+    // tile_cfg: 0 = the latency model's choice among 1..3;
+    //   1..3  = 128x128 / 128x64 / 64x64, BK 32, 3-stage ring        4..6 = the same tiles with the deep ring (5 / 6 / 8 stages)
+    //   7, 8  = 256x128 (wave tile 128x64), BK 32, 3 stages; 8 reads its fragments before refilling the ring
+    //   11..13 = the register-staged v1 main loop (A/B comparisons)
+    //   21..26 = BK 64 (128-byte LDS rows, whole-line DMA): 128x128 x2 stages, 128x64 x3, 64x64 x3, 128x128 x3, 256x128 x2, 128x64 x2
+    //   31..33 = 1..3 and 41..43 = 21..23 with fragment reads before the ring refill
+    //   51..53, 57 = 1..3, 7 with the conflict-free 64-byte-row key; 61..63, 67 = both
+    bool dma = true;
     if (tile_cfg >= 11 && tile_cfg <= 13) { dma = false; tile_cfg -= 10; }
-    bool deep = false;                     // tile_cfg 4..6 = the same tiles with the deep LDS ring (few-block grids)
-    if (tile_cfg >= 4 && tile_cfg <= 6) { deep = true; tile_cfg -= 3; }
-    if (tile_cfg >= 1 && tile_cfg <= 3) tile = tile_cfg - 1;
-    a.k_per_split = clora_cdiv(clora_cdiv(K, 32), splits) * 32;
+    const int cfg = tile_cfg > 0 ? tile_cfg : tile + 1;
+    const int bk = ((cfg >= 21 && cfg <= 26) || (cfg >= 41 && cfg <= 43)) ? 64 : 32;
+    a.k_per_split = clora_cdiv(clora_cdiv(K, bk), splits) * bk;
     splits = clora_cdiv(K, a.k_per_split);
     if (splits > 1) {
         if (!workspace || workspace_bytes < (size_t)splits * M * N * sizeof(float)) return CLORA_ERR_WORKSPACE;
         a.partial = (float*)workspace;
     }
     int rc;
-    if (deep) {
-        if (tile == 0) rc = launch_gemm<128, 128, 2, 2, 5>(a, splits, s, true);
-        else if (tile == 1) rc = launch_gemm<128, 64, 4, 1, 6>(a, splits, s, true);
-        else rc = launch_gemm<64, 64, 2, 2, 8>(a, splits, s, true);
-    } else if (tile == 0) rc = launch_gemm<128, 128, 2, 2>(a, splits, s, dma);
-    else if (tile == 1) rc = launch_gemm<128, 64, 4, 1>(a, splits, s, dma);
-    else rc = launch_gemm<64, 64, 2, 2>(a, splits, s, dma);
+    switch (cfg) {
+        case 1: rc = launch_gemm<128, 128, 2, 2>(a, splits, s, dma); break;
+        case 2: rc = launch_gemm<128, 64, 4, 1>(a, splits, s, dma); break;
+        case 3: rc = launch_gemm<64, 64, 2, 2>(a, splits, s, dma); break;
+        case 4: rc = launch_gemm<128, 128, 2, 2, 5>(a, splits, s, true); break;
+        case 5: rc = launch_gemm<128, 64, 4, 1, 6>(a, splits, s, true); break;
+        case 6: rc = launch_gemm<64, 64, 2, 2, 8>(a, splits, s, true); break;
+        case 7: rc = launch_gemm<256, 128, 2, 2, 3, 32, 0>(a, splits, s, true); break;
+        case 8: rc = launch_gemm<256, 128, 2, 2, 3, 32, 1>(a, splits, s, true); break;
+        case 21: rc = launch_gemm<128, 128, 2, 2, 2, 64, 0>(a, splits, s, true); break;
+        case 22: rc = launch_gemm<128, 64, 4, 1, 3, 64, 0>(a, splits, s, true); break;
+        case 23: rc = launch_gemm<64, 64, 2, 2, 3, 64, 0>(a, splits, s, true); break;
+        case 24: rc = launch_gemm<128, 128, 2, 2, 3, 64, 0>(a, splits, s, true); break;
+        case 25: rc = launch_gemm<256, 128, 2, 2, 2, 64, 0>(a, splits, s, true); break;
+        case 26: rc = launch_gemm<128, 64, 4, 1, 2, 64, 0>(a, splits, s, true); break;
+        case 31: rc = launch_gemm<128, 128, 2, 2, 3, 32, 1>(a, splits, s, true); break;
+        case 32: rc = launch_gemm<128, 64, 4, 1, 3, 32, 1>(a, splits, s, true); break;
+        case 33: rc = launch_gemm<64, 64, 2, 2, 3, 32, 1>(a, splits, s, true); break;
+        case 51: rc = launch_gemm<128, 128, 2, 2, 3, 32, 2>(a, splits, s, true); break;
+        case 52: rc = launch_gemm<128, 64, 4, 1, 3, 32, 2>(a, splits, s, true); break;
+        case 53: rc = launch_gemm<64, 64, 2, 2, 3, 32, 2>(a, splits, s, true); break;
+        case 57: rc = launch_gemm<256, 128, 2, 2, 3, 32, 2>(a, splits, s, true); break;
+        case 61: rc = launch_gemm<128, 128, 2, 2, 3, 32, 3>(a, splits, s, true); break;
+        case 62: rc = launch_gemm<128, 64, 4, 1, 3, 32, 3>(a, splits, s, true); break;
+        case 63: rc = launch_gemm<64, 64, 2, 2, 3, 32, 3>(a, splits, s, true); break;
+        case 67: rc = launch_gemm<256, 128, 2, 2, 3, 32, 3>(a, splits, s, true); break;
+        case 41: rc = launch_gemm<128, 128, 2, 2, 2, 64, 1>(a, splits, s, true); break;
+        case 42: rc = launch_gemm<128, 64, 4, 1, 3, 64, 1>(a, splits, s, true); break;
+        case 43: rc = launch_gemm<64, 64, 2, 2, 3, 64, 1>(a, splits, s, true); break;
+        default: return CLORA_ERR_ARG;
+    }
     if (rc != CLORA_OK) return rc;
     if (splits > 1) {
         const size_t chunks = (size_t)M * (N / 8);

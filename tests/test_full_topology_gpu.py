@@ -18,8 +18,9 @@ from tests import full_cases as F
 
 pytestmark = pytest.mark.gpu
 
-# measured on MI355X (r02): pred 2.2-2.6e-3, control maps 0.5-1.0e-3, loss <= 2e-4, flat gradient 3-5e-3
-TOL = dict(pred=5e-3, control=2.5e-3, loss=1e-3, grads=1e-2, grads_adapters=1.2e-2, grads_hint=1e-2)
+# measured on MI355X (r02, fill50k): pred 1.7e-3, control maps 1.9-2.9e-3, loss 2.5e-5, flat gradient 1.2e-3 (adapters
+# 1.1e-3, hint encoder 4.5e-3); limits are <= 2x the measured values
+TOL = dict(pred=3.5e-3, control=5e-3, loss=2e-4, grads=3e-3, grads_adapters=3e-3, grads_hint=9e-3)
 
 
 @pytest.mark.parametrize("config", ["fill50k.json", "mpii-pose-v2.json", "danbooru-sketch.json"])

@@ -33,7 +33,10 @@ def test_conv_small_channels():
     KC.case_conv("cpu", 1, 16, 16, 8, 32)       # hint-encoder conv_in shape class (3 -> padded 8 channels)
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6])
+ALL_TILE_CFGS = [1, 2, 3, 4, 5, 6, 7, 8, 21, 22, 23, 24, 25, 26, 31, 32, 33, 41, 42, 43, 51, 52, 53, 57, 61, 62, 63, 67]
+
+
+@pytest.mark.parametrize("tile", ALL_TILE_CFGS)
 def test_gemm_tile_configs(tile):
     """every main-loop variant (tile shape x ring depth), with ragged M/N/K, split-K and the fused epilogue"""
     KC.case_gemm_plain("cpu", 150, 72, 104, 1, tile_cfg=tile)
@@ -87,7 +90,7 @@ def test_conv_padded_channels_pack_and_oihw_grad():
     KC.case_conv_padded_channels("cpu")
 
 
-@pytest.mark.parametrize("tile", [1, 3, 5])
+@pytest.mark.parametrize("tile", [1, 3, 5, 7, 21, 23, 25, 42, 57, 63])
 def test_conv_fast_path_uniform_taps(tile):
     """3x3 stride-1 convs with Cin % 32 == 0 take the wave-uniform tap walk (CONV == 2) in forward and dgrad"""
     KC.case_conv("cpu", 1, 6, 5, 32, 64, tile_cfg=tile)

@@ -41,13 +41,17 @@ def test_conv_small_channels():
     KC.case_conv(DEV, 1, 64, 64, 8, 32)
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6])
+ALL_TILE_CFGS = [1, 2, 3, 4, 5, 6, 7, 8, 21, 22, 23, 24, 25, 26, 31, 32, 33, 41, 42, 43, 51, 52, 53, 57, 61, 62, 63, 67]
+
+
+@pytest.mark.parametrize("tile", ALL_TILE_CFGS)
 def test_gemm_tile_configs(tile):
     """every main-loop variant (tile shape x ring depth), with ragged M/N/K, split-K and the fused epilogue"""
     KC.case_gemm_plain(DEV, 1000, 328, 1256, 1, tile_cfg=tile)
     KC.case_gemm_plain(DEV, 333, 640, 2568, 3, tile_cfg=tile)
     KC.case_gemm_epilogue(DEV, M=2000, N=320, K_=320, split_k=1, tile_cfg=tile)
     KC.case_conv(DEV, 2, 32, 32, 64, 128, tile_cfg=tile)
+    KC.case_conv(DEV, 1, 32, 32, 320, 320, tile_cfg=tile)          # Cin % 64 == 0: the BK = 64 variants take the fast tap walk
 
 
 @pytest.mark.parametrize("B,H,Nq,Nk,D,fused", [
