@@ -35,7 +35,8 @@ class Epilogue(C.Structure):
     """mirror of clora_epilogue_t"""
     _fields_ = [("bias", C.c_void_p), ("rowadd", C.c_void_p), ("rows_per_batch", C.c_int), ("ld_rowadd", C.c_int),
                 ("residual", C.c_void_p), ("ldr", C.c_int), ("lora_t", C.c_void_p), ("ldt", C.c_int),
-                ("lora_u", C.c_void_p), ("ldu", C.c_int), ("lora_u_tr", C.c_int), ("lora_r", C.c_int), ("lora_seg", C.c_int), ("lora_scale", C.c_float)]
+                ("lora_u", C.c_void_p), ("ldu", C.c_int), ("lora_u_tr", C.c_int), ("lora_r", C.c_int), ("lora_seg", C.c_int), ("lora_scale", C.c_float),
+                ("geglu", C.c_int), ("geglu_f", C.c_int), ("geglu_h", C.c_void_p), ("geglu_y", C.c_void_p)]
 
 
 class LoraDownJob(C.Structure):

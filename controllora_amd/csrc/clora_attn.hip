@@ -17,7 +17,11 @@
 //     and the A operand (V^T, K^T, Q^T, dO^T) is fetched with the same slot assignment from ROW-MAJOR LDS tiles by
 //     the transpose read ds_read_b64_tr_b16 (frag_tr) -- the hardware only pairs slot e of lane-group g of A with
 //     slot e of group g of B; no transposed copies, no 2-byte scatter stores;
-//   * head dims 40 / 80 / 160 are zero-padded to 64 / 96 / 160 along the contraction dim only.
+//   * head dims 40 / 80 / 160 are zero-padded to 64 / 96 / 160 along the contraction dim only;
+//   * LDS tile pitches are == 32 bytes (mod 64): pitch/4 == 8 (mod 16) banks, so the 8 rows one half-wave touches in a
+//     transpose read start on 8 distinct multiples of 8 banks (conflict-free ds_read_b64_tr_b16) and the ds_read_b128
+//     fragment reads are conflict-free for the hardware's real lane groups as well (MI355X_MICROARCH.md section LDS;
+//     the round-1 pitch DP + 8 was 2-way conflicted for both).
 #include "clora_common.h"
 #include "../../include/clora.h"
 
@@ -97,7 +101,7 @@ __device__ __forceinline__ void tile_store_rows(const TileRegs<ROWS, DP>& r, hal
 // spill at 256 registers and keep the default.
 template <int DP, int DT>
 __global__ __launch_bounds__(256, (DP <= 64 ? 2 : 1)) void attn_fwd_kernel(AttnArgs p) {
-    constexpr int BKV = 64, LDK = DP + 8, LDV = DT * 16 + 8, KS = DP / 32, DV = DT * 16;
+    constexpr int BKV = 64, LDK = DP + 16, DV = DT * 16, LDV = DV + ((DV % 32) == 16 ? 0 : 16), KS = DP / 32;
     __shared__ __attribute__((aligned(16))) half_t smem[BKV * LDK + BKV * LDV];
     half_t* Ks = smem;
     half_t* Vs = smem + BKV * LDK;                         // V row-major [key][d]; read transposed (frag_tr) for P.V
@@ -225,7 +229,7 @@ __global__ __launch_bounds__(256, (DP <= 64 ? 2 : 1)) void attn_fwd_kernel(AttnA
 // ------------------------------------------------------------------------------------------ dQ
 template <int DP, int DT, int BKV>
 __global__ __launch_bounds__(256, (DP <= 64 ? 2 : 1)) void attn_bwd_dq_kernel(AttnArgs p) {
-    constexpr int LDK = DP + 8, KS = DP / 32, KT = BKV / 16, NP = BKV / 32;
+    constexpr int LDK = DP + 16, KS = DP / 32, KT = BKV / 16, NP = BKV / 32;
     __shared__ __attribute__((aligned(16))) half_t smem[2 * BKV * LDK];
     half_t* Ks = smem;                                     // K row-major: A operand of S^T as is, of dQ^T through frag_tr
     half_t* Vs = smem + BKV * LDK;
@@ -364,7 +368,7 @@ __global__ __launch_bounds__(256, (DP <= 64 ? 2 : 1)) void attn_bwd_dq_kernel(At
 // ------------------------------------------------------------------------------------------ dK, dV
 template <int DP, int DT, int BQT>
 __global__ __launch_bounds__(256, (DP <= 64 ? 2 : 1)) void attn_bwd_dkv_kernel(AttnArgs p) {
-    constexpr int LDK = DP + 8, KS = DP / 32, QT = BQT / 16, NP = BQT / 32;
+    constexpr int LDK = DP + 16, KS = DP / 32, QT = BQT / 16, NP = BQT / 32;
     constexpr int HALVES = 2 * BQT * LDK;
     __shared__ __attribute__((aligned(16))) half_t smem[HALVES + 4 * BQT];
     half_t* Qs = smem;                                     // Q, dO row-major: A operands of S / dP as is, of dK / dV through frag_tr

@@ -101,6 +101,7 @@ def workspace(nbytes: int, device) -> torch.Tensor:
 
 
 _ws_retired = []
+WIDE_TILE_CFGS = (1, 4, 7, 8, 9, 21, 31, 41)      # tile_cfg values whose tiles are >= 128 columns wide (GEGLU-forward epilogue)
 GEMM_WS_BYTES = 256 << 20   # split-K slab budget handed to the library's launch planner
 
 # Autotuned launch configurations (tools/tune_gemm.py on an MI355X): exact-shape lookups for the GEMMs of the
@@ -129,13 +130,27 @@ def gemm(A: torch.Tensor, Bw: torch.Tensor, M: int, N: int, K: int, *, lda: Opti
          conv: Optional[ConvDesc] = None, bias=None, rowadd=None, rows_per_batch=0, residual=None,
          lora_t=None, lora_u=None, lora_seg=0, lora_scale=1.0, lora_u_tr=False, lora_r=None,
          out: Optional[torch.Tensor] = None,
-         split_k: int = 0, tile_cfg: int = 0, _tuned: bool = True) -> torch.Tensor:
-    """C[M,N] = A . Bw^T with the fused epilogue of clora_epilogue_t."""
+         split_k: int = 0, tile_cfg: int = 0, _tuned: bool = True,
+         geglu: int = 0, geglu_h: Optional[torch.Tensor] = None, geglu_y: Optional[torch.Tensor] = None,
+         geglu_keep_h: bool = True) -> torch.Tensor:
+    """C[M,N] = A . Bw^T with the fused epilogue of clora_epilogue_t.
+    geglu=1 (Bw / bias packed by ops.GegluPack, N = 2F): returns (y [M,F], h [M,2F] or None when not geglu_keep_h);
+    geglu=2 (N = F, geglu_h = the saved h): returns dh [M, 2F]."""
     assert A.dtype == f16 and Bw.dtype == f16 and Bw.shape == (N, K) and Bw.is_contiguous()
-    C_ = out if out is not None else torch.empty((M, N), dtype=f16, device=A.device)
-    assert C_.dtype == f16 and C_.stride(-1) == 1
-    ldc = C_.stride(0) if C_.dim() == 2 else N
     e = Epilogue()
+    if geglu == 1:
+        F_ = N // 2
+        C_ = torch.empty((M, N), dtype=f16, device=A.device) if geglu_keep_h else None
+        y = geglu_y if geglu_y is not None else torch.empty((M, F_), dtype=f16, device=A.device)
+        e.geglu, e.geglu_f, e.geglu_y = 1, F_, ptr(y, f16)
+    elif geglu == 2:
+        assert geglu_h is not None and geglu_h.shape == (M, 2 * N) and geglu_h.is_contiguous()
+        C_ = out if out is not None else torch.empty((M, 2 * N), dtype=f16, device=A.device)
+        e.geglu, e.geglu_f, e.geglu_h = 2, N, ptr(geglu_h, f16)
+    else:
+        C_ = out if out is not None else torch.empty((M, N), dtype=f16, device=A.device)
+    assert C_ is None or (C_.dtype == f16 and C_.stride(-1) == 1)
+    ldc = (C_.stride(0) if C_.dim() == 2 else N) if C_ is not None else N
     if bias is not None:
         assert bias.dtype == f32 and bias.numel() == N
         e.bias = ptr(bias)
@@ -154,12 +169,18 @@ def gemm(A: torch.Tensor, Bw: torch.Tensor, M: int, N: int, K: int, *, lda: Opti
         hit = globals()["_tuned"](M, N, K, conv)
         if hit is not None:
             tile_cfg, split_k = hit
+    if geglu:
+        split_k = 1
+        if geglu == 1 and tile_cfg not in WIDE_TILE_CFGS:
+            tile_cfg = 0                       # the library picks a >= 128-column tile itself
     ws = workspace(GEMM_WS_BYTES if split_k == 0 else max(split_k, 1) * M * N * 4, A.device) if split_k != 1 else None
-    _call("clora_gemm_f16_ex", ptr(A), lda if lda is not None else K, ptr(Bw), ptr(C_), ldc, M, N, K,
+    _call("clora_gemm_f16_ex", ptr(A), lda if lda is not None else K, ptr(Bw), ptr(C_) if C_ is not None else None, ldc, M, N, K,
           C.byref(conv) if conv is not None else None, C.byref(e), split_k, tile_cfg,
           ptr(ws) if ws is not None else None, ws.numel() if ws is not None else 0,
           flops=2.0 * M * N * K, nbytes=2.0 * (A.numel() + N * K + M * N),
           tag=f"{M}x{N}x{K}{'conv' if conv is not None else ''}")
+    if geglu == 1:
+        return y, C_
     return C_
 
 

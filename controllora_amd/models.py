@@ -49,6 +49,29 @@ def _flat2(t):
     return t.reshape(-1, t.shape[-1])
 
 
+# ---- inference-only cache of the cross-attention K/V projections.  k = Wk e + s Lk(e), v = Wv e + s Lv(e) depend on the
+# text embedding and the (frozen, at inference) adapters only -- not on the latents or the timestep -- so a scheduler loop
+# (apps/gradio_canny2image.py:85-88: 50 UNet calls per image) needs them once.  Active only inside `text_kv_cache()` and
+# only with autograd off; keyed per processor on the embedding's storage / version / shape and the call's scale.
+_TEXT_KV = None
+
+
+class text_kv_cache:
+    def __init__(self, enabled=True):
+        self.enabled = enabled
+
+    def __enter__(self):
+        global _TEXT_KV
+        self._prev = _TEXT_KV
+        _TEXT_KV = {} if self.enabled else None
+        return self
+
+    def __exit__(self, *exc):
+        global _TEXT_KV
+        _TEXT_KV = self._prev
+        return False
+
+
 class LoRACrossAttnProcessor(nn.Module):
     fuses_residual = True
     version = 0
@@ -150,8 +173,14 @@ class LoRACrossAttnProcessor(nn.Module):
         packs = attn.fused_packs()
         if attn.is_cross:
             q = ops.lora_proj(h2, packs[0], [self._seg("to_q_lora", q_in, scale)])
-            kv = ops.lora_proj(e2, packs[1], [self._seg("to_k_lora", e2, scale, self.key_states_skipped),
-                                             self._seg("to_v_lora", e2, scale, self.value_states_skipped)])
+            cache = _TEXT_KV if not torch.is_grad_enabled() else None
+            key = (id(self), id(attn), e2.data_ptr(), e2._version, tuple(e2.shape), float(scale)) if cache is not None else None
+            kv = cache.get(key) if cache is not None else None
+            if kv is None:
+                kv = ops.lora_proj(e2, packs[1], [self._seg("to_k_lora", e2, scale, self.key_states_skipped),
+                                                 self._seg("to_v_lora", e2, scale, self.value_states_skipped)])
+                if cache is not None:
+                    cache[key] = kv
             a = attn.attend(q, kv, B, N, Nk)
         else:
             qkv = ops.lora_proj(h2, packs[0], [self._seg("to_q_lora", q_in, scale),

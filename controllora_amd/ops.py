@@ -38,6 +38,26 @@ class LinearPack:
             self.bias = torch.cat([b, b.new_zeros(Np - N)]) if Np != N else b.contiguous()
 
 
+class GegluPack:
+    """`FeedForward.net[0].proj` (Linear(C, 8C), upstream GEGLU) packed for the fused activation epilogue: the forward
+    operand's rows (and the bias) are regrouped as [64 a-columns | the 64 matching g-columns] per 128 (include/clora.h
+    `geglu`); the dgrad operand stays in the standard layout because the epilogues read / write h = (a | g) that way."""
+
+    def __init__(self, weight: torch.Tensor, bias: Optional[torch.Tensor]):
+        w = weight.detach().to(f16)
+        N, Kd = w.shape
+        F_ = N // 2
+        assert N % 128 == 0 and Kd % 8 == 0
+        idx = torch.arange(N, device=w.device).reshape(N // 128, 2, 64)
+        src = torch.where(torch.arange(2, device=w.device).reshape(1, 2, 1) == 0,
+                          (idx[:, :1] // 128) * 64 + idx[:, :1] % 64,
+                          F_ + (idx[:, 1:] // 128) * 64 + idx[:, 1:] % 64).reshape(-1)
+        self.N, self.K, self.F = N, Kd, F_
+        self.w = w[src].contiguous()                 # forward operand, grouped rows
+        self.wt = w.t().contiguous()                 # dgrad operand [K, 2F], standard column order
+        self.bias = bias.detach().to(f32)[src].contiguous() if bias is not None else None
+
+
 class ConvPack:
     """Frozen 3x3 conv: forward operand [Co, 9*Ci] in (ky,kx,ci) order, dgrad operand [Ci, 9*Co] in
     (ky,kx,co) order (the gather descriptor walks the taps with kmul = -1, so no flip is needed)."""
@@ -194,6 +214,40 @@ class _GegluFn(torch.autograd.Function):
 
 def geglu(h):
     return _GegluFn.apply(h)
+
+
+class _FeedForwardFn(torch.autograd.Function):
+    """out = W2 . (a * gelu_erf(g)) + b2 (+ residual), (a | g) = W1 x + b1 -- upstream FeedForward(GEGLU)
+    as TWO launches each way: the activation rides in the `proj` GEMM's epilogue and its derivative in the epilogue of the
+    dgrad GEMM of `out`; h = (a | g) is what is kept for the backward (the round-1 path ran separate geglu kernels that
+    re-read h: 69 + 46 MB per launch at level 0)."""
+
+    @staticmethod
+    def forward(ctx, x, pack1: "GegluPack", pack2: LinearPack, residual):
+        M = x.shape[0]
+        need = ctx.needs_input_grad[0]            # inference: h = (a | g) is never written
+        y, h = K.gemm(x, pack1.w, M, pack1.N, pack1.K, bias=pack1.bias, geglu=1, geglu_keep_h=need)
+        out = K.gemm(y, pack2.w, M, pack2.N, pack2.K, bias=pack2.bias, residual=residual)
+        ctx.packs, ctx.has_res = (pack1, pack2), residual is not None
+        if need:
+            ctx.save_for_backward(h)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        dout = dout.contiguous()
+        (h,) = ctx.saved_tensors
+        p1, p2 = ctx.packs
+        M = dout.shape[0]
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dh = K.gemm(dout, p2.wt, M, p2.K, p2.N, geglu=2, geglu_h=h)          # [M, 2F] = d(a | g)
+            dx = K.gemm(dh, p1.wt, M, p1.K, p1.N)
+        return dx, None, None, (dout if ctx.has_res and ctx.needs_input_grad[3] else None)
+
+
+def feed_forward(x, pack1: "GegluPack", pack2: LinearPack, residual=None):
+    return _FeedForwardFn.apply(x, pack1, pack2, residual)
 
 
 class _AddFn(torch.autograd.Function):

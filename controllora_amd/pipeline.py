@@ -11,9 +11,16 @@ from .schedulers import DDIMScheduler, DPMSolverMultistepScheduler
 
 @torch.no_grad()
 def ddim_sample(unet, control_lora, guide, cond_emb, uncond_emb, steps=50, guidance_scale=9.0, latents=None,
-                generator=None, sampler="ddim"):
+                generator=None, sampler="ddim", graph=None, cache_text_kv=True):
     """guide [Bc,3,H,W] (control batch 1 broadcasts over the CFG batch, quirk C6); cond/uncond [B,77,768].
-    sampler: "ddim" (BASELINE inference config) or "dpm" (DPM-Solver++(2M), what the reference apps select)."""
+    sampler: "ddim" (BASELINE inference config) or "dpm" (DPM-Solver++(2M), what the reference apps select).
+
+    What is invariant over the scheduler loop is evaluated ONCE: the hint encoder and the 32 control terms (reference
+    apps/gradio_canny2image.py:84 -- the processors keep the control states), and with `cache_text_kv` the cross-attention
+    K/V projections of the text embedding with their adapters (16 sites; they depend on neither the latents nor the
+    timestep).  graph: replay ONE captured hipGraph of the UNet forward per step (default: on a GPU); the timestep lives
+    in a device tensor, so all steps replay the same graph."""
+    from . import models
     B = cond_emb.shape[0]
     dev = cond_emb.device
     H, W = guide.shape[2] // 8, guide.shape[3] // 8
@@ -26,13 +33,35 @@ def ddim_sample(unet, control_lora, guide, cond_emb, uncond_emb, steps=50, guida
     latents = latents.float()
     if control_lora is not None:
         control_lora(guide)
-    ehs = torch.cat([uncond_emb, cond_emb], 0)
-    for t in sched.timesteps:
-        eps = unet(torch.cat([latents, latents], 0).half(), t, ehs).sample
-        eps_u, eps_c = eps.float().chunk(2)
-        eps = eps_u + guidance_scale * (eps_c - eps_u)
-        latents = sched.step(eps, t, latents)
-    return latents
+    ehs = torch.cat([uncond_emb, cond_emb], 0).half().contiguous()
+    if graph is None:
+        graph = dev.type == "cuda"
+    with models.text_kv_cache(enabled=cache_text_kv):
+        if not graph:
+            for t in sched.timesteps:
+                eps = unet(torch.cat([latents, latents], 0).half(), t, ehs).sample
+                eps_u, eps_c = eps.float().chunk(2)
+                latents = sched.step(eps_u + guidance_scale * (eps_c - eps_u), t, latents)
+            return latents
+        x_in = torch.empty((2 * B, 4, H, W), device=dev, dtype=torch.float16)
+        t_in = torch.zeros(1, device=dev, dtype=torch.long)
+        x_in.copy_(torch.cat([latents, latents], 0))
+        t_in.fill_(int(sched.timesteps[0]))
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                # warm-up outside the capture: lazy weight packs, K/V cache, allocator
+            unet(x_in, t_in, ehs)
+        torch.cuda.current_stream().wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            eps_out = unet(x_in, t_in, ehs).sample
+        for t in sched.timesteps:
+            x_in.copy_(torch.cat([latents, latents], 0))
+            t_in.fill_(int(t))
+            g.replay()
+            eps_u, eps_c = eps_out.float().chunk(2)
+            latents = sched.step(eps_u + guidance_scale * (eps_c - eps_u), t, latents)
+        return latents
 
 
 class ControlLoRAPipeline:

@@ -208,10 +208,17 @@ class CrossAttention(nn.Module):
         return self.to_out[0](a, res2).reshape(B, N, C_)
 
 
+class _GegluLinear(Linear):
+    """`proj` of upstream GEGLU: same parameters / state-dict keys as a Linear, packed for the fused activation epilogue"""
+
+    def _build(self):
+        return ops.GegluPack(self.weight, self.bias)
+
+
 class GEGLU(nn.Module):
     def __init__(self, dim_in, dim_out):
         super().__init__()
-        self.proj = Linear(dim_in, dim_out * 2)
+        self.proj = _GegluLinear(dim_in, dim_out * 2)
 
 
 class FeedForward(nn.Module):
@@ -220,7 +227,7 @@ class FeedForward(nn.Module):
         self.net = nn.ModuleList([GEGLU(dim, dim * mult), nn.Dropout(0.0), Linear(dim * mult, dim)])
 
     def forward(self, x, residual):
-        return self.net[2](ops.geglu(self.net[0].proj(x)), residual)
+        return ops.feed_forward(x, self.net[0].proj.pack(), self.net[2].pack(), residual)
 
 
 class BasicTransformerBlock(nn.Module):

@@ -62,6 +62,17 @@ typedef struct {
     int lora_r;
     int lora_seg;
     float lora_scale;
+    /* GEGLU fused into the feed-forward GEMMs (upstream FeedForward / GEGLU, SURVEY.md U5: proj -> a * gelu_erf(g) -> out):
+     * geglu = 1 (forward, the `proj` GEMM, N = 2F): B's rows (and bias) are packed in groups of 128 = [64 a-columns |
+     *   the 64 matching g-columns]; the epilogue writes y[m, j] = fp16(a) * gelu(fp16(g)) to geglu_y [M, F] and, when C is
+     *   not NULL, fp16(a) / fp16(g) to C[m, j] / C[m, F + j] in the standard layout (what the backward needs).
+     * geglu = 2 (backward, the dgrad GEMM of `out`, N = F): the GEMM result is dy; with a, g read from geglu_h [M, 2F]
+     *   the epilogue writes C[m, j] = dy * gelu(g) and C[m, F + j] = dy * a * gelu'(g)  (C is [M, 2F]).
+     * Both need split_k = 1, tiles at least 128 columns wide and no rowadd / residual / adapter terms. */
+    int geglu;
+    int geglu_f;                 /* F */
+    const clora_half* geglu_h;   /* mode 2 */
+    clora_half* geglu_y;         /* mode 1 */
 } clora_epilogue_t;
 
 /* C[M,N] = A[M,K] . B[N,K]^T  (fp16 in, fp32 accumulate on MFMA, fp16 out).

@@ -302,3 +302,48 @@ def case_loss_and_optimizer(dev, n=5000, seed=9):
             assert float(state[6]) == 1.0 and float(state[3]) == 512.0
         assert rel(p, pt.detach()) < 1e-6, (step, rel(p, pt.detach()))
     assert float(state[2]) == 2.0
+
+
+def case_feed_forward_fused(dev, M=200, C=64, seed=12, tile_cfg=0):
+    """FeedForward(GEGLU) with the activation fused into the GEMM epilogues (ops.feed_forward: GegluPack + geglu = 1 / 2)
+    against (i) the unfused kernels -- bit-identical, same rounding points -- and (ii) an fp32 torch reference
+    (upstream FeedForward: Linear(C, 8C) -> a * gelu_erf(g) -> Linear(4C, C), + residual), forward and d(input)."""
+    from controllora_amd import ops
+    g = torch.Generator().manual_seed(seed)
+    Fd = 4 * C
+    x = rnd((M, C), dev, g)
+    w1, b1 = rnd((2 * Fd, C), dev, g, C ** -0.5), rnd((2 * Fd,), dev, g, 0.1)
+    w2, b2 = rnd((C, Fd), dev, g, Fd ** -0.5), rnd((C,), dev, g, 0.1)
+    res = rnd((M, C), dev, g)
+    dout = rnd((M, C), dev, g)
+    p1, p2 = ops.GegluPack(w1, b1), ops.LinearPack(w2, b2)
+    xf = x.clone().requires_grad_(True)
+    old_tuned = K._TUNING
+    if tile_cfg:
+        K._TUNING = {K.tuning_key(M, 2 * Fd, C, None): [tile_cfg, 1], K.tuning_key(M, Fd, C, None): [tile_cfg, 1]}
+    try:
+        out = ops.feed_forward(xf, p1, p2, res)
+        out.backward(dout)
+    finally:
+        K._TUNING = old_tuned
+    # (i) unfused kernels
+    lp1 = ops.LinearPack(w1, b1)
+    xu = x.clone().requires_grad_(True)
+    out_u = ops.frozen_linear(ops.geglu(ops.frozen_linear(xu, lp1)), p2, res)
+    out_u.backward(dout)
+    assert torch.equal(out, out_u), float((out.float() - out_u.float()).abs().max())
+    assert torch.equal(xf.grad, xu.grad), float((xf.grad.float() - xu.grad.float()).abs().max())
+    # (ii) fp32 reference
+    x32 = x.float().cpu().requires_grad_(True)
+    h = F.linear(x32, w1.float().cpu(), b1.float().cpu())
+    a, gg = h.chunk(2, -1)
+    ref = F.linear(a * F.gelu(gg), w2.float().cpu(), b2.float().cpu()) + res.float().cpu()
+    ref.backward(dout.float().cpu())
+    assert rel(out, ref.detach()) < 2e-3, rel(out, ref.detach())
+    assert rel(xf.grad, x32.grad) < 3e-3, rel(xf.grad, x32.grad)
+    # inference: no h is written
+    with torch.no_grad():
+        y_inf, h_inf = K.gemm(x, p1.w, M, p1.N, p1.K, bias=p1.bias, geglu=1, geglu_keep_h=False)
+        assert h_inf is None
+        out_inf = ops.feed_forward(x, p1, p2, res)
+    assert torch.equal(out_inf, out.detach())

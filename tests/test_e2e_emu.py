@@ -41,3 +41,24 @@ def test_vae_encode_decode_matches_oracle():
 @pytest.mark.parametrize("case", ["v1", "v2"])
 def test_inference_with_control_batch_broadcast(case):
     print(case, E.check_inference_broadcast(case, "cpu"))
+
+
+def test_ddim_text_kv_cache_is_exact():
+    """the per-loop cache of the cross-attention K/V projections (pipeline.ddim_sample) changes nothing but the work"""
+    from controllora_amd import models as M
+    from controllora_amd.pipeline import ddim_sample
+    from oracle import cases
+    unet, _, clora = E.build_product_case("v1", "cpu")
+    inp = cases.seeded_inputs()
+    args = (unet, clora, inp["guide"][:1].half(), inp["ehs"][:1].half(), inp["ehs"][1:2].half())
+    a = ddim_sample(*args, steps=3, guidance_scale=5.0, latents=inp["latents"][:1].half(), cache_text_kv=False)
+    calls = []
+    orig = M.ops.lora_proj
+    M.ops.lora_proj = lambda x, pack, segs, residual=None: (calls.append(x.shape[0]), orig(x, pack, segs, residual))[1]
+    try:
+        b = ddim_sample(*args, steps=3, guidance_scale=5.0, latents=inp["latents"][:1].half(), cache_text_kv=True)
+    finally:
+        M.ops.lora_proj = orig
+    assert torch.equal(a, b)
+    kv_rows = 2 * cases.CTX_LEN                         # CFG batch 2 x text length: the K/V projections' row count
+    assert sum(1 for m in calls if m == kv_rows) == 16  # 16 cross-attention sites, projected once for all 3 steps

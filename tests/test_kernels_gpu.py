@@ -41,7 +41,7 @@ def test_conv_small_channels():
     KC.case_conv(DEV, 1, 64, 64, 8, 32)
 
 
-ALL_TILE_CFGS = [1, 2, 3, 4, 5, 6, 7, 8, 21, 22, 23, 24, 25, 26, 31, 32, 33, 41, 42, 43, 51, 52, 53, 57, 61, 62, 63, 67]
+ALL_TILE_CFGS = [1, 2, 3, 4, 5, 6, 7, 8, 9, 21, 22, 23, 26, 31, 32, 33, 41, 42, 43]
 
 
 @pytest.mark.parametrize("tile", ALL_TILE_CFGS)
@@ -108,3 +108,9 @@ def test_conv_fast_path_variants(kw):
     wave-uniform fast path is reserved for stride-1: a tabulated-offset generalisation measured no faster than generic)"""
     KC.case_conv(DEV, 2, 16, 16, 64, 96, **kw)
     KC.case_conv(DEV, 1, 32, 32, 320, 320, **kw)
+
+
+@pytest.mark.parametrize("tile", [0, 1, 7, 8, 21, 31, 41])
+def test_feed_forward_fused_geglu(tile):
+    KC.case_feed_forward_fused(DEV, M=1000, C=320, tile_cfg=tile)
+    KC.case_feed_forward_fused(DEV, M=300, C=1280, tile_cfg=tile)

@@ -8,7 +8,7 @@ GROUPS = [list(range(0, 4)) + list(range(12, 16)) + list(range(20, 28)),
           list(range(36, 44)) + list(range(48, 52)) + list(range(60, 64))]
 
 
-ALT = False       # BK = 32: key(r) = (r >> 2) & 3 (round 1)  vs  (-(r >> 2)) & 3 (FLAGS bit 1 of gemm_dma_kernel)
+ALT = False       # BK = 32: key(r) = (r >> 2) & 3 (round 1, FLAGS bit 1 of gemm_dma_kernel)  vs  (-(r >> 2)) & 3 (default)
 
 
 def addr(l, bk, ks, base_row=0):

@@ -14,10 +14,12 @@ from controllora_amd.train import ControlLoRATrainer
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=4)
 ap.add_argument("--res", type=int, default=512)
-ap.add_argument("--infer-batch", type=int, default=32)
+ap.add_argument("--infer-batch", type=int, default=32, help="0 = skip the inference forward")
+ap.add_argument("--config", default="fill50k.json")
+ap.add_argument("--merge", action="store_true", help="keep the entries already in the table and add / refresh the measured ones")
 args = ap.parse_args()
 dev = torch.device("cuda", 0)
-unet, clora = bench.build_models(dev)
+unet, clora = bench.build_models(dev, config=args.config)
 trainer = ControlLoRATrainer(unet, clora)
 batch = bench.synthetic_batch(args.batch, args.res, dev, 42)
 noisy = DDPMScheduler().add_noise(batch["latents"], batch["noise"], batch["timesteps"]).half()
@@ -25,19 +27,23 @@ noisy = DDPMScheduler().add_noise(batch["latents"], batch["noise"], batch["times
 # 1) record every distinct GEMM signature of a train step (+ the inference forward at the DDIM batch)
 seen = {}
 orig = K.gemm
+wide_only = set()           # signatures used with the GEGLU-forward epilogue: tiles must be >= 128 columns wide
 def rec(A, Bw, M, N, Kd, **kw):
     conv = kw.get("conv")
     ck = tuple(getattr(conv, f) for f, _ in ConvDesc._fields_) if conv is not None else None
     seen.setdefault((M, N, Kd, ck), 0)
     seen[(M, N, Kd, ck)] += 1
+    if kw.get("geglu") == 1:
+        wide_only.add((M, N, Kd, ck))
     return orig(A, Bw, M, N, Kd, **kw)
 K.gemm = rec
 import controllora_amd.ops as ops
 trainer.step(noisy, batch["timesteps"], batch["ehs"], batch["guide"], batch["noise"])
-with torch.no_grad():
-    nb = args.infer_batch
-    clora(batch["guide"][:1])
-    unet(torch.randn(nb, 4, args.res // 8, args.res // 8, device=dev).half(), 10, torch.randn(nb, 77, 768, device=dev).half())
+if args.infer_batch > 0:
+    with torch.no_grad():
+        nb = args.infer_batch
+        clora(batch["guide"][:1])
+        unet(torch.randn(nb, 4, args.res // 8, args.res // 8, device=dev).half(), 10, torch.randn(nb, 77, 768, device=dev).half())
 K.gemm = orig
 torch.cuda.synchronize()
 print(f"{len(seen)} distinct GEMM signatures", flush=True)
@@ -59,7 +65,10 @@ def timeit(fn, iters=10, warm=2):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / (2 * iters) * 1e3
 
-table = {}
+CFGS = [1, 2, 3, 4, 5, 6, 7, 8, 21, 22, 23, 26, 31, 32, 33, 41, 42, 43]
+path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "controllora_amd", "gemm_tuning_gfx950.json")
+table = json.load(open(path))["table"] if (args.merge and os.path.exists(path)) else {}
+tot_auto = tot_best = tot_r01 = 0.0
 for (M, N, Kd, ck), cnt in sorted(seen.items(), key=lambda kv: -kv[0][0] * kv[0][1] * kv[0][2]):
     if ck is None:
         A = torch.randn(M, Kd, device=dev).half(); conv = None
@@ -70,27 +79,42 @@ for (M, N, Kd, ck), cnt in sorted(seen.items(), key=lambda kv: -kv[0][0] * kv[0]
     out = torch.empty(M, N, device=dev, dtype=torch.float16)
     res_ = torch.randn(M, N, device=dev).half()
     best, err = None, None
-    auto = timeit(lambda: K.gemm(A, Bw, M, N, Kd, conv=conv, out=out, residual=res_, split_k=0, tile_cfg=0, _tuned=False))
-    for tile in (1, 2, 3, 4, 5, 6):
+    run = lambda sk, tile: K.gemm(A, Bw, M, N, Kd, conv=conv, out=out, residual=res_, split_k=sk, tile_cfg=tile, _tuned=False)
+    auto = timeit(lambda: run(0, 0))
+    iters = 10 if auto < 300 else 4
+    r01 = None
+    geglu_sig = (M, N, Kd, ck) in wide_only
+    for tile in CFGS:
+        if geglu_sig and tile not in K.WIDE_TILE_CFGS:
+            continue
+        prev = None
         for sk in (1, 2, 3, 4, 6, 8, 12, 16):
-            if sk > 1 and (Kd // 32) // sk < 4:
-                continue
-            if sk > 1 and sk * M * N * 4 > K.GEMM_WS_BYTES:
-                continue
+            if sk > 1 and (geglu_sig or (Kd // 32) // sk < 4 or sk * M * N * 4 > K.GEMM_WS_BYTES or M * N > 16384 * 1280):
+                break
             try:
-                us = timeit(lambda: K.gemm(A, Bw, M, N, Kd, conv=conv, out=out, residual=res_, split_k=sk, tile_cfg=tile, _tuned=False))
+                us = timeit(lambda: run(sk, tile), iters=iters)
             except Exception as ex:
                 err = ex
-                continue
+                break
             if best is None or us < best[0]:
                 best = (us, tile, sk)
+            if tile <= 6 and (r01 is None or us < r01):
+                r01 = us
+            if prev is not None and us > prev * 1.03:      # split-K stopped paying for this tile
+                break
+            prev = us
     key = K.tuning_key(M, N, Kd, conv)
     if best is None:
         print(f"{key}: no configuration ran ({err!r})", flush=True)
         continue
     table[key] = [best[1], best[2]]
-    print(f"{key:48s} x{cnt:3d} auto {auto:8.1f}us best tile={best[1]} sk={best[2]:2d} {best[0]:8.1f}us  ({auto / best[0]:.2f}x)", flush=True)
-path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "controllora_amd", "gemm_tuning_gfx950.json")
-json.dump(dict(device=torch.cuda.get_device_name(0), note="tile: 1=128x128 2=128x64 3=64x64, 4-6 = same tiles with the deep LDS ring; value = [tile, split_k]", table=table),
+    tot_auto += cnt * auto; tot_best += cnt * best[0]; tot_r01 += cnt * (r01 or best[0])
+    print(f"{key:48s} x{cnt:3d} auto {auto:8.1f}us r01-tiles {r01 or 0:8.1f}us best tile={best[1]:2d} sk={best[2]:2d} {best[0]:8.1f}us  "
+          f"({(r01 or best[0]) / best[0]:.2f}x) {2.0 * M * N * Kd / best[0] / 1e6:7.1f}TF", flush=True)
+    del A, Bw, out, res_
+print(f"sum over the recorded launches: latency model {tot_auto / 1e3:.2f} ms, round-1 tile set {tot_r01 / 1e3:.2f} ms, full set {tot_best / 1e3:.2f} ms")
+json.dump(dict(device=torch.cuda.get_device_name(0),
+               note="value = [tile_cfg, split_k]; tile_cfg as documented at clora_gemm_f16_ex (1-3 BK32 ring, 4-6 deep ring, 7/8 256x128, "
+                    "21/22/23/26 BK64 whole-line rows, 3x/4x fragment reads before the ring refill)", table=table),
           open(path, "w"), indent=0)
-print("wrote", path)
+print("wrote", path, len(table), "entries")
