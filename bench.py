@@ -221,6 +221,7 @@ def main():
                     "rendezvous, flat all-reduce, rank-0 line) without touching a GPU")
     ap.add_argument("--trace-child", action="store_true", help=argparse.SUPPRESS)    # run by rocprof_child_trace()
     ap.add_argument("--no-rocprof", action="store_true", help="skip the rocprofv3 child run (roofline falls back to HIP events)")
+    ap.add_argument("--trace-out", default=None, help="write the child run's full per-kernel table (json) here, e.g. profiles/r02_kernel_stats.json")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -330,6 +331,11 @@ def main():
             fam_ms = sum(r_["total_ms"] for r_ in rows) / n_st
             fam_launches = round(sum(r_["calls"] for r_ in rows) / n_st)
             src = f"rocprofv3 --kernel-trace child run ({n_st} steps, hipGraph replay), kernels matching {GEMM_FAMILY}"
+            if args.trace_out:
+                json.dump({"command": "rocprofv3 --kernel-trace -- python bench.py --trace-child ...", "steps_in_trace": n_st,
+                           "total_kernel_ms_per_step": trace["total_kernel_ms_per_step"], "launches_per_step": trace["launches_per_step"],
+                           "kernels": [dict(r_, ms_per_step=round(r_["total_ms"] / n_st, 4), calls_per_step=round(r_["calls"] / n_st, 2))
+                                       for r_ in trace["kernels"]]}, open(args.trace_out, "w"), indent=1)
             kt = {"total_kernel_ms_per_step": round(trace["total_kernel_ms_per_step"], 3),
                   "launches_per_step": trace["launches_per_step"],
                   "top": [{"kernel": r_["kernel"][:60], "calls_per_step": round(r_["calls"] / n_st, 1),

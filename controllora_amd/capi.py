@@ -28,7 +28,7 @@ class ConvDesc(C.Structure):
     """mirror of clora_conv_t"""
     _fields_ = [(n, C.c_int) for n in (
         "enabled", "Hin", "Win", "Cin", "Hout", "Wout", "ksize", "mul", "kmul", "off", "lim_h", "lim_w", "shift",
-        "need_even")]
+        "need_even", "kchunk")]
 
 
 class Epilogue(C.Structure):

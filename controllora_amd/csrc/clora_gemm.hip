@@ -153,8 +153,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
         b_base[i] = (size_t)n * p.K;
     }
     int k = kbeg + kc * 8;  // this thread's k for the tile being loaded
-    int tap = 0, ci = k;
-    if (conv) { tap = k / p.conv.Cin; ci = k - tap * p.conv.Cin; }
+    // K order (clora_conv_t.kchunk): slabs of kcs channels, the taps of a slab back to back (kcs = Cin: plain tap-major)
+    const int kcs = p.conv.kchunk > 0 ? p.conv.kchunk : p.conv.Cin, ntap = p.conv.ksize * p.conv.ksize;
+    int tap = 0, ci = k, cb = 0;       // tap, channel inside the slab, first channel of the slab
+    if (conv) { cb = (k / (ntap * kcs)) * kcs; const int r = k % (ntap * kcs); tap = r / kcs; ci = r - tap * kcs; }
 
     half8 ra[A_CH], rb[B_CH];
     auto load_tile = [&]() {
@@ -172,7 +174,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
                     bool ok = ty >= 0 && ty < p.conv.lim_h && tx >= 0 && tx < p.conv.lim_w;
                     if (p.conv.need_even) ok = ok && (((ty | tx) & 1) == 0);
                     if (ok)
-                        v = ld8(p.A + (a_base[i] + (size_t)(ty >> p.conv.shift) * p.conv.Win + (tx >> p.conv.shift)) * p.conv.Cin + ci);
+                        v = ld8(p.A + (a_base[i] + (size_t)(ty >> p.conv.shift) * p.conv.Win + (tx >> p.conv.shift)) * p.conv.Cin + cb + ci);
                 }
             }
             ra[i] = v;
@@ -186,7 +188,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
         k += BK;
         if (conv) {
             ci += BK;
-            while (ci >= p.conv.Cin) { ci -= p.conv.Cin; ++tap; }
+            while (ci >= kcs) { ci -= kcs; if (++tap == ntap) { tap = 0; cb += kcs; } }
         }
     };
     auto store_tile = [&](int buf) {
@@ -397,11 +399,13 @@ __global__ __launch_bounds__(256, (DmaOcc<BM, BN, NST, BK>::v)) void gemm_dma_ke
         b_base[i] = (size_t)n * p.K;
     }
     int k = kbeg + kc * 8;
-    int tap = 0, ci = k;
-    if (conv) { tap = k / p.conv.Cin; ci = k - tap * p.conv.Cin; }
-    // CONV == 2: wave-uniform walk (kq = first k of the stage, its tap and channel offset), kept in SGPRs
-    int kq = kbeg, qtap = 0, qci = 0;
-    if (CONV == 2) { qtap = kbeg / p.conv.Cin; qci = kbeg - qtap * p.conv.Cin; }
+    // K order (clora_conv_t.kchunk): slabs of kcs channels, the 9 taps of a slab back to back (kcs = Cin: plain tap-major)
+    const int kcs = p.conv.kchunk > 0 ? p.conv.kchunk : p.conv.Cin, ntap = p.conv.ksize * p.conv.ksize;
+    int tap = 0, ci = k, cb = 0;       // generic gather: tap, channel inside the slab, first channel of the slab (per lane)
+    if (conv) { cb = (k / (ntap * kcs)) * kcs; const int r = k % (ntap * kcs); tap = r / kcs; ci = r - tap * kcs; }
+    // CONV == 2: wave-uniform walk (kq = first k of the stage, its tap, slab and offset inside the slab), kept in SGPRs
+    int kq = kbeg, qtap = 0, qci = 0, qcb = 0;
+    if (CONV == 2) { qcb = (kbeg / (9 * kcs)) * kcs; const int r = kbeg % (9 * kcs); qtap = r / kcs; qci = r - qtap * kcs; }
 
     auto issue_stage = [&](int buf) {
         half_t* As = smem + buf * STAGE;
@@ -409,7 +413,7 @@ __global__ __launch_bounds__(256, (DmaOcc<BM, BN, NST, BK>::v)) void gemm_dma_ke
         if (CONV == 2) {
             const bool kokq = kq < kend;                    // K = 9*Cin and the split size are multiples of BK: whole stages only
             const int qky = qtap / 3, qkx = qtap - qky * 3;
-            const long delta = ((long)(p.conv.off + qky * p.conv.kmul) * p.conv.Win + (p.conv.off + qkx * p.conv.kmul)) * p.conv.Cin + qci;
+            const long delta = ((long)(p.conv.off + qky * p.conv.kmul) * p.conv.Win + (p.conv.off + qkx * p.conv.kmul)) * p.conv.Cin + qcb + qci;
 #pragma unroll
             for (int i = 0; i < A_IN; ++i) {
                 const bool ok = kokq && ((a_mask[i] >> qtap) & 1u);
@@ -423,7 +427,7 @@ __global__ __launch_bounds__(256, (DmaOcc<BM, BN, NST, BK>::v)) void gemm_dma_ke
             }
             kq += BK;
             qci += BK;
-            if (qci >= p.conv.Cin) { qci = 0; ++qtap; }
+            if (qci >= kcs) { qci = 0; if (++qtap == 9) { qtap = 0; qcb += kcs; } }
             return;
         }
         const bool kok = k < kend;
@@ -440,7 +444,7 @@ __global__ __launch_bounds__(256, (DmaOcc<BM, BN, NST, BK>::v)) void gemm_dma_ke
                     bool ok = ty >= 0 && ty < p.conv.lim_h && tx >= 0 && tx < p.conv.lim_w;
                     if (p.conv.need_even) ok = ok && (((ty | tx) & 1) == 0);
                     if (ok)
-                        src = p.A + (a_base[i] + (size_t)(ty >> p.conv.shift) * p.conv.Win + (tx >> p.conv.shift)) * p.conv.Cin + ci;
+                        src = p.A + (a_base[i] + (size_t)(ty >> p.conv.shift) * p.conv.Win + (tx >> p.conv.shift)) * p.conv.Cin + cb + ci;
                 }
             }
             CLORA_GLDS16(src, As + (w * A_IN + i) * RPI * BK);
@@ -453,7 +457,7 @@ __global__ __launch_bounds__(256, (DmaOcc<BM, BN, NST, BK>::v)) void gemm_dma_ke
         k += BK;
         if (conv) {
             ci += BK;
-            while (ci >= p.conv.Cin) { ci -= p.conv.Cin; ++tap; }
+            while (ci >= kcs) { ci -= kcs; if (++tap == ntap) { tap = 0; cb += kcs; } }
         }
     };
 
@@ -828,8 +832,9 @@ __global__ __launch_bounds__(256) void conv_weight_pack_kernel(const float* w, i
 int conv_mode(const GemmArgs& a, int bk) {
     const clora_conv_t& c = a.conv;
     if (!c.enabled) return 0;
+    const int kcs = c.kchunk > 0 ? c.kchunk : c.Cin;
     const bool fast = c.ksize == 3 && c.shift == 0 && c.need_even == 0 && (c.kmul == 1 || c.kmul == -1) &&
-                      (c.Cin % bk) == 0 && (a.k_per_split % bk) == 0 && c.lim_h == c.Hin && c.lim_w == c.Win;
+                      (kcs % bk) == 0 && (a.k_per_split % bk) == 0 && c.lim_h == c.Hin && c.lim_w == c.Win;
     return fast ? 2 : 1;
 }
 
@@ -893,6 +898,7 @@ extern "C" int clora_gemm_f16_ex(const clora_half* A, int lda, const clora_half*
     if (conv && conv->enabled) {
         a.conv = *conv;
         if ((conv->Cin & 7) || K != conv->ksize * conv->ksize * conv->Cin) return CLORA_ERR_ARG;
+        if (conv->kchunk < 0 || (conv->kchunk > 0 && ((conv->kchunk & 7) || conv->Cin % conv->kchunk))) return CLORA_ERR_ARG;
     } else {
         a.conv = clora_conv_t();
         a.conv.enabled = 0;
@@ -1035,7 +1041,7 @@ extern "C" int clora_conv_wgrad_f16(const clora_half* dY, int ldy, const clora_h
     a.ldy = ldy; a.ldx = ldx; a.M = M; a.N = N; a.K = K; a.oihw_ci = oihw_ci;
     if (conv && conv->enabled) {
         a.conv = *conv;
-        if ((conv->Cin & 7) || K != conv->ksize * conv->ksize * conv->Cin) return CLORA_ERR_ARG;
+        if ((conv->Cin & 7) || K != conv->ksize * conv->ksize * conv->Cin || conv->kchunk != 0) return CLORA_ERR_ARG;
     } else {
         a.conv = clora_conv_t();
         a.conv.enabled = 0;

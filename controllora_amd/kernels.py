@@ -58,26 +58,27 @@ def _c2(t: torch.Tensor) -> torch.Tensor:
 
 
 # ------------------------------------------------------------------ conv descriptors (see include/clora.h)
-def conv_fwd_desc(Hin, Win, Cin, ksize=3, stride=1, pad=1, upsample=False, asym_pad=False) -> Tuple[ConvDesc, int, int]:
-    """Forward gather.  asym_pad = diffusers Downsample2D(padding=0): F.pad (0,1,0,1) then stride 2 (A9)."""
+def conv_fwd_desc(Hin, Win, Cin, ksize=3, stride=1, pad=1, upsample=False, asym_pad=False, kchunk=0) -> Tuple[ConvDesc, int, int]:
+    """Forward gather.  asym_pad = diffusers Downsample2D(padding=0): F.pad (0,1,0,1) then stride 2 (A9).
+    kchunk: K order of the weight operand (include/clora.h clora_conv_t.kchunk; ops.conv_k_order)."""
     if upsample:
         Hout, Wout = 2 * Hin, 2 * Win
-        return ConvDesc(1, Hin, Win, Cin, Hout, Wout, ksize, 1, 1, -pad, 2 * Hin, 2 * Win, 1, 0), Hout, Wout
+        return ConvDesc(1, Hin, Win, Cin, Hout, Wout, ksize, 1, 1, -pad, 2 * Hin, 2 * Win, 1, 0, kchunk), Hout, Wout
     if asym_pad:
         Hout, Wout = (Hin + 1 - ksize) // stride + 1, (Win + 1 - ksize) // stride + 1
-        return ConvDesc(1, Hin, Win, Cin, Hout, Wout, ksize, stride, 1, 0, Hin, Win, 0, 0), Hout, Wout
+        return ConvDesc(1, Hin, Win, Cin, Hout, Wout, ksize, stride, 1, 0, Hin, Win, 0, 0, kchunk), Hout, Wout
     Hout, Wout = (Hin + 2 * pad - ksize) // stride + 1, (Win + 2 * pad - ksize) // stride + 1
-    return ConvDesc(1, Hin, Win, Cin, Hout, Wout, ksize, stride, 1, -pad, Hin, Win, 0, 0), Hout, Wout
+    return ConvDesc(1, Hin, Win, Cin, Hout, Wout, ksize, stride, 1, -pad, Hin, Win, 0, 0, kchunk), Hout, Wout
 
 
-def conv_dgrad_desc(Hout, Wout, Cout, Hin, Win, ksize=3, stride=1, pad=1, asym_pad=False) -> ConvDesc:
+def conv_dgrad_desc(Hout, Wout, Cout, Hin, Win, ksize=3, stride=1, pad=1, asym_pad=False, kchunk=0) -> ConvDesc:
     """Gather for dX (rows enumerate the INPUT pixels of the forward conv, A operand is dY).  For an
     upsampled forward pass (Hin, Win) are the upsampled dims and the result is 2x2 sum-pooled afterwards."""
     p = 0 if asym_pad else pad
     if stride == 1:
-        return ConvDesc(1, Hout, Wout, Cout, Hin, Win, ksize, 1, -1, p, Hout, Wout, 0, 0)
+        return ConvDesc(1, Hout, Wout, Cout, Hin, Win, ksize, 1, -1, p, Hout, Wout, 0, 0, kchunk)
     assert stride == 2
-    return ConvDesc(1, Hout, Wout, Cout, Hin, Win, ksize, 1, -1, p, 2 * Hout, 2 * Wout, 1, 1)
+    return ConvDesc(1, Hout, Wout, Cout, Hin, Win, ksize, 1, -1, p, 2 * Hout, 2 * Wout, 1, 1, kchunk)
 
 
 _ws_cache = {}

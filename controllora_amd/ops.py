@@ -58,9 +58,23 @@ class GegluPack:
         self.bias = bias.detach().to(f32)[src].contiguous() if bias is not None else None
 
 
+KCHUNK = 64      # channel-chunk-major K order of the frozen 3x3 convs (clora_conv_t.kchunk) when the channel count allows
+
+
+def conv_k_order(w_taps_ci: torch.Tensor, kchunk: int) -> torch.Tensor:
+    """[rows, 9, C] (tap-major) -> [rows, 9*C] in the K order the gather walks: tap-major for kchunk == 0, else
+    ((ci / kchunk) * 9 + tap) * kchunk + ci % kchunk."""
+    rows, taps, Cc = w_taps_ci.shape
+    if kchunk == 0:
+        return w_taps_ci.reshape(rows, taps * Cc).contiguous()
+    return w_taps_ci.reshape(rows, taps, Cc // kchunk, kchunk).permute(0, 2, 1, 3).reshape(rows, taps * Cc).contiguous()
+
+
 class ConvPack:
     """Frozen 3x3 conv: forward operand [Co, 9*Ci] in (ky,kx,ci) order, dgrad operand [Ci, 9*Co] in
-    (ky,kx,co) order (the gather descriptor walks the taps with kmul = -1, so no flip is needed)."""
+    (ky,kx,co) order (the gather descriptor walks the taps with kmul = -1, so no flip is needed); with the channel
+    count a multiple of 64 both are stored channel-chunk-major instead (conv_k_order): the 9 shifted re-reads of an input
+    slab then sit next to each other in the k loop."""
 
     def __init__(self, weight: torch.Tensor, bias: Optional[torch.Tensor], stride=1, pad=1, upsample=False,
                  asym_pad=False, need_dgrad=True):
@@ -71,12 +85,14 @@ class ConvPack:
         wp = w.new_zeros(Cop, 3, 3, Cip)
         wp[:Co, :, :, :Ci] = w.permute(0, 2, 3, 1)
         self.Ci, self.Co, self.Cip, self.Cop = Ci, Co, Cip, Cop
-        self.w = wp.reshape(Cop, 9 * Cip).contiguous()
+        self.kchunk = KCHUNK if Cip % KCHUNK == 0 else 0
+        self.kchunk_d = KCHUNK if Cop % KCHUNK == 0 else 0
+        self.w = conv_k_order(wp.reshape(Cop, 9, Cip), self.kchunk)
         self.wd = None
         if need_dgrad:
             wd = w.new_zeros(Cip, 3, 3, Cop)
             wd[:Ci, :, :, :Co] = w.permute(1, 2, 3, 0)
-            self.wd = wd.reshape(Cip, 9 * Cop).contiguous()
+            self.wd = conv_k_order(wd.reshape(Cip, 9, Cop), self.kchunk_d)
         self.bias = None
         if bias is not None:
             b = bias.detach().to(f32)
@@ -110,7 +126,7 @@ def frozen_linear(x, pack: LinearPack, residual=None, rowadd=None, rows_per_batc
 class _FrozenConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, pack: ConvPack, B, H, W, residual, rowadd):
-        cd, Ho, Wo = K.conv_fwd_desc(H, W, pack.Cip, 3, pack.stride, pack.pad, pack.upsample, pack.asym_pad)
+        cd, Ho, Wo = K.conv_fwd_desc(H, W, pack.Cip, 3, pack.stride, pack.pad, pack.upsample, pack.asym_pad, pack.kchunk)
         M = B * Ho * Wo
         y = K.gemm(x, pack.w, M, pack.Cop, 9 * pack.Cip, conv=cd, bias=pack.bias, residual=residual, rowadd=rowadd,
                    rows_per_batch=Ho * Wo)
@@ -125,7 +141,7 @@ class _FrozenConvFn(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             Hi, Wi = (2 * H, 2 * W) if p.upsample else (H, W)
-            cdd = K.conv_dgrad_desc(Ho, Wo, p.Cop, Hi, Wi, 3, p.stride, p.pad, p.asym_pad)
+            cdd = K.conv_dgrad_desc(Ho, Wo, p.Cop, Hi, Wi, 3, p.stride, p.pad, p.asym_pad, p.kchunk_d)
             dx = K.gemm(dy, p.wd, B * Hi * Wi, p.Cip, 9 * p.Cop, conv=cdd)
             if p.upsample:
                 dx = K.pool2x2_sum(dx, B, H, W, p.Cip).reshape(B * H * W, p.Cip)

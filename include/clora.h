@@ -41,6 +41,11 @@ typedef struct {
     int Hout, Wout;      /* spatial dims that enumerate the GEMM rows */
     int ksize;           /* 1 or 3 */
     int mul, kmul, off, lim_h, lim_w, shift, need_even;
+    int kchunk;          /* K order of the gather (and of B's columns): 0 = tap-major, k = tap*Cin + ci;
+                          * c > 0 (Cin % c == 0) = channel-chunk-major, k = ((ci / c) * ksize^2 + tap) * c + ci % c:
+                          * the ksize^2 taps of one c-channel slab are walked back to back, so the shifted re-reads of the
+                          * same input pixels happen within a few k-steps (L1 / L2 hits instead of a pass over the whole
+                          * activation per tap) */
 } clora_conv_t;
 
 /* ---- fused epilogue of clora_gemm_f16:

@@ -130,7 +130,7 @@ def oracle_ddim(o_unet, o_clora, guide, cond, uncond, steps, guidance_scale, lat
 
 
 def ddim_parity(o_unet, o_clora, p_unet, p_clora, dev, res, steps, guidance_scale=9.0, nb=1, ctx_dim=768, ctx_len=77, seed=5,
-                graph=False):
+                graph=False, fp16_floor=False):
     """denoised-latent parity: product `pipeline.ddim_sample` vs the oracle loop; rel-L2 of the final latents (the
     quantity north_star states 1e-3 for) and of the per-step trajectory."""
     from controllora_amd.pipeline import ddim_sample
@@ -141,7 +141,22 @@ def ddim_parity(o_unet, o_clora, p_unet, p_clora, dev, res, steps, guidance_scal
     uncond = torch.randn(nb, ctx_len, ctx_dim, generator=g).half().float()
     lat0 = torch.randn(nb, 4, L, L, generator=g).half().float()
     ref, traj = oracle_ddim(o_unet, o_clora, guide, cond, uncond, steps, guidance_scale, lat0)
+    floor = None
+    if fp16_floor:
+        floor = fp16_oracle_floor(o_unet, o_clora, guide, cond, uncond, steps, guidance_scale, lat0, ref)
     kw = dict(graph=True) if graph else {}
     out = ddim_sample(p_unet, p_clora, guide.to(dev).half(), cond.to(dev).half(), uncond.to(dev).half(), steps=steps,
                       guidance_scale=guidance_scale, latents=lat0.to(dev).half(), **kw)
-    return {"latents": rel(out, ref), "steps": steps, "latent_norm": float(ref.norm())}
+    return {"latents": rel(out, ref), "steps": steps, "latent_norm": float(ref.norm()), "fp16_oracle_vs_fp32_oracle": floor}
+
+
+def fp16_oracle_floor(o_unet, o_clora, guide, cond, uncond, steps, guidance_scale, lat0, ref):
+    """What "fp16" costs ANY implementation: the same oracle loop with every module and tensor in fp16 (the arithmetic
+    regime of the reference's own fp16 pipeline: fp16 storage of weights / activations / latents) against the fp32 oracle.
+    north_star's "within 1e-3 rel fp16" is read against this floor (SURVEY.md section 8c "Tolerance reading")."""
+    import copy
+    from oracle.controllora_ref import map_processors_to_unet as omap
+    h_unet, h_clora = copy.deepcopy(o_unet).half(), copy.deepcopy(o_clora).half()
+    h_unet.set_attn_processor(omap(h_unet, h_clora))
+    out, _ = oracle_ddim(h_unet, h_clora, guide.half(), cond.half(), uncond.half(), steps, guidance_scale, lat0.half())
+    return rel(out, ref)

@@ -40,9 +40,15 @@ def test_ddim_denoised_latents_small_50_steps():
     from oracle import cases
     o_unet, _, o_clora = cases.build_oracle_case("v1")
     p_unet, _, p_clora = E.build_product_case("v1", "cuda")
-    r = F.ddim_parity(o_unet, o_clora, p_unet, p_clora, "cuda", res=128, steps=50, guidance_scale=9.0, nb=2, ctx_dim=64, ctx_len=7)
+    with torch.no_grad():
+        for p in o_unet.parameters():                      # frozen weights: fp16 values on both sides
+            p.copy_(p.half().float())
+    r = F.ddim_parity(o_unet, o_clora, p_unet, p_clora, "cuda", res=128, steps=50, guidance_scale=9.0, nb=2, ctx_dim=64, ctx_len=7,
+                      fp16_floor=True)
     print("DDIM_LATENT_PARITY small 50 steps", r)
-    assert r["latents"] < 2e-2, r
+    # measured on MI355X: 2.6e-3 vs the fp32 oracle, while the fp16 oracle itself sits 4.7e-3 from the fp32 oracle: the
+    # product must stay below the fp16 floor of the reference's own arithmetic and below 2x its measured value
+    assert r["latents"] < 5.5e-3 and r["latents"] < r["fp16_oracle_vs_fp32_oracle"] * 1.1, r
 
 
 def test_ddim_denoised_latents_full_topology():
@@ -51,7 +57,7 @@ def test_ddim_denoised_latents_full_topology():
     o_unet, o_clora, p_unet, p_clora = F.build_pair("fill50k.json", "cuda")
     r = F.ddim_parity(o_unet, o_clora, p_unet, p_clora, "cuda", res=256, steps=6, guidance_scale=9.0, nb=1)
     print("DDIM_LATENT_PARITY sd15 6 steps", r)
-    assert r["latents"] < 1e-2, r
+    assert r["latents"] < 7.5e-3, r                       # measured 3.8e-3 on MI355X
 
 
 @pytest.mark.parametrize("cross", [False, True])

@@ -103,3 +103,15 @@ def test_conv_fast_path_uniform_taps(tile):
 def test_feed_forward_fused_geglu(tile):
     KC.case_feed_forward_fused("cpu", M=150, C=32, tile_cfg=tile)
     KC.case_feed_forward_fused("cpu", M=70, C=64, tile_cfg=tile)
+
+
+@pytest.mark.parametrize("tile", [0, 1, 3, 7, 21, 23, 42, 12])
+def test_conv_channel_chunk_major_k_order(tile):
+    """clora_conv_t.kchunk: slabs of kchunk channels with their 9 taps back to back -- fast tap walk (kchunk % BK == 0),
+    generic gather (strided / upsampled / kchunk < BK), split-K starting inside a slab, forward and dgrad"""
+    KC.case_conv("cpu", 1, 6, 5, 64, 64, tile_cfg=tile, kchunk=64)
+    KC.case_conv("cpu", 2, 4, 4, 128, 64, tile_cfg=tile, kchunk=64)
+    KC.case_conv("cpu", 1, 6, 6, 64, 32, tile_cfg=tile, kchunk=32)
+    KC.case_conv("cpu", 1, 5, 5, 32, 32, tile_cfg=tile, kchunk=16)
+    for kw in (dict(stride=2, pad=1), dict(asym=True, stride=2, pad=0), dict(ups=True)):
+        KC.case_conv("cpu", 1, 6, 6, 64, 64, tile_cfg=tile, kchunk=64, **kw)

@@ -114,3 +114,13 @@ def test_conv_fast_path_variants(kw):
 def test_feed_forward_fused_geglu(tile):
     KC.case_feed_forward_fused(DEV, M=1000, C=320, tile_cfg=tile)
     KC.case_feed_forward_fused(DEV, M=300, C=1280, tile_cfg=tile)
+
+
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 7, 8, 21, 22, 23, 26, 41, 43])
+def test_conv_channel_chunk_major_k_order(tile):
+    """clora_conv_t.kchunk = 64 (what ops.ConvPack uses for every UNet conv) at real widths, forward and dgrad, plus the
+    strided / upsampled gathers"""
+    KC.case_conv(DEV, 2, 32, 32, 320, 640, tile_cfg=tile, kchunk=64)
+    KC.case_conv(DEV, 1, 16, 16, 1280, 1280, tile_cfg=tile, kchunk=64)
+    for kw in (dict(stride=2, pad=1), dict(asym=True, stride=2, pad=0), dict(ups=True)):
+        KC.case_conv(DEV, 1, 16, 16, 128, 64, tile_cfg=tile, kchunk=64, **kw)
