@@ -58,7 +58,9 @@ class GegluPack:
         self.bias = bias.detach().to(f32)[src].contiguous() if bias is not None else None
 
 
-KCHUNK = 64      # channel-chunk-major K order of the frozen 3x3 convs (clora_conv_t.kchunk) when the channel count allows
+import os as _os
+# channel-chunk-major K order of the frozen 3x3 convs (clora_conv_t.kchunk) when the channel count allows; 0 = tap-major (A/B runs)
+KCHUNK = int(_os.environ.get("CLORA_KCHUNK", "64"))
 
 
 def conv_k_order(w_taps_ci: torch.Tensor, kchunk: int) -> torch.Tensor:
@@ -85,8 +87,8 @@ class ConvPack:
         wp = w.new_zeros(Cop, 3, 3, Cip)
         wp[:Co, :, :, :Ci] = w.permute(0, 2, 3, 1)
         self.Ci, self.Co, self.Cip, self.Cop = Ci, Co, Cip, Cop
-        self.kchunk = KCHUNK if Cip % KCHUNK == 0 else 0
-        self.kchunk_d = KCHUNK if Cop % KCHUNK == 0 else 0
+        self.kchunk = KCHUNK if (KCHUNK and Cip % KCHUNK == 0) else 0
+        self.kchunk_d = KCHUNK if (KCHUNK and Cop % KCHUNK == 0) else 0
         self.w = conv_k_order(wp.reshape(Cop, 9, Cip), self.kchunk)
         self.wd = None
         if need_dgrad:
