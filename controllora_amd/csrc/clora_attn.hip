@@ -22,6 +22,7 @@
 //     transpose read start on 8 distinct multiples of 8 banks (conflict-free ds_read_b64_tr_b16) and the ds_read_b128
 //     fragment reads are conflict-free for the hardware's real lane groups as well (MI355X_MICROARCH.md section LDS;
 //     the round-1 pitch DP + 8 was 2-way conflicted for both).
+#include <stdlib.h>
 #include "clora_common.h"
 #include "../../include/clora.h"
 
@@ -65,51 +66,94 @@ __device__ __forceinline__ half8 frag_from_acc(floatx4 lo, floatx4 hi) {
     return r;
 }
 
-// register-staged tile loads: issue the global loads of tile t+1 before the MFMAs of tile t, write them to LDS
-// after the barrier that ends tile t (cdna_hip_programming.md T14)
-template <int ROWS, int DP>
-struct TileRegs {
-    static constexpr int N = (ROWS * (DP / 8) + 255) / 256;
-    half8 v[N];
+// K / V / Q / dO tiles go global -> LDS by LDS-DMA (`global_load_lds_dwordx4`: no staging registers, no ds_write pass) into a
+// DOUBLE-BUFFERED tile pair: the copy of tile t+1 is issued before the MFMAs of tile t and only has to have landed at the
+// single barrier that ends the iteration (s_waitcnt vmcnt(0) + s_barrier) -- one barrier per tile instead of two, no exposed
+// LDS write phase, and 16-32 VGPRs of staging registers returned to the loop.
+// A tile is ROWS x (LD/8) 16-byte chunks, row pitch LD halves (the conflict-free padded pitch of the fragment reads); the
+// DMA image is lane-linear, so one wave-instruction fills 64 consecutive chunk slots; the lane that owns slot s fetches
+// chunk s % (LD/8) of row s / (LD/8) -- or a 16-byte zero page for the head-dim / row padding, or (ONE) the "one page"
+// for the chunk that starts at column D: the ones column of V that makes P.V accumulate rowsum(P) (attn_fwd_kernel).
+__device__ __attribute__((aligned(16))) const unsigned g_attn_zero16[4] = {0u, 0u, 0u, 0u};
+__device__ __attribute__((aligned(16))) const unsigned short g_attn_one16[8] = {0x3C00u, 0, 0, 0, 0, 0, 0, 0};
+
+template <int ROWS, int LD>
+struct TileDma {
+    static constexpr int PCH = LD / 8;                 // chunks per padded row
+    static constexpr int NI = ROWS * PCH / 64;         // wave-instructions per tile
+    static constexpr int NIW = (NI + 3) / 4;           // ... per wave (wave w issues instructions w, w+4, ...)
+    static_assert((ROWS * PCH) % 64 == 0, "a tile must be a whole number of DMA wave-instructions");
+    int row[NIW], col[NIW];                            // this lane's (row, first column) per instruction; col -1: padding, -2: ones chunk
+    __device__ __forceinline__ void init(int w, int l, int D) {
+#pragma unroll
+        for (int j = 0; j < NIW; ++j) {
+            const int sl = (w + 4 * j) * 64 + l;
+            const int r = sl / PCH, c = sl - r * PCH;
+            row[j] = r;
+            col[j] = (c * 8 < D) ? c * 8 : (c * 8 == D ? -2 : -1);
+        }
+    }
+    template <bool ONE>
+    __device__ __forceinline__ void issue(const half_t* base, int ld, int rows_valid, half_t* dst, int w) const {
+        const half_t* zero_page = reinterpret_cast<const half_t*>(g_attn_zero16);
+        const half_t* one_page = reinterpret_cast<const half_t*>(g_attn_one16);
+#pragma unroll
+        for (int j = 0; j < NIW; ++j) {
+            const int i = w + 4 * j;
+            if (i < NI) {
+                const bool in = row[j] < rows_valid;       // selects, not branches: the issue path stays straight-line
+                const half_t* src = (in && col[j] >= 0) ? base + row[j] * ld + col[j] : zero_page;
+                if (ONE) src = (in && col[j] == -2) ? one_page : src;
+                CLORA_GLDS16(src, dst + i * 512);
+            }
+        }
+    }
 };
-template <int ROWS, int DP, bool ROW_FAST>
-__device__ __forceinline__ void tile_load(TileRegs<ROWS, DP>& r, const half_t* src, int ld, int rows_valid, int D, int t) {
-    constexpr int CPR = DP / 8;
-#pragma unroll
-    for (int i = 0; i < TileRegs<ROWS, DP>::N; ++i) {
-        const int c = t + 256 * i;
-        const int row = ROW_FAST ? c % ROWS : c / CPR;
-        const int col = (ROW_FAST ? c / ROWS : c - (c / CPR) * CPR) * 8;
-        half8 v = zero8();
-        if (c < ROWS * CPR && row < rows_valid && col < D) v = ld8(src + (size_t)row * ld + col);
-        r.v[i] = v;
-    }
-}
-template <int ROWS, int DP, int LD>
-__device__ __forceinline__ void tile_store_rows(const TileRegs<ROWS, DP>& r, half_t* dst, int t) {
-    constexpr int CPR = DP / 8;
-#pragma unroll
-    for (int i = 0; i < TileRegs<ROWS, DP>::N; ++i) {
-        const int c = t + 256 * i;
-        if (c < ROWS * CPR) { const int row = c / CPR, col = (c - row * CPR) * 8; st8(dst + row * LD + col, r.v[i]); }
-    }
+__device__ __forceinline__ floatx4 splat4f(float x) {
+    floatx4 z = {x, x, x, x};
+    return z;
 }
 // ------------------------------------------------------------------------------------------ forward
 // __launch_bounds__(256, 2) for head dims <= 64: with a 256-register budget the compiler keeps the MFMA accumulators in
 // VGPRs; with the default (one block per CU, 512 registers) it parks them in AGPRs and the softmax / rescale VALU work
 // pays ~145 v_accvgpr_read/write moves per KV tile (a third of the loop's VALU instructions).  Larger head dims would
 // spill at 256 registers and keep the default.
-template <int DP, int DT>
-__global__ __launch_bounds__(256, (DP <= 64 ? 2 : 1)) void attn_fwd_kernel(AttnArgs p) {
+//
+// The loop is VALU-bound at head dim 40 (32 exponentials + ~135 plain VALU instructions against 28 MFMAs per KV tile and
+// wave), so the softmax bookkeeping is kept off the vector pipe:
+//   * the exponent reference is LAZY: the score accumulators are initialised to -mref (free: it replaces the zero
+//     initialisation), so the MFMA delivers s - mref and the probabilities are one bare v_exp_f32 each -- no per-element
+//     subtraction.  mref only follows the running maximum when a tile exceeds it by more than 2^kRebase (wave-uniform
+//     branch; always on the first tile): probabilities are then bounded by 2^kRebase = 256 instead of 1, which changes
+//     nothing for fp16's relative precision or the fp32 accumulators, and the common tile pays no rescale of O.
+//   * ONES (head dims with D = 16 DT - 8, i.e. 40): V's zero-padding column D is staged as 1, so the P.V MFMAs that
+//     multiply the padding anyway accumulate rowsum(P) in row D of O^T -- no per-element additions, and the running sum
+//     is rescaled together with O.  (It is the sum of the fp16-rounded probabilities, i.e. exactly the weights that
+//     multiplied V.)
+constexpr float kRebase = 8.0f;
+
+template <int DP, int DT, bool ONES>
+__global__ __launch_bounds__(256, (DP <= 64 ? 3 : 1)) void attn_fwd_kernel(AttnArgs p) {
     constexpr int BKV = 64, LDK = DP + 16, DV = DT * 16, LDV = DV + ((DV % 32) == 16 ? 0 : 16), KS = DP / 32;
-    __shared__ __attribute__((aligned(16))) half_t smem[BKV * LDK + BKV * LDV];
-    half_t* Ks = smem;
-    half_t* Vs = smem + BKV * LDK;                         // V row-major [key][d]; read transposed (frag_tr) for P.V
+    constexpr int TILE = BKV * LDK + BKV * LDV;           // one K tile + one V tile; two of them: double buffer
+    __shared__ __attribute__((aligned(16))) half_t smem[2 * TILE];
     const int t = threadIdx.x, w = t >> 6, l = t & 63, g = l >> 4, li = l & 15;
     const int b = blockIdx.y / p.H, h = blockIdx.y % p.H;
     const int q0 = blockIdx.x * 128 + w * 32;
     const int D = p.D;
     const float c = p.scale * kLog2e;
+
+    const half_t* kbase = p.k + (size_t)b * p.Nk * p.ldk + h * D;
+    const half_t* vbase = p.v + (size_t)b * p.Nk * p.ldv + h * D;
+    TileDma<BKV, LDK> dk_;
+    TileDma<BKV, LDV> dv_;
+    dk_.init(w, l, D);
+    dv_.init(w, l, D);
+    {
+        const int rows0 = p.Nk < BKV ? p.Nk : BKV;
+        dk_.template issue<false>(kbase, p.ldk, rows0, smem, w);
+        dv_.template issue<ONES>(vbase, p.ldv, rows0, smem + BKV * LDK, w);
+    }
 
     half8 qf[2][KS];       // Q pre-multiplied by scale*log2(e): scores come out of the MFMA ready for exp2
 #pragma unroll
@@ -125,32 +169,26 @@ __global__ __launch_bounds__(256, (DP <= 64 ? 2 : 1)) void attn_fwd_kernel(AttnA
     floatx4 oacc[DT][2];
 #pragma unroll
     for (int i = 0; i < DT; ++i) { oacc[i][0] = zero4f(); oacc[i][1] = zero4f(); }
-    float mrun[2] = {kNegBig, kNegBig}, lrun[2] = {0.f, 0.f};
+    float mref[2] = {0.f, 0.f}, lrun[2] = {0.f, 0.f};
+    bool first = true;
 
-    const half_t* kbase = p.k + (size_t)b * p.Nk * p.ldk + h * D;
-    const half_t* vbase = p.v + (size_t)b * p.Nk * p.ldv + h * D;
-    TileRegs<BKV, DP> rk;
-    TileRegs<BKV, DV> rv;
-    {
-        const int rows0 = p.Nk < BKV ? p.Nk : BKV;
-        tile_load<BKV, DP, false>(rk, kbase, p.ldk, rows0, D, t);
-        tile_load<BKV, DV, false>(rv, vbase, p.ldv, rows0, D, t);
-    }
+    CLORA_WAIT_VMCNT(0);
+    __syncthreads();                                       // tile 0 has landed for every wave
+    int cur = 0;
     for (int kv0 = 0; kv0 < p.Nk; kv0 += BKV) {
         const int rows = (p.Nk - kv0 < BKV) ? p.Nk - kv0 : BKV;
-        __syncthreads();                                   // previous tile fully consumed
-        tile_store_rows<BKV, DP, LDK>(rk, Ks, t);
-        tile_store_rows<BKV, DV, LDV>(rv, Vs, t);
-        __syncthreads();
-        if (kv0 + BKV < p.Nk) {                            // prefetch the next tile while this one is processed
+        const half_t* Ks = smem + cur * TILE;
+        const half_t* Vs = Ks + BKV * LDK;                 // V row-major [key][d]; read transposed (frag_tr) for P.V
+        if (kv0 + BKV < p.Nk) {                            // tile t+1 -> the other buffer (consumed in iteration t-1, barrier since)
             const int nrows = (p.Nk - kv0 - BKV < BKV) ? p.Nk - kv0 - BKV : BKV;
-            tile_load<BKV, DP, false>(rk, kbase + (size_t)(kv0 + BKV) * p.ldk, p.ldk, nrows, D, t);
-            tile_load<BKV, DV, false>(rv, vbase + (size_t)(kv0 + BKV) * p.ldv, p.ldv, nrows, D, t);
+            half_t* nb = smem + (cur ^ 1) * TILE;
+            dk_.template issue<false>(kbase + (size_t)(kv0 + BKV) * p.ldk, p.ldk, nrows, nb, w);
+            dv_.template issue<ONES>(vbase + (size_t)(kv0 + BKV) * p.ldv, p.ldv, nrows, nb + BKV * LDK, w);
         }
 
         floatx4 s[4][2];
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt) { s[kt][0] = zero4f(); s[kt][1] = zero4f(); }
+        for (int kt = 0; kt < 4; ++kt) { s[kt][0] = splat4f(-mref[0]); s[kt][1] = splat4f(-mref[1]); }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
@@ -166,30 +204,44 @@ __global__ __launch_bounds__(256, (DP <= 64 ? 2 : 1)) void attn_fwd_kernel(AttnA
                 for (int r = 0; r < 4; ++r)
                     if (kt * 16 + 4 * g + r >= rows) { s[kt][0][r] = kNegBig; s[kt][1][r] = kNegBig; }
         }
+        float mx[2];
 #pragma unroll
         for (int qg = 0; qg < 2; ++qg) {
-            float mx = kNegBig;
+            float m = kNegBig;
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][qg][r]);
-            mx = fmaxf(mx, __shfl_xor(mx, 16));
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
-            const float mnew = fmaxf(mrun[qg], mx);
-            const float alpha = CLORA_EXP2(mrun[qg] - mnew);
-            mrun[qg] = mnew;
+                for (int r = 0; r < 4; ++r) m = fmaxf(m, s[kt][qg][r]);
+            m = fmaxf(m, __shfl_xor(m, 16));
+            m = fmaxf(m, __shfl_xor(m, 32));
+            mx[qg] = m;                                    // tile maximum relative to mref, same in the 4 lanes of a query
+        }
+        if (__any(first || mx[0] > kRebase || mx[1] > kRebase)) {
+#pragma unroll
+            for (int qg = 0; qg < 2; ++qg) {
+                const float d = (first || mx[qg] > kRebase) ? mx[qg] : 0.f;
+                const float alpha = CLORA_EXP2(-d);
+                mref[qg] += d;
+                lrun[qg] *= alpha;
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt) s[kt][qg] -= d;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) oacc[dt][qg] *= alpha;
+            }
+            first = false;
+        }
+#pragma unroll
+        for (int qg = 0; qg < 2; ++qg) {
             float ps = 0.f;
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float pv = CLORA_EXP2(s[kt][qg][r] - mnew);
+                    const float pv = CLORA_EXP2(s[kt][qg][r]);
                     s[kt][qg][r] = pv;
-                    ps += pv;
+                    if (!ONES) ps += pv;
                 }
-            lrun[qg] = lrun[qg] * alpha + ps;
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt) oacc[dt][qg] *= alpha;
+            if (!ONES) lrun[qg] += ps;
         }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -202,12 +254,20 @@ __global__ __launch_bounds__(256, (DP <= 64 ? 2 : 1)) void attn_fwd_kernel(AttnA
                 oacc[dt][1] = mfma16(a, pb1, oacc[dt][1]);
             }
         }
+        CLORA_WAIT_VMCNT(0);                               // this wave's share of tile t+1 has landed ...
+        __syncthreads();                                   // ... everyone's has, and tile t is fully consumed
+        cur ^= 1;
     }
 #pragma unroll
     for (int qg = 0; qg < 2; ++qg) {
-        float lt = lrun[qg];
-        lt += __shfl_xor(lt, 16);
-        lt += __shfl_xor(lt, 32);
+        float lt;
+        if (ONES) {
+            lt = __shfl(oacc[DT - 1][qg][0], 32 + li);     // row D = 16 (DT-1) + 8 of O^T: lane group 2, register 0
+        } else {
+            lt = lrun[qg];
+            lt += __shfl_xor(lt, 16);
+            lt += __shfl_xor(lt, 32);
+        }
         const float inv = 1.0f / lt;
         const int q = q0 + qg * 16 + li;
         if (q < p.Nq) {
@@ -221,7 +281,7 @@ __global__ __launch_bounds__(256, (DP <= 64 ? 2 : 1)) void attn_fwd_kernel(AttnA
                     st4(p.out + ((size_t)b * p.Nq + q) * p.ldo + h * D + d, o);
                 }
             }
-            if (g == 0 && p.lse) p.lse[((size_t)b * p.H + h) * p.Nq + q] = (mrun[qg] + log2f(lt)) * kLn2;
+            if (g == 0 && p.lse) p.lse[((size_t)b * p.H + h) * p.Nq + q] = (mref[qg] + log2f(lt)) * kLn2;
         }
     }
 }
@@ -230,13 +290,21 @@ __global__ __launch_bounds__(256, (DP <= 64 ? 2 : 1)) void attn_fwd_kernel(AttnA
 template <int DP, int DT, int BKV>
 __global__ __launch_bounds__(256, (DP <= 64 ? 2 : 1)) void attn_bwd_dq_kernel(AttnArgs p) {
     constexpr int LDK = DP + 16, KS = DP / 32, KT = BKV / 16, NP = BKV / 32;
-    __shared__ __attribute__((aligned(16))) half_t smem[2 * BKV * LDK];
-    half_t* Ks = smem;                                     // K row-major: A operand of S^T as is, of dQ^T through frag_tr
-    half_t* Vs = smem + BKV * LDK;
+    constexpr int TILE = 2 * BKV * LDK;                    // K tile + V tile; double buffered (see TileDma)
+    __shared__ __attribute__((aligned(16))) half_t smem[2 * TILE];
     const int t = threadIdx.x, w = t >> 6, l = t & 63, g = l >> 4, li = l & 15;
     const int b = blockIdx.y / p.H, h = blockIdx.y % p.H;
     const int q0 = blockIdx.x * 128 + w * 32;
     const int D = p.D;
+    const half_t* kbase = p.k + (size_t)b * p.Nk * p.ldk + h * D;
+    const half_t* vbase = p.v + (size_t)b * p.Nk * p.ldv + h * D;
+    TileDma<BKV, LDK> dma;                                 // K and V tiles share the slot -> (row, column) map
+    dma.init(w, l, D);
+    {
+        const int rows0 = p.Nk < BKV ? p.Nk : BKV;
+        dma.template issue<false>(kbase, p.ldk, rows0, smem, w);
+        dma.template issue<false>(vbase, p.ldv, rows0, smem + BKV * LDK, w);
+    }
 
     half8 qf[2][KS], dof[2][KS];
     float Lq[2], Dq[2];
@@ -281,29 +349,28 @@ __global__ __launch_bounds__(256, (DP <= 64 ? 2 : 1)) void attn_bwd_dq_kernel(At
 #pragma unroll
     for (int i = 0; i < DT; ++i) { acc[i][0] = zero4f(); acc[i][1] = zero4f(); }
 
-    const half_t* kbase = p.k + (size_t)b * p.Nk * p.ldk + h * D;
-    const half_t* vbase = p.v + (size_t)b * p.Nk * p.ldv + h * D;
-    TileRegs<BKV, DP> rk, rv;
-    {
-        const int rows0 = p.Nk < BKV ? p.Nk : BKV;
-        tile_load<BKV, DP, false>(rk, kbase, p.ldk, rows0, D, t);
-        tile_load<BKV, DP, false>(rv, vbase, p.ldv, rows0, D, t);
-    }
+    CLORA_WAIT_VMCNT(0);
+    __syncthreads();                                       // tile 0 has landed for every wave
+    int cur = 0;
     for (int kv0 = 0; kv0 < p.Nk; kv0 += BKV) {
         const int rows = (p.Nk - kv0 < BKV) ? p.Nk - kv0 : BKV;
-        __syncthreads();
-        tile_store_rows<BKV, DP, LDK>(rk, Ks, t);
-        tile_store_rows<BKV, DP, LDK>(rv, Vs, t);
-        __syncthreads();
-        if (kv0 + BKV < p.Nk) {
+        const half_t* Ks = smem + cur * TILE;              // K row-major: A operand of S^T as is, of dQ^T through frag_tr
+        const half_t* Vs = Ks + BKV * LDK;
+        if (kv0 + BKV < p.Nk) {                            // tile t+1 -> the other buffer
             const int nrows = (p.Nk - kv0 - BKV < BKV) ? p.Nk - kv0 - BKV : BKV;
-            tile_load<BKV, DP, false>(rk, kbase + (size_t)(kv0 + BKV) * p.ldk, p.ldk, nrows, D, t);
-            tile_load<BKV, DP, false>(rv, vbase + (size_t)(kv0 + BKV) * p.ldv, p.ldv, nrows, D, t);
+            half_t* nb = smem + (cur ^ 1) * TILE;
+            dma.template issue<false>(kbase + (size_t)(kv0 + BKV) * p.ldk, p.ldk, nrows, nb, w);
+            dma.template issue<false>(vbase + (size_t)(kv0 + BKV) * p.ldv, p.ldv, nrows, nb + BKV * LDK, w);
         }
 
+        // the accumulators start at -LSE / -delta of the lane's query column: the MFMAs deliver s - L and dP - delta
+        // directly and dS^T is one exponential and one multiplication per element
         floatx4 s[KT][2], dp[KT][2];
 #pragma unroll
-        for (int kt = 0; kt < KT; ++kt) { s[kt][0] = zero4f(); s[kt][1] = zero4f(); dp[kt][0] = zero4f(); dp[kt][1] = zero4f(); }
+        for (int kt = 0; kt < KT; ++kt) {
+            s[kt][0] = splat4f(-Lq[0]); s[kt][1] = splat4f(-Lq[1]);
+            dp[kt][0] = splat4f(-Dq[0]); dp[kt][1] = splat4f(-Dq[1]);
+        }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
@@ -322,7 +389,7 @@ __global__ __launch_bounds__(256, (DP <= 64 ? 2 : 1)) void attn_bwd_dq_kernel(At
                 for (int qg = 0; qg < 2; ++qg)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        s[kt][qg][r] = CLORA_EXP2(s[kt][qg][r] - Lq[qg]) * (dp[kt][qg][r] - Dq[qg]);  // dS^T
+                        s[kt][qg][r] = CLORA_EXP2(s[kt][qg][r]) * dp[kt][qg][r];  // dS^T
         } else {
 #pragma unroll
             for (int kt = 0; kt < KT; ++kt)
@@ -331,8 +398,8 @@ __global__ __launch_bounds__(256, (DP <= 64 ? 2 : 1)) void attn_bwd_dq_kernel(At
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const bool ok = (kt * 16 + 4 * g + r) < rows;
-                        const float pv = ok ? CLORA_EXP2(s[kt][qg][r] - Lq[qg]) : 0.f;
-                        s[kt][qg][r] = pv * (dp[kt][qg][r] - Dq[qg]);
+                        const float pv = ok ? CLORA_EXP2(s[kt][qg][r]) : 0.f;
+                        s[kt][qg][r] = pv * dp[kt][qg][r];
                     }
         }
 #pragma unroll
@@ -346,6 +413,9 @@ __global__ __launch_bounds__(256, (DP <= 64 ? 2 : 1)) void attn_bwd_dq_kernel(At
                 acc[dt][1] = mfma16(a, b1, acc[dt][1]);
             }
         }
+        CLORA_WAIT_VMCNT(0);                               // tile t+1 has landed; tile t is fully consumed after the barrier
+        __syncthreads();
+        cur ^= 1;
     }
 #pragma unroll
     for (int qg = 0; qg < 2; ++qg) {
@@ -366,20 +436,45 @@ __global__ __launch_bounds__(256, (DP <= 64 ? 2 : 1)) void attn_bwd_dq_kernel(At
 }
 
 // ------------------------------------------------------------------------------------------ dK, dV
-template <int DP, int DT, int BQT>
-__global__ __launch_bounds__(256, (DP <= 64 ? 2 : 1)) void attn_bwd_dkv_kernel(AttnArgs p) {
+// OCC: blocks per CU the register allocator is asked to leave room for at head dims <= 64 (2: no spills, 8 waves per CU;
+// 3: 12 waves per CU at the price of ~48 spilled dwords of loop-invariant addresses) -- A/B switch CLORA_ATTN_DKV_OCC
+template <int DP, int DT, int BQT, int OCC>
+__global__ __launch_bounds__(256, (DP <= 64 ? OCC : 1)) void attn_bwd_dkv_kernel(AttnArgs p) {
     constexpr int LDK = DP + 16, KS = DP / 32, QT = BQT / 16, NP = BQT / 32;
-    constexpr int HALVES = 2 * BQT * LDK;
-    __shared__ __attribute__((aligned(16))) half_t smem[HALVES + 4 * BQT];
-    half_t* Qs = smem;                                     // Q, dO row-major: A operands of S / dP as is, of dK / dV through frag_tr
-    half_t* dOs = smem + BQT * LDK;
-    float* Ls = reinterpret_cast<float*>(smem + HALVES);
-    float* Ds = Ls + BQT;
+    constexpr int TILE = 2 * BQT * LDK;                    // Q tile + dO tile; double buffered (see TileDma)
+    __shared__ __attribute__((aligned(16))) half_t smem[2 * TILE + 2 * 4 * BQT];
+    float* LD_ = reinterpret_cast<float*>(smem + 2 * TILE);   // [2 buffers][-LSE*log2e (BQT) | -delta (BQT)]
     const int t = threadIdx.x, w = t >> 6, l = t & 63, g = l >> 4, li = l & 15;
     const int b = blockIdx.y / p.H, h = blockIdx.y % p.H;
     const int k0 = blockIdx.x * 128 + w * 32;
     const int D = p.D;
+    const float c = p.scale * kLog2e;
 
+    const int q_beg = blockIdx.z * p.q_per_split;
+    const int q_end = (q_beg + p.q_per_split < p.Nq) ? q_beg + p.q_per_split : p.Nq;
+    const half_t* qbase = p.q + (size_t)b * p.Nq * p.ldq + h * D;
+    const half_t* dobase = p.dO + (size_t)b * p.Nq * p.lddo + h * D;
+    const size_t sbase = ((size_t)b * p.H + h) * p.Nq;
+    TileDma<BQT, LDK> dma;                                 // Q and dO tiles share the slot -> (row, column) map
+    dma.init(w, l, D);
+    // thread t < BQT carries -LSE*log2(e) of query row t of the tile in flight, thread BQT <= t < 2 BQT carries -delta:
+    // they initialise the accumulators (below), so they are kept negated
+    auto load_ld = [&](int qq, int rows) -> float {
+        if (t >= 2 * BQT) return 0.f;
+        const int r = t < BQT ? t : t - BQT;
+        if (r >= rows) return t < BQT ? -1.0e30f : 0.f;
+        return t < BQT ? -p.lse_in[sbase + qq + r] * kLog2e : -p.delta[sbase + qq + r];
+    };
+    float ldreg;
+    {
+        const int rows0 = (q_end - q_beg < BQT) ? q_end - q_beg : BQT;
+        dma.template issue<false>(qbase + (size_t)q_beg * p.ldq, p.ldq, rows0, smem, w);
+        dma.template issue<false>(dobase + (size_t)q_beg * p.lddo, p.lddo, rows0, smem + BQT * LDK, w);
+        ldreg = load_ld(q_beg, rows0);
+    }
+
+    // K pre-multiplied by scale*log2(e) (as the forward does with Q): S leaves the MFMA ready for exp2 once the accumulator
+    // carries -LSE; Q stays unscaled in LDS because dK = scale * dS^T Q contracts against it
     half8 kf[2][KS], vf[2][KS];
 #pragma unroll
     for (int kg = 0; kg < 2; ++kg)
@@ -387,38 +482,43 @@ __global__ __launch_bounds__(256, (DP <= 64 ? 2 : 1)) void attn_bwd_dkv_kernel(A
         for (int ks = 0; ks < KS; ++ks) {
             const int key = k0 + kg * 16 + li, d = ks * 32 + g * 8;
             const bool ok = key < p.Nk && d < D;
-            kf[kg][ks] = ok ? ld8(p.k + ((size_t)b * p.Nk + key) * p.ldk + h * D + d) : zero8();
+            half8 kv_ = ok ? ld8(p.k + ((size_t)b * p.Nk + key) * p.ldk + h * D + d) : zero8();
+#pragma unroll
+            for (int e = 0; e < 8; ++e) kv_[e] = (half_t)((float)kv_[e] * c);
+            kf[kg][ks] = kv_;
             vf[kg][ks] = ok ? ld8(p.v + ((size_t)b * p.Nk + key) * p.ldv + h * D + d) : zero8();
         }
     floatx4 dkacc[DT][2], dvacc[DT][2];
 #pragma unroll
     for (int i = 0; i < DT; ++i) { dkacc[i][0] = zero4f(); dkacc[i][1] = zero4f(); dvacc[i][0] = zero4f(); dvacc[i][1] = zero4f(); }
-    const float c = p.scale * kLog2e;
 
-    const int q_beg = blockIdx.z * p.q_per_split;
-    const int q_end = (q_beg + p.q_per_split < p.Nq) ? q_beg + p.q_per_split : p.Nq;
+    CLORA_WAIT_VMCNT(0);
+    if (t < 2 * BQT) LD_[t] = ldreg;
+    __syncthreads();                                       // tile 0 (and its LSE / delta) is in LDS for every wave
+    int cur = 0;
     for (int qq = q_beg; qq < q_end; qq += BQT) {
-        const int rows = (q_end - qq < BQT) ? q_end - qq : BQT;
-        const half_t* qg_ = p.q + ((size_t)b * p.Nq + qq) * p.ldq + h * D;
-        const half_t* dog = p.dO + ((size_t)b * p.Nq + qq) * p.lddo + h * D;
-        __syncthreads();
-        {
-            TileRegs<BQT, DP> rq, rdo;
-            tile_load<BQT, DP, false>(rq, qg_, p.ldq, rows, D, t);
-            tile_load<BQT, DP, false>(rdo, dog, p.lddo, rows, D, t);
-            tile_store_rows<BQT, DP, LDK>(rq, Qs, t);
-            tile_store_rows<BQT, DP, LDK>(rdo, dOs, t);
+        const half_t* Qs = smem + cur * TILE;              // Q, dO row-major: A operands of S / dP as is, of dK / dV through frag_tr
+        const half_t* dOs = Qs + BQT * LDK;
+        const float* Ls = LD_ + cur * 2 * BQT;
+        const float* Ds = Ls + BQT;
+        const bool more = qq + BQT < q_end;
+        if (more) {                                        // tile t+1 -> the other buffer
+            const int nrows = (q_end - qq - BQT < BQT) ? q_end - qq - BQT : BQT;
+            half_t* nb = smem + (cur ^ 1) * TILE;
+            dma.template issue<false>(qbase + (size_t)(qq + BQT) * p.ldq, p.ldq, nrows, nb, w);
+            dma.template issue<false>(dobase + (size_t)(qq + BQT) * p.lddo, p.lddo, nrows, nb + BQT * LDK, w);
+            ldreg = load_ld(qq + BQT, nrows);
         }
-        if (t < BQT) {
-            const size_t si = ((size_t)b * p.H + h) * p.Nq + qq + t;
-            Ls[t] = (t < rows) ? p.lse_in[si] * kLog2e : 1.0e30f;
-            Ds[t] = (t < rows) ? p.delta[si] : 0.f;
-        }
-        __syncthreads();
 
+        // accumulators start at -LSE / -delta of their query rows (kept negated in LDS; 4 consecutive rows per lane: one 16-byte
+        // read each): the MFMAs deliver s*c - L and dP - delta, P and dS cost one v_exp_f32 and one v_mul_f32 per element
         floatx4 s[QT][2], dp[QT][2];
 #pragma unroll
-        for (int qt = 0; qt < QT; ++qt) { s[qt][0] = zero4f(); s[qt][1] = zero4f(); dp[qt][0] = zero4f(); dp[qt][1] = zero4f(); }
+        for (int qt = 0; qt < QT; ++qt) {
+            const floatx4 lv = *reinterpret_cast<const floatx4*>(Ls + qt * 16 + 4 * g);
+            const floatx4 dv = *reinterpret_cast<const floatx4*>(Ds + qt * 16 + 4 * g);
+            s[qt][0] = lv; s[qt][1] = lv; dp[qt][0] = dv; dp[qt][1] = dv;
+        }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
@@ -433,16 +533,13 @@ __global__ __launch_bounds__(256, (DP <= 64 ? 2 : 1)) void attn_bwd_dkv_kernel(A
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int ql = qt * 16 + 4 * g + r;
-                const float Lv = Ls[ql], Dv = Ds[ql];
+            for (int kg = 0; kg < 2; ++kg)
 #pragma unroll
-                for (int kg = 0; kg < 2; ++kg) {
-                    const float pv = CLORA_EXP2(s[qt][kg][r] * c - Lv);
+                for (int r = 0; r < 4; ++r) {
+                    const float pv = CLORA_EXP2(s[qt][kg][r]);
                     s[qt][kg][r] = pv;                       // P
-                    dp[qt][kg][r] = pv * (dp[qt][kg][r] - Dv);  // dS
+                    dp[qt][kg][r] *= pv;                     // dS
                 }
-            }
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
             const half8 p0 = frag_from_acc(s[2 * j][0], s[2 * j + 1][0]);
@@ -459,6 +556,10 @@ __global__ __launch_bounds__(256, (DP <= 64 ? 2 : 1)) void attn_bwd_dkv_kernel(A
                 dkacc[dt][1] = mfma16(aq, d1, dkacc[dt][1]);
             }
         }
+        CLORA_WAIT_VMCNT(0);                               // tile t+1 and its LSE / delta values have arrived
+        if (more && t < 2 * BQT) LD_[(cur ^ 1) * 2 * BQT + t] = ldreg;
+        __syncthreads();                                   // ... for every wave, and tile t is fully consumed
+        cur ^= 1;
     }
 #pragma unroll
     for (int kg = 0; kg < 2; ++kg) {
@@ -508,7 +609,9 @@ __global__ __launch_bounds__(256) void attn_dkv_convert_kernel(AttnArgs p) {
 
 template <int DP, int DT>
 int launch_fwd(const AttnArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL((attn_fwd_kernel<DP, DT>), dim3(clora_cdiv(a.Nq, 128), a.B * a.H), dim3(256), 0, s, a);
+    const dim3 grid(clora_cdiv(a.Nq, 128), a.B * a.H);
+    if (a.D == DT * 16 - 8) hipLaunchKernelGGL((attn_fwd_kernel<DP, DT, true>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((attn_fwd_kernel<DP, DT, false>), grid, dim3(256), 0, s, a);
     return clora_check_launch();
 }
 template <int DP, int DT, int BT>
@@ -516,7 +619,10 @@ int launch_bwd(const AttnArgs& a, hipStream_t s) {
     hipLaunchKernelGGL((attn_bwd_dq_kernel<DP, DT, BT>), dim3(clora_cdiv(a.Nq, 128), a.B * a.H), dim3(256), 0, s, a);
     int rc = clora_check_launch();
     if (rc != CLORA_OK) return rc;
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<DP, DT, BT>), dim3(clora_cdiv(a.Nk, 128), a.B * a.H, a.nsplit), dim3(256), 0, s, a);
+    static const int occ3 = [] { const char* e = getenv("CLORA_ATTN_DKV_OCC"); return e && e[0] == '3'; }();
+    const dim3 gkv(clora_cdiv(a.Nk, 128), a.B * a.H, a.nsplit);
+    if (DP <= 64 && occ3) hipLaunchKernelGGL((attn_bwd_dkv_kernel<DP, DT, BT, 3>), gkv, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((attn_bwd_dkv_kernel<DP, DT, BT, 2>), gkv, dim3(256), 0, s, a);
     if (a.nsplit > 1) {
         const size_t total = (size_t)a.B * a.Nk * (a.H * a.D / 4);
         int blocks = (int)((total + 255) / 256);

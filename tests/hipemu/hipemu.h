@@ -74,6 +74,13 @@ template <typename T> static inline T __shfl(T v, int src, int = 64) { return hi
 template <typename T> static inline T __shfl_xor(T v, int mask, int = 64) { return hipemu_shfl(v, mask, 1); }
 template <typename T> static inline T __shfl_down(T v, int d, int = 64) { return hipemu_shfl(v, d, 2); }
 
+// wave vote: OR of the predicate over the live lanes (butterfly of xor shuffles; missing lanes read themselves)
+static inline int __any(int pred) {
+    int v = pred ? 1 : 0;
+    for (int m = 32; m >= 1; m >>= 1) v |= hipemu_shfl(v, m, 1);
+    return v;
+}
+
 static inline hipemu_floatx4 __builtin_amdgcn_mfma_f32_16x16x32_f16(hipemu_half8 a, hipemu_half8 b,
                                                                     hipemu_floatx4 c, int, int, int) {
     return hipemu::mfma_16x16x32_f16(a, b, c);

@@ -142,7 +142,10 @@ def _attn_ref(q, k, v, H, scale):
     return (p @ vh).permute(0, 2, 1, 3).reshape(B, Nq, HD)
 
 
-def case_attention(dev, B, H, Nq, Nk, D, seed=3, fused_qkv=False, tol=2e-3):
+def case_attention(dev, B, H, Nq, Nk, D, seed=3, fused_qkv=False, tol=2e-3, ramp=0.0):
+    """ramp > 0: keys grow along the sequence (k_j scaled by 1 + ramp*j/Nk) and q is 3x larger, so the row maxima keep
+    rising from KV tile to KV tile by more than the forward kernel's lazy-rescale threshold: the rebase path runs on
+    later tiles too, for some queries of a wave and not for others."""
     g = torch.Generator().manual_seed(seed)
     scale = D ** -0.5
     if fused_qkv:   # q,k,v are column slices of one [B*N, 3*H*D] buffer (self-attention layout)
@@ -150,6 +153,11 @@ def case_attention(dev, B, H, Nq, Nk, D, seed=3, fused_qkv=False, tol=2e-3):
         q2, k2, v2 = qkv[:, :H * D], qkv[:, H * D:2 * H * D], qkv[:, 2 * H * D:]
     else:
         q2, k2, v2 = rnd((B * Nq, H * D), dev, g), rnd((B * Nk, H * D), dev, g), rnd((B * Nk, H * D), dev, g)
+    if ramp > 0:
+        assert not fused_qkv
+        w = 1.0 + ramp * torch.arange(Nk, dtype=f32).repeat(B)[:, None] / Nk
+        k2 = (k2.float().cpu() * w).to(f16).to(dev)
+        q2 = (q2.float() * 3.0).to(f16)
     q3 = q2.reshape(B, Nq, H * D).float().clone().requires_grad_(True)
     k3 = k2.reshape(B, Nk, H * D).float().clone().requires_grad_(True)
     v3 = v2.reshape(B, Nk, H * D).float().clone().requires_grad_(True)

@@ -52,6 +52,12 @@ def test_attention(B, H, Nq, Nk, D, fused):
     KC.case_attention("cpu", B, H, Nq, Nk, D, fused_qkv=fused)
 
 
+@pytest.mark.parametrize("D", [40, 80])
+def test_attention_rising_maxima(D):
+    """forward: lazy exponent reference, rebased on later KV tiles for a subset of the queries (D = 40: rowsum from the ones column)"""
+    KC.case_attention("cpu", 1, 2, 70, 300, D, ramp=4.0, tol=3e-3)
+
+
 @pytest.mark.parametrize("B,HW,C,G,silu,train", [(2, 50, 320, 32, True, False), (1, 37, 64, 8, False, False),
                                                  (2, 64, 32, 32, True, True), (1, 9, 2560, 32, True, False),
                                                  (2, 300, 64, 8, True, False), (2, 256, 320, 32, False, False)])

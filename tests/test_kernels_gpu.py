@@ -62,6 +62,12 @@ def test_attention(B, H, Nq, Nk, D, fused):
     KC.case_attention(DEV, B, H, Nq, Nk, D, fused_qkv=fused)
 
 
+@pytest.mark.parametrize("Nq,Nk,D", [(1024, 4096, 40), (300, 1000, 80), (70, 300, 160)])
+def test_attention_rising_maxima(Nq, Nk, D):
+    """forward: lazy exponent reference, rebased on later KV tiles for a subset of the queries (D = 40: rowsum from the ones column)"""
+    KC.case_attention(DEV, 2, 8, Nq, Nk, D, ramp=4.0, tol=3e-3)
+
+
 @pytest.mark.parametrize("B,HW,C,G,silu,train", [(2, 4096, 320, 32, True, False), (2, 1024, 960, 32, True, False),
                                                  (1, 64, 2560, 32, True, False), (2, 4096, 32, 32, True, True),
                                                  (1, 1024, 640, 32, False, False), (1, 37, 64, 8, False, True),
