@@ -166,7 +166,7 @@ def dry_run(args):
     return 0 if ok else 1
 
 
-GEMM_FAMILY = ("gemm_dma_kernel", "splitk_finish_kernel", "gemm_")       # kernels behind clora_gemm_f16_ex
+GEMM_FAMILY = ("gemm_dma_kernel", "conv3x3_patch_kernel", "splitk_finish_kernel", "gemm_")       # kernels behind clora_gemm_f16_ex
 
 
 def rocprof_child_trace(args, steps=6, warmup=2):

@@ -22,7 +22,6 @@
 //     transpose read start on 8 distinct multiples of 8 banks (conflict-free ds_read_b64_tr_b16) and the ds_read_b128
 //     fragment reads are conflict-free for the hardware's real lane groups as well (MI355X_MICROARCH.md section LDS;
 //     the round-1 pitch DP + 8 was 2-way conflicted for both).
-#include <stdlib.h>
 #include "clora_common.h"
 #include "../../include/clora.h"
 
@@ -436,10 +435,10 @@ __global__ __launch_bounds__(256, (DP <= 64 ? 2 : 1)) void attn_bwd_dq_kernel(At
 }
 
 // ------------------------------------------------------------------------------------------ dK, dV
-// OCC: blocks per CU the register allocator is asked to leave room for at head dims <= 64 (2: no spills, 8 waves per CU;
-// 3: 12 waves per CU at the price of ~48 spilled dwords of loop-invariant addresses) -- A/B switch CLORA_ATTN_DKV_OCC
-template <int DP, int DT, int BQT, int OCC>
-__global__ __launch_bounds__(256, (DP <= 64 ? OCC : 1)) void attn_bwd_dkv_kernel(AttnArgs p) {
+// (256, 2): asking for 3 blocks per CU (168 registers) spills ~48 dwords of loop-invariant addresses into the loop --
+// measured 1.75x SLOWER at d = 40 (profiles/r02_attn_ab.json note); with the DMA double buffer two blocks hide the latency.
+template <int DP, int DT, int BQT>
+__global__ __launch_bounds__(256, (DP <= 64 ? 2 : 1)) void attn_bwd_dkv_kernel(AttnArgs p) {
     constexpr int LDK = DP + 16, KS = DP / 32, QT = BQT / 16, NP = BQT / 32;
     constexpr int TILE = 2 * BQT * LDK;                    // Q tile + dO tile; double buffered (see TileDma)
     __shared__ __attribute__((aligned(16))) half_t smem[2 * TILE + 2 * 4 * BQT];
@@ -619,10 +618,7 @@ int launch_bwd(const AttnArgs& a, hipStream_t s) {
     hipLaunchKernelGGL((attn_bwd_dq_kernel<DP, DT, BT>), dim3(clora_cdiv(a.Nq, 128), a.B * a.H), dim3(256), 0, s, a);
     int rc = clora_check_launch();
     if (rc != CLORA_OK) return rc;
-    static const int occ3 = [] { const char* e = getenv("CLORA_ATTN_DKV_OCC"); return e && e[0] == '3'; }();
-    const dim3 gkv(clora_cdiv(a.Nk, 128), a.B * a.H, a.nsplit);
-    if (DP <= 64 && occ3) hipLaunchKernelGGL((attn_bwd_dkv_kernel<DP, DT, BT, 3>), gkv, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((attn_bwd_dkv_kernel<DP, DT, BT, 2>), gkv, dim3(256), 0, s, a);
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<DP, DT, BT>), dim3(clora_cdiv(a.Nk, 128), a.B * a.H, a.nsplit), dim3(256), 0, s, a);
     if (a.nsplit > 1) {
         const size_t total = (size_t)a.B * a.Nk * (a.H * a.D / 4);
         int blocks = (int)((total + 255) / 256);

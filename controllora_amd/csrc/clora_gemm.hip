@@ -289,6 +289,124 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
 // Out-of-range / padding chunks are fetched from a 16-byte zero page.
 __device__ __attribute__((aligned(16))) const unsigned g_clora_zero16[4] = {0u, 0u, 0u, 0u};
 
+// Epilogue shared by the LDS-DMA main loops (gemm_dma_kernel, conv3x3_patch_kernel): split-K slab, or fp32 accumulators ->
+// LDS (64 rows per pass) -> per row-chunk: bias / time-embedding / rank-r adapter update (float4 operand loads) -> fp16 ->
+// + residual (or the fused GEGLU forms) -> 16-byte coalesced stores.  NT threads = WM x WN waves, wave tile FM x FN MFMA tiles.
+template <int BM, int BN, int WM, int WN, int NT, int SMEM>
+__device__ __forceinline__ void dma_epilogue(const GemmArgs& p, floatx4 (&acc)[BM / WM / 16][BN / WN / 16], int m0, int n0, int split,
+                                             half_t* smem, int t) {
+    constexpr int FM = BM / WM / 16, FN = BN / WN / 16;
+    const int w = t >> 6, l = t & 63, g = l >> 4, li = l & 15;
+    const int wm = w / WN, wn = w % WN;
+    if (p.partial) {
+        float* slab = p.partial + (size_t)split * p.M * p.N;
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = m0 + wm * FM * 16 + i * 16 + 4 * g + r;
+                    const int n = n0 + wn * FN * 16 + j * 16 + li;
+                    if (m < p.M && n < p.N) slab[(size_t)m * p.N + n] = acc[i][j][r];
+                }
+        return;
+    }
+    // ---- fp32 accumulators -> LDS (64 rows per pass) -> per row-chunk: bias / time-embedding / rank-r
+    // adapter update (float4 operand loads) -> fp16 -> + residual -> 16-byte coalesced stores.  Doing the fused
+    // math AFTER the LDS hop keeps it out of the main loop's register budget.
+    constexpr int PR = 64, F_LD = BN + 4, NPASS = BM / PR;
+    static_assert(PR * F_LD * 2 <= SMEM, "fp32 staging must fit in the LDS allocation");
+    float* Cf = reinterpret_cast<float*>(smem);
+    constexpr int CPR = BN / 8;
+#pragma unroll
+    for (int ph = 0; ph < NPASS; ++ph) {
+        __syncthreads();                                       // ring (or previous pass) fully consumed
+        const int wrow0 = wm * FM * 16;                        // first tile row of this wave
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            const int frow = wrow0 + i * 16;                   // this fragment's 16 rows lie inside one 64-row pass
+            if (frow >= ph * PR && frow < (ph + 1) * PR) {
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        Cf[(frow - ph * PR + 4 * g + r) * F_LD + wn * FN * 16 + j * 16 + li] = acc[i][j][r];
+            }
+        }
+        __syncthreads();
+        if (p.epi.geglu == 1) {
+            // forward GEGLU: tile columns come in groups of [64 a | 64 g]; one thread takes an a-chunk and its g-chunk
+            if constexpr (BN % 128 == 0) {
+                constexpr int HPR = CPR / 2;                   // a-chunks per tile row
+                const int F = p.epi.geglu_f;
+                for (int c = t; c < PR * HPR; c += NT) {
+                    const int ml = c / HPR, hc = c - ml * HPR;
+                    const int col = (hc >> 3) * 128 + (hc & 7) * 8;        // tile column of the a-chunk; g sits 64 further
+                    const int m = m0 + ph * PR + ml, n = n0 + col;
+                    if (m < p.M && n < p.N) {
+                        float va[8], vg[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { va[e] = Cf[ml * F_LD + col + e]; vg[e] = Cf[ml * F_LD + col + 64 + e]; }
+                        epi_chunk8(va, m, n, p.epi);
+                        epi_chunk8(vg, m, n + 64, p.epi);
+                        const int j = (n >> 7) * 64 + (hc & 7) * 8;       // column in the standard [a | g] layout
+                        half8 a8, g8, y8;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            a8[e] = (half_t)va[e];
+                            g8[e] = (half_t)vg[e];
+                            y8[e] = (half_t)((float)a8[e] * gelu_f((float)g8[e]));
+                        }
+                        st8((half_t*)p.epi.geglu_y + (size_t)m * F + j, y8);
+                        if (p.C) {
+                            st8(p.C + (size_t)m * p.ldc + j, a8);
+                            st8(p.C + (size_t)m * p.ldc + F + j, g8);
+                        }
+                    }
+                }
+            }
+            continue;
+        }
+        for (int c = t; c < PR * CPR; c += NT) {
+            const int ml = c / CPR, nc = c - ml * CPR;
+            const int m = m0 + ph * PR + ml, n = n0 + nc * 8;
+            if (m < p.M && n < p.N) {
+                const floatx4 f0 = *reinterpret_cast<const floatx4*>(Cf + ml * F_LD + nc * 8);
+                const floatx4 f1 = *reinterpret_cast<const floatx4*>(Cf + ml * F_LD + nc * 8 + 4);
+                float v[8] = {f0[0], f0[1], f0[2], f0[3], f1[0], f1[1], f1[2], f1[3]};
+                epi_chunk8(v, m, n, p.epi);
+                half8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (half_t)v[e];
+                if (p.epi.geglu == 2) {                        // backward GEGLU: o = dy (fp16-rounded like the unfused path)
+                    const int F = p.epi.geglu_f;
+                    const half_t* hrow = (const half_t*)p.epi.geglu_h + (size_t)m * 2 * F + n;
+                    const half8 a = ld8(hrow), gg = ld8(hrow + F);
+                    half8 da, dg;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float gf = (float)gg[e], df = (float)o[e];
+                        float cdf, pdf;
+                        gelu_parts(gf, cdf, pdf);
+                        da[e] = (half_t)(df * gf * cdf);
+                        dg[e] = (half_t)(df * (float)a[e] * (cdf + gf * pdf));
+                    }
+                    st8(p.C + (size_t)m * p.ldc + n, da);
+                    st8(p.C + (size_t)m * p.ldc + F + n, dg);
+                    continue;
+                }
+                if (p.epi.residual) {
+                    const half8 rr = ld8((const half_t*)p.epi.residual + (size_t)m * p.epi.ldr + n);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = (half_t)((float)o[e] + (float)rr[e]);
+                }
+                st8(p.C + (size_t)m * p.ldc + n, o);
+            }
+        }
+    }
+}
+
 // blocks per CU the LDS ring allows, capped by what the accumulators leave room for in the register file: the register
 // allocator is told to leave room for them.  (NST = 3, BK = 32: 48 / 36 / 24 KB -> 3 / 4 / 6 blocks; the deep rings for
 // grids that cannot fill a CU with blocks anyway -- 5 x 16 KB, 6 x 12 KB, 8 x 8 KB -- leave 2 blocks per CU but 2-3x the
@@ -418,11 +536,17 @@ __global__ __launch_bounds__(256, (DmaOcc<BM, BN, NST, BK>::v)) void gemm_dma_ke
             for (int i = 0; i < A_IN; ++i) {
                 const bool ok = kokq && ((a_mask[i] >> qtap) & 1u);
                 const half_t* src = ok ? p.A + (long)a_base[i] + delta : zero_page;
+#ifdef CLORA_DMA_PROBE
+                if (FLAGS & 4) src = zero_page;             // timing probe: same instruction stream, no operand traffic
+#endif
                 CLORA_GLDS16(src, As + (w * A_IN + i) * RPI * BK);
             }
 #pragma unroll
             for (int i = 0; i < B_IN; ++i) {
                 const half_t* src = (b_ok[i] && kokq) ? p.B + b_base[i] + kq + kc * 8 : zero_page;
+#ifdef CLORA_DMA_PROBE
+                if (FLAGS & 8) src = zero_page;
+#endif
                 CLORA_GLDS16(src, Bs + (w * B_IN + i) * RPI * BK);
             }
             kq += BK;
@@ -447,11 +571,17 @@ __global__ __launch_bounds__(256, (DmaOcc<BM, BN, NST, BK>::v)) void gemm_dma_ke
                         src = p.A + (a_base[i] + (size_t)(ty >> p.conv.shift) * p.conv.Win + (tx >> p.conv.shift)) * p.conv.Cin + cb + ci;
                 }
             }
+#ifdef CLORA_DMA_PROBE
+            if (FLAGS & 4) src = zero_page;
+#endif
             CLORA_GLDS16(src, As + (w * A_IN + i) * RPI * BK);
         }
 #pragma unroll
         for (int i = 0; i < B_IN; ++i) {
             const half_t* src = (b_ok[i] && kok) ? p.B + b_base[i] + k : zero_page;
+#ifdef CLORA_DMA_PROBE
+            if (FLAGS & 8) src = zero_page;
+#endif
             CLORA_GLDS16(src, Bs + (w * B_IN + i) * RPI * BK);
         }
         k += BK;
@@ -501,114 +631,180 @@ __global__ __launch_bounds__(256, (DmaOcc<BM, BN, NST, BK>::v)) void gemm_dma_ke
                 for (int j = 0; j < FN; ++j) acc[i][j] = mfma16(af[ks][i], bf[ks][j], acc[i][j]);
     }
     CLORA_WAIT_VMCNT(0);                                       // trailing zero-page stages: LDS is reused below
+    dma_epilogue<BM, BN, WM, WN, 256, SMEM>(p, acc, m0, n0, split, smem, t);
+}
 
-    if (p.partial) {
-        float* slab = p.partial + (size_t)split * p.M * p.N;
+// ------------------------------------------------------------------------------------------------
+// 3x3 / stride-1 / pad-1 convolution and its dgrad with the input staged ONCE per channel slab as a spatial patch in LDS.
+//
+// The implicit GEMM above fetches every input pixel nine times from L2 (once per filter tap); with its operand DMAs
+// redirected to a zero page the same kernel runs 32-40 % faster on the ResnetBlock convs (tools/dma_probe.py,
+// profiles/r02_dma_probe.txt): the gather traffic, not the matrix pipe, bounds it.  Here a workgroup owns BM output pixels =
+// whole image rows (or whole images at 8x8 and below) and per 64-channel slab loads the (rows+2) x (W+2) halo patch by
+// LDS-DMA once -- 1.4-2.1 x the output pixels instead of 9 x -- into a double-buffered patch; the nine taps of the slab are
+// nine k-steps whose A fragments are read from the patch at a wave-uniform pixel offset.  The weight operand streams
+// through an NST-stage ring exactly as in gemm_dma_kernel (its K order is already slab-major: clora_conv_t.kchunk = 64).
+//   patch pixel pp = (image * (rows+2) + patch_row) * (W+2) + patch_col, 128 bytes (64 channels) each; the 16-byte chunk c of
+//   pixel pp lives in slot c ^ (pp & 7): conflict-free ds_read_b128 for 16 consecutive pixels (source-side swizzle, the DMA
+//   image is lane-linear: the lane that fills slot `pos` of pixel pp fetches chunk pos ^ (pp & 7)).
+//   Out-of-image halo pixels and rows past M come from the zero page: padding costs nothing.
+// One workgroup = WM x WN waves (512 threads: the patch pair + ring take most of the CU's LDS, so the eight waves of ONE
+// block provide the two waves per SIMD).  vmcnt waits are compile-time constants: the tap loop is unrolled and every
+// wave issues the same number of DMA instructions per k-step (B_IN, plus PA_IN at tap 0; surplus ones fetch the zero page
+// into a dump slot).
+template <int BM, int BN> struct PatchCfg {
+    static constexpr int MAXPP = (BM == 256) ? 400 : 288;    // patch pixels (multiple of 8): 4x66 / 6x34 / 10x18 / nx10x10 ... see eligibility
+};
+
+template <int BM, int BN, int WM, int WN, int NST>
+__global__ __launch_bounds__(WM * WN * 64, 1) void conv3x3_patch_kernel(GemmArgs p) {
+    constexpr int NT = WM * WN * 64, NW = WM * WN, BK = 64;
+    constexpr int FM = BM / WM / 16, FN = BN / WN / 16;
+    constexpr int MAXPP = PatchCfg<BM, BN>::MAXPP;
+    constexpr int PA_IN = (MAXPP / 8 + NW - 1) / NW;           // patch DMA wave-instructions per wave per slab
+    constexpr int B_NI = BN / 8;                               // ring DMA wave-instructions per stage (8 rows x 128 B each)
+    constexpr int B_IN = (B_NI + NW - 1) / NW;                 // ... per wave (instruction ib = w + NW*i; surplus ones fetch the zero page into a dump slot)
+    constexpr int PATCH = MAXPP * 64 + 512;                    // halves per patch buffer (+ one 1-KB dump slot)
+    constexpr int BST = BN * BK + ((B_NI % NW) ? 512 : 0);     // halves per ring stage (+ dump slot when the split is uneven: BN = 160)
+    constexpr int SMEM = 2 * PATCH + NST * BST;
+    static_assert(64 * (BN + 4) * 2 <= SMEM, "epilogue staging");
+    __shared__ __attribute__((aligned(16))) half_t smem[SMEM];
+    half_t* const Pb = smem;
+    half_t* const Bring = smem + 2 * PATCH;
+
+    const int t = threadIdx.x;
+    const int tiles = gridDim.x, nwg = gridDim.x * gridDim.y;  // XCD-aware block order, as in gemm_dma_kernel
+    const int lin = blockIdx.y * gridDim.x + blockIdx.x;
+    const int xq = nwg >> 3, xr = nwg & 7, xcd = lin & 7;
+    const int logical = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (lin >> 3);
+    const int split = logical / tiles, tile = logical - split * tiles;
+    const int tile_m = tile / p.tiles_n, tile_n = tile % p.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int w = t >> 6, l = t & 63, g = l >> 4, li = l & 15;
+    const int wm = w / WN, wn = w % WN;
+    const half_t* zero_page = reinterpret_cast<const half_t*>(g_clora_zero16);
+
+    // ---- geometry of this tile
+    const int H = p.conv.Hin, W = p.conv.Win, C = p.conv.Cin, HW = H * W;
+    const int nimg = HW >= BM ? 1 : BM / HW, rpi = HW >= BM ? BM / W : H;   // images per tile, image rows per image
+    const int PW = W + 2, PRI = rpi + 2;
+    const int npp = nimg * PRI * PW;
+    const int b0 = m0 / HW, y0 = (m0 - b0 * HW) / W;
+    const int nb = p.M / HW;
+    const int slabs = C / 64;
+    const int cs_beg = split * p.k_per_split, cs_end_ = cs_beg + p.k_per_split;   // k_per_split counts SLABS here
+    const int cs_end = cs_end_ < slabs ? cs_end_ : slabs;
+
+    // ---- patch loader: instruction i = w + NW*j fills slots i*64 .. +63; slot s -> pixel s >> 3, position s & 7
+    int poff[PA_IN];                                           // element offset of this lane's 16-byte chunk at slab 0; -1: zero page
 #pragma unroll
-        for (int i = 0; i < FM; ++i)
-#pragma unroll
-            for (int j = 0; j < FN; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int m = m0 + wm * FM * 16 + i * 16 + 4 * g + r;
-                    const int n = n0 + wn * FN * 16 + j * 16 + li;
-                    if (m < p.M && n < p.N) slab[(size_t)m * p.N + n] = acc[i][j][r];
-                }
-        return;
-    }
-    // ---- epilogue: fp32 accumulators -> LDS (64 rows per pass) -> per row-chunk: bias / time-embedding / rank-r
-    // adapter update (float4 operand loads) -> fp16 -> + residual -> 16-byte coalesced stores.  Doing the fused
-    // math AFTER the LDS hop keeps it out of the main loop's register budget.
-    constexpr int PR = 64, F_LD = BN + 4, NPASS = BM / PR;
-    static_assert(PR * F_LD * 2 <= SMEM, "fp32 staging must fit in the LDS allocation");
-    float* Cf = reinterpret_cast<float*>(smem);
-    constexpr int CPR = BN / 8;
-#pragma unroll
-    for (int ph = 0; ph < NPASS; ++ph) {
-        __syncthreads();                                       // ring (or previous pass) fully consumed
-        const int wrow0 = wm * FM * 16;                        // first tile row of this wave
-#pragma unroll
-        for (int i = 0; i < FM; ++i) {
-            const int frow = wrow0 + i * 16;                   // this fragment's 16 rows lie inside one 64-row pass
-            if (frow >= ph * PR && frow < (ph + 1) * PR) {
-#pragma unroll
-                for (int j = 0; j < FN; ++j)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        Cf[(frow - ph * PR + 4 * g + r) * F_LD + wn * FN * 16 + j * 16 + li] = acc[i][j][r];
-            }
-        }
-        __syncthreads();
-        if (p.epi.geglu == 1) {
-            // forward GEGLU: tile columns come in groups of [64 a | 64 g]; one thread takes an a-chunk and its g-chunk
-            if constexpr (BN % 128 == 0) {
-                constexpr int HPR = CPR / 2;                   // a-chunks per tile row
-                const int F = p.epi.geglu_f;
-                for (int c = t; c < PR * HPR; c += 256) {
-                    const int ml = c / HPR, hc = c - ml * HPR;
-                    const int col = (hc >> 3) * 128 + (hc & 7) * 8;        // tile column of the a-chunk; g sits 64 further
-                    const int m = m0 + ph * PR + ml, n = n0 + col;
-                    if (m < p.M && n < p.N) {
-                        float va[8], vg[8];
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) { va[e] = Cf[ml * F_LD + col + e]; vg[e] = Cf[ml * F_LD + col + 64 + e]; }
-                        epi_chunk8(va, m, n, p.epi);
-                        epi_chunk8(vg, m, n + 64, p.epi);
-                        const int j = (n >> 7) * 64 + (hc & 7) * 8;       // column in the standard [a | g] layout
-                        half8 a8, g8, y8;
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            a8[e] = (half_t)va[e];
-                            g8[e] = (half_t)vg[e];
-                            y8[e] = (half_t)((float)a8[e] * gelu_f((float)g8[e]));
-                        }
-                        st8((half_t*)p.epi.geglu_y + (size_t)m * F + j, y8);
-                        if (p.C) {
-                            st8(p.C + (size_t)m * p.ldc + j, a8);
-                            st8(p.C + (size_t)m * p.ldc + F + j, g8);
-                        }
-                    }
-                }
-            }
-            continue;
-        }
-        for (int c = t; c < PR * CPR; c += 256) {
-            const int ml = c / CPR, nc = c - ml * CPR;
-            const int m = m0 + ph * PR + ml, n = n0 + nc * 8;
-            if (m < p.M && n < p.N) {
-                const floatx4 f0 = *reinterpret_cast<const floatx4*>(Cf + ml * F_LD + nc * 8);
-                const floatx4 f1 = *reinterpret_cast<const floatx4*>(Cf + ml * F_LD + nc * 8 + 4);
-                float v[8] = {f0[0], f0[1], f0[2], f0[3], f1[0], f1[1], f1[2], f1[3]};
-                epi_chunk8(v, m, n, p.epi);
-                half8 o;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = (half_t)v[e];
-                if (p.epi.geglu == 2) {                        // backward GEGLU: o = dy (fp16-rounded like the unfused path)
-                    const int F = p.epi.geglu_f;
-                    const half_t* hrow = (const half_t*)p.epi.geglu_h + (size_t)m * 2 * F + n;
-                    const half8 a = ld8(hrow), gg = ld8(hrow + F);
-                    half8 da, dg;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const float gf = (float)gg[e], df = (float)o[e];
-                        float cdf, pdf;
-                        gelu_parts(gf, cdf, pdf);
-                        da[e] = (half_t)(df * gf * cdf);
-                        dg[e] = (half_t)(df * (float)a[e] * (cdf + gf * pdf));
-                    }
-                    st8(p.C + (size_t)m * p.ldc + n, da);
-                    st8(p.C + (size_t)m * p.ldc + F + n, dg);
-                    continue;
-                }
-                if (p.epi.residual) {
-                    const half8 rr = ld8((const half_t*)p.epi.residual + (size_t)m * p.epi.ldr + n);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) o[e] = (half_t)((float)o[e] + (float)rr[e]);
-                }
-                st8(p.C + (size_t)m * p.ldc + n, o);
-            }
+    for (int j = 0; j < PA_IN; ++j) {
+        const int sl = (w + NW * j) * 64 + l, pp = sl >> 3, pos = sl & 7;
+        poff[j] = -1;
+        if (pp < npp) {
+            const int img = pp / (PRI * PW), rem = pp - img * (PRI * PW);
+            const int pr = rem / PW, pc = rem - pr * PW;
+            const int y = y0 - 1 + pr, x = pc - 1, b = b0 + img;
+            if (b < nb && y >= 0 && y < H && x >= 0 && x < W) poff[j] = ((b * H + y) * W + x) * C + ((pos ^ (pp & 7)) * 8);
         }
     }
+    auto issue_patch = [&](int cs, int buf) {
+        half_t* dst = Pb + buf * PATCH;
+        const bool live = cs < cs_end;
+#pragma unroll
+        for (int j = 0; j < PA_IN; ++j) {
+            const int i = w + NW * j;
+            const half_t* src = (live && poff[j] >= 0) ? p.A + poff[j] + cs * 64 : zero_page;
+            CLORA_GLDS16(src, (i * 8 < MAXPP) ? dst + i * 512 : dst + MAXPP * 64);   // surplus instructions land in the dump slot
+        }
+    };
+    // ---- ring loader (rows of the [N, K] weight operand, 128-byte rows, key r & 7): instruction ib = w + NW*i fills rows ib*8..+8
+    const int lrow = l >> 3, bpos = l & 7, kc = bpos ^ (lrow & 7);
+    bool b_ok[B_IN];
+    size_t b_base[B_IN];
+#pragma unroll
+    for (int i = 0; i < B_IN; ++i) {
+        const int ib = w + NW * i, n = n0 + ib * 8 + lrow;
+        b_ok[i] = ib < B_NI && n < p.N;
+        b_base[i] = (size_t)n * p.K + kc * 8;
+    }
+    const int kbeg = cs_beg * 576, kend = cs_end * 576;
+    int kq = kbeg;
+    auto issue_b = [&](int buf) {
+        half_t* Bs = Bring + buf * BST;
+        const bool kok = kq < kend;
+#pragma unroll
+        for (int i = 0; i < B_IN; ++i) {
+            const int ib = w + NW * i;
+            const half_t* src = (b_ok[i] && kok) ? p.B + b_base[i] + kq : zero_page;
+            CLORA_GLDS16(src, Bs + (ib < B_NI ? ib * 8 * BK : BN * BK));
+        }
+        kq += BK;
+    };
+
+    // ---- fragment addressing
+    int pp0[FM];                                               // patch pixel of (output pixel, tap offset 0,0) per A fragment
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        const int ml = wm * FM * 16 + i * 16 + li;
+        const int img = ml / (rpi * W), rem = ml - img * (rpi * W);
+        const int yl = rem / W, x = rem - yl * W;
+        pp0[i] = (img * PRI + yl) * PW + x;
+    }
+    int bsw[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) bsw[ks] = ((ks * 4 + g) ^ (li & 7)) * 8;
+    const int toff0 = 1 + p.conv.off, tmul = p.conv.kmul;      // patch row/col of tap (ky,kx): local + toff0 + k*tmul
+
+    floatx4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = zero4f();
+
+    issue_patch(cs_beg, 0);
+#pragma unroll
+    for (int st = 0; st < NST - 1; ++st) issue_b(st);
+    int rd = 0, wr = NST - 1;
+    for (int cs = cs_beg; cs < cs_end; ++cs) {
+        const half_t* P = Pb + ((cs - cs_beg) & 1) * PATCH;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            // loads younger than ring stage kt: stages kt+1 .. kt+NST-2, plus the patch issued at tap 0 of this slab (an
+            // iteration ago for tap 1, ..., NST-1 iterations ago for tap NST-1: it was issued AFTER stage kt+NST-1-tap)
+            if (tap >= 1 && tap <= NST - 1) CLORA_WAIT_VMCNT((NST - 2) * B_IN + PA_IN);
+            else CLORA_WAIT_VMCNT((NST - 2) * B_IN);
+            CLORA_RAW_BARRIER();
+            issue_b(wr);
+            wr = (wr + 1 == NST) ? 0 : wr + 1;
+            if (tap == 0) issue_patch(cs + 1, ((cs - cs_beg) & 1) ^ 1);      // consumed through tap 8 of the previous slab: free
+            const half_t* Bs = Bring + rd * BST;
+            rd = (rd + 1 == NST) ? 0 : rd + 1;
+            const int ky = tap / 3, kx = tap - ky * 3;
+            const int tapoff = (toff0 + ky * tmul) * PW + (toff0 + kx * tmul);
+            half8 af[2][FM], bf[2][FN];
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                const int pp = pp0[i] + tapoff;
+                const half_t* q = P + pp * 64;
+                const int k7 = pp & 7;
+                af[0][i] = ld8(q + ((g ^ k7) * 8));
+                af[1][i] = ld8(q + (((4 + g) ^ k7) * 8));
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) bf[ks][j] = ld8(Bs + (wn * FN * 16 + j * 16 + li) * BK + bsw[ks]);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) acc[i][j] = mfma16(af[ks][i], bf[ks][j], acc[i][j]);
+        }
+    }
+    CLORA_WAIT_VMCNT(0);
+    dma_epilogue<BM, BN, WM, WN, NT, SMEM>(p, acc, m0, n0, split, smem, t);
 }
 
 __global__ __launch_bounds__(256) void splitk_finish_kernel(GemmArgs p, int splits) {
@@ -853,6 +1049,27 @@ int launch_gemm(GemmArgs& a, int splits, hipStream_t s, bool dma) {
     return clora_check_launch();
 }
 
+// conv3x3_patch_kernel: what it can take (everything else stays on gemm_dma_kernel)
+bool patch_eligible(const GemmArgs& a, int bm) {
+    const clora_conv_t& c = a.conv;
+    if (!c.enabled || c.ksize != 3 || c.mul != 1 || c.shift != 0 || c.need_even != 0 || c.kchunk != 64 || (c.Cin % 64)) return false;
+    if (!((c.kmul == 1 && c.off == -1) || (c.kmul == -1 && c.off == 1))) return false;        // forward pad 1 / its dgrad
+    if (c.Hout != c.Hin || c.Wout != c.Win || c.lim_h != c.Hin || c.lim_w != c.Win) return false;
+    const int W = c.Win, HW = c.Hin * c.Win;
+    if (W <= 0 || bm % W || (a.M % HW) || (long)a.M * c.Cin >= (1L << 31)) return false;
+    if (!((HW % bm) == 0 || (bm % HW) == 0)) return false;                                     // whole rows of one image, or whole images
+    const int nimg = HW >= bm ? 1 : bm / HW, rpi = HW >= bm ? bm / W : c.Hin;
+    return nimg * (rpi + 2) * (W + 2) <= (bm == 256 ? 400 : 288);
+}
+
+template <int BM, int BN, int WM, int WN, int NST>
+int launch_patch(GemmArgs& a, int splits, hipStream_t s) {
+    a.tiles_n = clora_cdiv(a.N, BN);
+    const dim3 grid(clora_cdiv(a.M, BM) * a.tiles_n, splits);
+    hipLaunchKernelGGL((conv3x3_patch_kernel<BM, BN, WM, WN, NST>), grid, dim3(WM * WN * 64), 0, s, a);
+    return clora_check_launch();
+}
+
 }  // namespace
 
 // ---- launch planning --------------------------------------------------------------------------------
@@ -935,12 +1152,60 @@ extern "C" int clora_gemm_f16_ex(const clora_half* A, int lda, const clora_half*
     bool dma = true;
     if (tile_cfg >= 11 && tile_cfg <= 13) { dma = false; tile_cfg -= 10; }
     int cfg = tile_cfg > 0 ? tile_cfg : tile + 1;
+    // untuned shape (no table entry: tile_cfg == 0) that the patch-staged conv kernel can take: it beat every implicit-GEMM
+    // variant on all 46 tuned signatures (profiles/r02_tune_patch.log), so it is the default there too -- 128-pixel tiles, 160
+    // columns when the width allows, split over slabs until the grid covers the chip (split_k == 0) or as forced
+    if (tile_cfg == 0 && dma && !a.epi.geglu && patch_eligible(a, 128)) {
+        cfg = (N % 160 == 0) ? 76 : 72;
+        if (split_k == 0) {
+            const long blocks = (long)clora_cdiv(M, 128) * clora_cdiv(N, cfg == 76 ? 160 : 128);
+            const int slabs = a.conv.Cin / 64;
+            int want = (int)((256 + blocks - 1) / blocks);
+            if (want > slabs) want = slabs;
+            while (want > 1 && (!workspace || workspace_bytes < (size_t)want * M * N * sizeof(float))) --want;
+            splits = want < 1 ? 1 : want;
+        }
+    }
     if (a.epi.geglu) {
         if (!dma) return CLORA_ERR_ARG;
         const bool wide = cfg == 1 || cfg == 4 || cfg == 7 || cfg == 8 || cfg == 9 || cfg == 21 || cfg == 31 || cfg == 41;
         if (a.epi.geglu == 1 && !wide) { if (tile_cfg > 0) return CLORA_ERR_ARG; cfg = 1; }
     }
-    const int bk = ((cfg >= 21 && cfg <= 26) || (cfg >= 41 && cfg <= 43)) ? 64 : 32;
+    //   71..76 = conv3x3_patch_kernel (3x3 stride-1 pad-1 convs and their dgrads, input patch staged once per 64-channel slab):
+    //            256x128 (8 waves of 64x64), 128x128 (64x32), 128x128 (32x64), 256x64 (32x64), 128x64 (32x32), 128x160 (32x80: the
+    //            UNet widths 320 / 640 / 960 / 1280 are multiples of 160, not of 128); shapes it cannot take fall back to 21
+    if (cfg >= 71 && cfg <= 76) {
+        if (!dma || !patch_eligible(a, (cfg == 71 || cfg == 74) ? 256 : 128)) cfg = 21;
+        else {
+            const int slabs = a.conv.Cin / 64;
+            if (splits > slabs) splits = slabs;
+            a.k_per_split = clora_cdiv(slabs, splits);                 // SLABS per split for this kernel
+            splits = clora_cdiv(slabs, a.k_per_split);
+            if (splits > 1) {
+                if (!workspace || workspace_bytes < (size_t)splits * M * N * sizeof(float)) return CLORA_ERR_WORKSPACE;
+                a.partial = (float*)workspace;
+            }
+            int rc;
+            switch (cfg) {
+                case 71: rc = launch_patch<256, 128, 4, 2, 3>(a, splits, s); break;
+                case 72: rc = launch_patch<128, 128, 2, 4, 3>(a, splits, s); break;
+                case 73: rc = launch_patch<128, 128, 4, 2, 3>(a, splits, s); break;
+                case 74: rc = launch_patch<256, 64, 8, 1, 4>(a, splits, s); break;
+                case 75: rc = launch_patch<128, 64, 4, 2, 4>(a, splits, s); break;
+                default: rc = launch_patch<128, 160, 4, 2, 3>(a, splits, s); break;
+            }
+            if (rc != CLORA_OK) return rc;
+            if (splits > 1) {
+                const size_t chunks = (size_t)M * (N / 8);
+                int blocks = (int)((chunks + 255) / 256);
+                if (blocks > 2048) blocks = 2048;
+                hipLaunchKernelGGL(splitk_finish_kernel, dim3(blocks), dim3(256), 0, s, a, splits);
+                rc = clora_check_launch();
+            }
+            return rc;
+        }
+    }
+    const int bk = ((cfg >= 21 && cfg <= 26) || (cfg >= 41 && cfg <= 43) || (cfg >= 91 && cfg <= 96)) ? 64 : 32;
     a.k_per_split = clora_cdiv(clora_cdiv(K, bk), splits) * bk;
     splits = clora_cdiv(K, a.k_per_split);
     if (splits > 1) {
@@ -965,6 +1230,16 @@ extern "C" int clora_gemm_f16_ex(const clora_half* A, int lda, const clora_half*
         case 32: rc = launch_gemm<128, 64, 4, 1, 3, 32, 1>(a, splits, s, true); break;
         case 33: rc = launch_gemm<64, 64, 2, 2, 3, 32, 1>(a, splits, s, true); break;
         case 9: rc = launch_gemm<128, 128, 2, 2, 3, 32, 2>(a, splits, s, true); break;     // round-1 swizzle key (A/B)
+#ifdef CLORA_DMA_PROBE
+        // timing probes (results are garbage): the A and / or B tiles are fetched from the 16-byte zero page -- the same DMA
+        // instruction stream with no L2 -> LDS operand traffic.  Built only by tools/dma_probe.sh.
+        case 91: rc = launch_gemm<128, 128, 2, 2, 2, 64, 4>(a, splits, s, true); break;
+        case 92: rc = launch_gemm<128, 128, 2, 2, 2, 64, 8>(a, splits, s, true); break;
+        case 93: rc = launch_gemm<128, 128, 2, 2, 2, 64, 12>(a, splits, s, true); break;
+        case 94: rc = launch_gemm<128, 64, 4, 1, 2, 64, 4>(a, splits, s, true); break;
+        case 95: rc = launch_gemm<128, 64, 4, 1, 2, 64, 8>(a, splits, s, true); break;
+        case 96: rc = launch_gemm<128, 64, 4, 1, 2, 64, 12>(a, splits, s, true); break;
+#endif
         case 41: rc = launch_gemm<128, 128, 2, 2, 2, 64, 1>(a, splits, s, true); break;
         case 42: rc = launch_gemm<128, 64, 4, 1, 3, 64, 1>(a, splits, s, true); break;
         case 43: rc = launch_gemm<64, 64, 2, 2, 3, 64, 1>(a, splits, s, true); break;
@@ -979,6 +1254,13 @@ extern "C" int clora_gemm_f16_ex(const clora_half* A, int lda, const clora_half*
         rc = clora_check_launch();
     }
     return rc;
+}
+
+extern "C" int clora_conv_patch_eligible(int M, const clora_conv_t* conv, int tile_cfg) {
+    if (!conv || tile_cfg < 71 || tile_cfg > 76) return 0;
+    GemmArgs a;
+    a.M = M; a.conv = *conv;
+    return patch_eligible(a, (tile_cfg == 71 || tile_cfg == 74) ? 256 : 128) ? 1 : 0;
 }
 
 extern "C" int clora_gemm_f16(const clora_half* A, int lda, const clora_half* B, clora_half* C, int ldc, int M, int N,

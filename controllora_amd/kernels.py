@@ -185,6 +185,14 @@ def gemm(A: torch.Tensor, Bw: torch.Tensor, M: int, N: int, K: int, *, lda: Opti
     return C_
 
 
+PATCH_TILE_CFGS = (71, 72, 73, 74, 75, 76)     # conv3x3_patch_kernel variants of clora_gemm_f16_ex
+
+
+def conv_patch_eligible(M: int, conv: ConvDesc, tile_cfg: int) -> bool:
+    """would `gemm(..., conv=conv, tile_cfg=tile_cfg)` run on the patch-staged 3x3 kernel (True) or fall back (False)?"""
+    return bool(capi.lib().cdll.clora_conv_patch_eligible(M, C.byref(conv), tile_cfg))
+
+
 def conv_wgrad(dY: torch.Tensor, X: torch.Tensor, M: int, N: int, K: int, conv: Optional[ConvDesc],
                ldx: Optional[int] = None, with_bias: bool = False):
     """dW [N, K] (and the bias gradient [N] when with_bias) of a trainable conv / linear, one pass over dY and X."""

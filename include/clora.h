@@ -96,6 +96,11 @@ int clora_gemm_f16_ex(const clora_half* A, int lda, const clora_half* B, clora_h
                       int M, int N, int K, const clora_conv_t* conv, const clora_epilogue_t* epi,
                       int split_k, int tile_cfg, void* workspace, size_t workspace_bytes, void* stream);
 
+/* 1 when clora_gemm_f16_ex(..., tile_cfg) would run `conv` (M output pixels) on the patch-staged 3x3 kernel (tile_cfg 71..76:
+ * stride 1, pad 1, kchunk 64, whole image rows per tile), 0 when it would fall back to the implicit-GEMM main loop.  The
+ * reference op is the same F.conv2d of upstream ResnetBlock2D; tuner / tests use this to know what they time. */
+int clora_conv_patch_eligible(int M, const clora_conv_t* conv, int tile_cfg);
+
 /* dW[N, K] += dY[M,N]^T . gather(X)[M,K] and (db != NULL) db[N] += column sums of dY  (fp32 atomics; caller
  * zeroes dW / db).
  * Weight gradient of the trainable hint-encoder convolutions (reference models.py:470,529,594-597,684:

@@ -105,6 +105,41 @@ def case_conv(dev, Bn, H, W, Ci, Co, stride=1, pad=1, ups=False, asym=False, see
             assert float(stage.abs().max()) == 0.0
 
 
+def case_conv_patch(dev, Bn, H, W, Ci, Co, tile_cfg, seed=12):
+    """conv3x3_patch_kernel (tile_cfg 71..75): forward and dgrad of a stride-1 pad-1 conv with the slab-major K order,
+    split-K 1..3, bias + residual epilogue, against F.conv2d autograd -- and the shape must really take the patch path."""
+    from controllora_amd.ops import conv_k_order
+    g = torch.Generator().manual_seed(seed)
+    x = rnd((Bn, Ci, H, W), dev, g)
+    w = rnd((Co, Ci, 3, 3), dev, g, 1 / math.sqrt(Ci * 9))
+    xin = x.float().clone().requires_grad_(True)
+    w32 = w.float().clone().requires_grad_(True)
+    y = F.conv2d(xin, w32, padding=1)
+    dy = rnd((Bn, Co, H, W), dev, g)
+    y.backward(dy.float())
+    M = Bn * H * W
+    xn = x.permute(0, 2, 3, 1).contiguous().reshape(M, Ci)
+    wp = conv_k_order(w.permute(0, 2, 3, 1).contiguous().reshape(Co, 9, Ci), 64)
+    cd, _, _ = K.conv_fwd_desc(H, W, Ci, 3, 1, 1, kchunk=64)
+    assert K.conv_patch_eligible(M, cd, tile_cfg), "shape does not take the patch kernel"
+    yref = y.detach().permute(0, 2, 3, 1).reshape(M, Co)
+    bias = rnd((Co,), dev, g, dtype=f32)
+    res = rnd((M, Co), dev, g)
+    for sk in (1, 2, 3):
+        out = K.gemm(xn, wp, M, Co, 9 * Ci, conv=cd, tile_cfg=tile_cfg, split_k=sk)
+        assert rel(out, yref) < 6e-4, (sk, rel(out, yref))
+    out = K.gemm(xn, wp, M, Co, 9 * Ci, conv=cd, tile_cfg=tile_cfg, split_k=1, bias=bias, residual=res)
+    assert rel(out, yref.float().cpu() + bias.float().cpu() + res.float().cpu()) < 6e-4
+    if Co % 64 == 0:
+        wd = conv_k_order(w.permute(1, 2, 3, 0).contiguous().reshape(Ci, 9, Co), 64)
+        dyn = dy.permute(0, 2, 3, 1).contiguous().reshape(M, Co)
+        cdd = K.conv_dgrad_desc(H, W, Co, H, W, 3, 1, 1, kchunk=64)
+        assert K.conv_patch_eligible(M, cdd, tile_cfg)
+        for sk in (1, 2):
+            dx = K.gemm(dyn, wd, M, Ci, 9 * Co, conv=cdd, tile_cfg=tile_cfg, split_k=sk)
+            assert rel(dx, xin.grad.permute(0, 2, 3, 1).reshape(M, Ci)) < 6e-4, (sk,)
+
+
 def case_conv_padded_channels(dev, seed=9):
     """3 -> padded 8 input channels (the hint encoder's conv_in): packing pads with zeros, the OIHW gradient drops them"""
     g = torch.Generator().manual_seed(seed)

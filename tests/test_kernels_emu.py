@@ -45,6 +45,20 @@ def test_gemm_tile_configs(tile):
     KC.case_conv("cpu", 1, 8, 8, 16, 24, tile_cfg=tile)
 
 
+@pytest.mark.parametrize("tile", [71, 72, 73, 74, 75, 76])
+@pytest.mark.parametrize("Bn,H,W,Ci,Co", [(2, 8, 8, 128, 64), (1, 16, 16, 64, 72), (3, 4, 4, 64, 64)])
+def test_conv_patch_kernel(tile, Bn, H, W, Ci, Co):
+    """patch-staged 3x3 conv: whole images per tile (8x8, 4x4: tiles straddle the batch, rows past M), whole rows (16x16)"""
+    if tile in (71, 74) and W == 4:
+        pytest.skip("16 images of 4x4 exceed the 256-pixel tile's patch budget (falls back by design)")
+    KC.case_conv_patch("cpu", Bn, H, W, Ci, Co, tile)
+
+
+def test_conv_patch_kernel_wide_rows():
+    KC.case_conv_patch("cpu", 1, 32, 32, 64, 64, 71)
+    KC.case_conv_patch("cpu", 1, 64, 64, 64, 64, 73)
+
+
 @pytest.mark.parametrize("B,H,Nq,Nk,D,fused", [(1, 2, 70, 70, 40, True), (2, 2, 64, 77, 40, False), (1, 2, 33, 130, 80, False),
                                                (1, 1, 40, 40, 160, True), (1, 2, 20, 20, 8, False), (1, 1, 150, 77, 64, False),
                                                (1, 2, 640, 77, 40, False)])

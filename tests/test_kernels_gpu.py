@@ -54,6 +54,14 @@ def test_gemm_tile_configs(tile):
     KC.case_conv(DEV, 1, 32, 32, 320, 320, tile_cfg=tile)          # Cin % 64 == 0: the BK = 64 variants take the fast tap walk
 
 
+@pytest.mark.parametrize("tile", [71, 72, 73, 74, 75, 76])
+@pytest.mark.parametrize("Bn,H,W,Ci,Co", [(4, 64, 64, 320, 320), (4, 32, 32, 640, 640), (2, 16, 16, 1280, 640), (4, 8, 8, 1280, 1280),
+                                          (1, 32, 32, 320, 320), (3, 8, 8, 128, 72)])
+def test_conv_patch_kernel(tile, Bn, H, W, Ci, Co):
+    """patch-staged 3x3 conv at the ResnetBlock2D shapes of every UNet level (forward, dgrad, split-K, fused epilogue)"""
+    KC.case_conv_patch(DEV, Bn, H, W, Ci, Co, tile)
+
+
 @pytest.mark.parametrize("B,H,Nq,Nk,D,fused", [
     (1, 8, 4096, 4096, 40, True), (2, 8, 4096, 77, 40, False), (2, 8, 1024, 1024, 80, True), (2, 8, 1024, 77, 80, False),
     (2, 8, 256, 256, 160, True), (2, 8, 64, 77, 160, False), (1, 2, 70, 70, 40, True), (1, 1, 150, 77, 64, False),

@@ -17,6 +17,9 @@ ap.add_argument("--res", type=int, default=512)
 ap.add_argument("--infer-batch", type=int, default=32, help="0 = skip the inference forward")
 ap.add_argument("--config", default="fill50k.json")
 ap.add_argument("--merge", action="store_true", help="keep the entries already in the table and add / refresh the measured ones")
+ap.add_argument("--cfgs", default="", help="comma list of tile_cfg values to sweep instead of the full set (with --merge the current "
+                "table entry of a signature is timed too and only replaced by a faster candidate)")
+ap.add_argument("--patch-only", action="store_true", help="only the signatures the patch-staged 3x3 conv kernel can take (tile_cfg 71..75)")
 args = ap.parse_args()
 dev = torch.device("cuda", 0)
 unet, clora = bench.build_models(dev, config=args.config)
@@ -65,7 +68,9 @@ def timeit(fn, iters=10, warm=2):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / (2 * iters) * 1e3
 
-CFGS = [1, 2, 3, 4, 5, 6, 7, 8, 21, 22, 23, 26, 31, 32, 33, 41, 42, 43]
+CFGS = [1, 2, 3, 4, 5, 6, 7, 8, 21, 22, 23, 26, 31, 32, 33, 41, 42, 43, 71, 72, 73, 74, 75]
+if args.cfgs:
+    CFGS = [int(c) for c in args.cfgs.split(",")]
 path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "controllora_amd", "gemm_tuning_gfx950.json")
 table = json.load(open(path))["table"] if (args.merge and os.path.exists(path)) else {}
 tot_auto = tot_best = tot_r01 = 0.0
@@ -80,16 +85,27 @@ for (M, N, Kd, ck), cnt in sorted(seen.items(), key=lambda kv: -kv[0][0] * kv[0]
     res_ = torch.randn(M, N, device=dev).half()
     best, err = None, None
     run = lambda sk, tile: K.gemm(A, Bw, M, N, Kd, conv=conv, out=out, residual=res_, split_k=sk, tile_cfg=tile, _tuned=False)
+    if args.patch_only and not (conv is not None and any(K.conv_patch_eligible(M, conv, c) for c in K.PATCH_TILE_CFGS)):
+        del A, Bw, out, res_
+        continue
     auto = timeit(lambda: run(0, 0))
     iters = 10 if auto < 300 else 4
+    cur = table.get(K.tuning_key(M, N, Kd, conv))
+    if args.cfgs and cur is not None:                      # the incumbent defends its entry
+        best = (timeit(lambda: run(cur[1], cur[0]), iters=iters), cur[0], cur[1])
+        auto = best[0]
     r01 = None
     geglu_sig = (M, N, Kd, ck) in wide_only
     for tile in CFGS:
         if geglu_sig and tile not in K.WIDE_TILE_CFGS:
             continue
+        if tile in K.PATCH_TILE_CFGS and not (conv is not None and K.conv_patch_eligible(M, conv, tile)):
+            continue                                       # would only re-time the fallback
         prev = None
         for sk in (1, 2, 3, 4, 6, 8, 12, 16):
             if sk > 1 and (geglu_sig or (Kd // 32) // sk < 4 or sk * M * N * 4 > K.GEMM_WS_BYTES or M * N > 16384 * 1280):
+                break
+            if tile in K.PATCH_TILE_CFGS and sk > conv.Cin // 64:
                 break
             try:
                 us = timeit(lambda: run(sk, tile), iters=iters)
