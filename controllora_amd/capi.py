@@ -43,7 +43,8 @@ class LoraDownJob(C.Structure):
     """mirror of clora_lora_down_job_t"""
     _fields_ = [("X", C.c_void_p), ("ldx", C.c_int), ("D", C.c_void_p), ("ldd", C.c_int), ("T", C.c_void_p), ("ldt", C.c_int),
                 ("toff", C.c_int), ("M", C.c_int), ("K", C.c_int), ("R", C.c_int), ("accumulate", C.c_int), ("x_rows", C.c_int),
-                ("d_kmajor", C.c_int), ("d_scale", C.c_float), ("X2", C.c_void_p), ("ldx2", C.c_int), ("x2_rows", C.c_int)]
+                ("d_kmajor", C.c_int), ("d_scale", C.c_float), ("X2", C.c_void_p), ("ldx2", C.c_int), ("x2_rows", C.c_int),
+                ("r2", C.c_int)]
 
 
 class LoraUpJob(C.Structure):

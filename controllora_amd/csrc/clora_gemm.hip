@@ -685,7 +685,8 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void conv3x3_patch_kernel(GemmArgs
     const half_t* zero_page = reinterpret_cast<const half_t*>(g_clora_zero16);
 
     // ---- geometry of this tile
-    const int H = p.conv.Hin, W = p.conv.Win, C = p.conv.Cin, HW = H * W;
+    // (nearest-2x upsampled convs: the tile / patch live at the OUTPUT resolution and the loader reads source pixel (y>>1, x>>1))
+    const int H = p.conv.Hout, W = p.conv.Wout, C = p.conv.Cin, HW = H * W, sh = p.conv.shift;
     const int nimg = HW >= BM ? 1 : BM / HW, rpi = HW >= BM ? BM / W : H;   // images per tile, image rows per image
     const int PW = W + 2, PRI = rpi + 2;
     const int npp = nimg * PRI * PW;
@@ -705,7 +706,8 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void conv3x3_patch_kernel(GemmArgs
             const int img = pp / (PRI * PW), rem = pp - img * (PRI * PW);
             const int pr = rem / PW, pc = rem - pr * PW;
             const int y = y0 - 1 + pr, x = pc - 1, b = b0 + img;
-            if (b < nb && y >= 0 && y < H && x >= 0 && x < W) poff[j] = ((b * H + y) * W + x) * C + ((pos ^ (pp & 7)) * 8);
+            if (b < nb && y >= 0 && y < H && x >= 0 && x < W)
+                poff[j] = ((b * p.conv.Hin + (y >> sh)) * p.conv.Win + (x >> sh)) * C + ((pos ^ (pp & 7)) * 8);
         }
     }
     auto issue_patch = [&](int cs, int buf) {
@@ -1052,13 +1054,18 @@ int launch_gemm(GemmArgs& a, int splits, hipStream_t s, bool dma) {
 // conv3x3_patch_kernel: what it can take (everything else stays on gemm_dma_kernel)
 bool patch_eligible(const GemmArgs& a, int bm) {
     const clora_conv_t& c = a.conv;
-    if (!c.enabled || c.ksize != 3 || c.mul != 1 || c.shift != 0 || c.need_even != 0 || c.kchunk != 64 || (c.Cin % 64)) return false;
-    if (!((c.kmul == 1 && c.off == -1) || (c.kmul == -1 && c.off == 1))) return false;        // forward pad 1 / its dgrad
-    if (c.Hout != c.Hin || c.Wout != c.Win || c.lim_h != c.Hin || c.lim_w != c.Win) return false;
-    const int W = c.Win, HW = c.Hin * c.Win;
+    if (!c.enabled || c.ksize != 3 || c.mul != 1 || c.need_even != 0 || c.kchunk != 64 || (c.Cin % 64)) return false;
+    if (c.shift == 0) {
+        if (!((c.kmul == 1 && c.off == -1) || (c.kmul == -1 && c.off == 1))) return false;    // forward pad 1 / its dgrad
+        if (c.Hout != c.Hin || c.Wout != c.Win || c.lim_h != c.Hin || c.lim_w != c.Win) return false;
+    } else {                                                                                   // forward of conv(nearest-2x(x)), pad 1
+        if (c.shift != 1 || c.kmul != 1 || c.off != -1 || c.Hout != 2 * c.Hin || c.Wout != 2 * c.Win || c.lim_h != c.Hout || c.lim_w != c.Wout)
+            return false;
+    }
+    const int W = c.Wout, HW = c.Hout * c.Wout;
     if (W <= 0 || bm % W || (a.M % HW) || (long)a.M * c.Cin >= (1L << 31)) return false;
     if (!((HW % bm) == 0 || (bm % HW) == 0)) return false;                                     // whole rows of one image, or whole images
-    const int nimg = HW >= bm ? 1 : bm / HW, rpi = HW >= bm ? bm / W : c.Hin;
+    const int nimg = HW >= bm ? 1 : bm / HW, rpi = HW >= bm ? bm / W : c.Hout;
     return nimg * (rpi + 2) * (W + 2) <= (bm == 256 ? 400 : 288);
 }
 

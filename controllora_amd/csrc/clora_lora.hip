@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void lora_down_kernel(DownJobs jobs) {
     const int m = m0 + li;
     const bool mok = m < M;
     size_t xoff = (size_t)(mok ? (p.x_rows > 0 ? m % p.x_rows : m) : 0) * ldx;
-    const bool jok = li < R;
+    bool jok = li < R;
     const int jj = jok ? li : 0;
     const int d_kmajor = p.d_kmajor;
     const float dscale = p.d_scale;
@@ -55,7 +55,10 @@ __global__ __launch_bounds__(256) void lora_down_kernel(DownJobs jobs) {
     constexpr int G = 4;                                   // k-steps in flight
     const int npass = p.X2 ? 2 : 1;                        // second input: (X + X2) . D^T by linearity, same accumulator
     for (int pass = 0; pass < npass; ++pass) {
-    if (pass == 1) { X = (const half_t*)p.X2; xoff = (size_t)(mok ? (p.x2_rows > 0 ? m % p.x2_rows : m) : 0) * p.ldx2; }
+    if (pass == 1) {
+        X = (const half_t*)p.X2; xoff = (size_t)(mok ? (p.x2_rows > 0 ? m % p.x2_rows : m) : 0) * p.ldx2;
+        if (p.r2 > 0) jok = li < p.r2;                      // stacked adapters: the second input feeds the first r2 rows of D only
+    }
     for (int k0 = kbeg; k0 < kend; k0 += 32 * G) {
         half8 a[G];
         floatx4 d0[G], d1[G];
@@ -107,7 +110,7 @@ __global__ __launch_bounds__(256) void lora_down_kernel(DownJobs jobs) {
         }
     }
     // C layout: lane holds T[m0 + 4g + r][toff + li]
-    if (jok) {
+    if (li < R) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int mm = m0 + 4 * g + r;
@@ -339,7 +342,7 @@ extern "C" int clora_lora_down_f16(const clora_half* X, int ldx, const float* D,
         clora_lora_down_job_t j;
         j.X = X; j.ldx = ldx; j.D = d_kmajor ? D + r0 : (D ? D + (size_t)r0 * ldd : D); j.ldd = ldd; j.T = T; j.ldt = ldt;
         j.toff = toff + r0; j.M = M; j.K = K; j.R = (R - r0 < 16) ? R - r0 : 16; j.accumulate = accumulate;
-        j.x_rows = x_rows; j.d_kmajor = d_kmajor; j.d_scale = d_scale; j.X2 = nullptr; j.ldx2 = 0; j.x2_rows = 0;
+        j.x_rows = x_rows; j.d_kmajor = d_kmajor; j.d_scale = d_scale; j.X2 = nullptr; j.ldx2 = 0; j.x2_rows = 0; j.r2 = 0;
         const int rc = clora_lora_down_multi_f16(&j, 1, stream);
         if (rc != CLORA_OK) return rc;
     }

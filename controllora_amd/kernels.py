@@ -348,13 +348,14 @@ def lora_down(X, D, T, toff, M, K, accumulate=False, x_rows=0, ldx=None, kmajor=
     return T
 
 
-def down_job(X, D, T, toff, M, K, accumulate=False, x_rows=0, ldx=None, kmajor=False, R=None, d_scale=1.0, X2=None, x2_rows=0):
-    """one problem of lora_down_multi (same arguments as lora_down; rank <= 16); X2: second input, T = (X + X2) . D^T"""
+def down_job(X, D, T, toff, M, K, accumulate=False, x_rows=0, ldx=None, kmajor=False, R=None, d_scale=1.0, X2=None, x2_rows=0, r2=0):
+    """one problem of lora_down_multi (same arguments as lora_down; rank <= 16); X2: second input, T = (X + X2) . D^T;
+    r2 > 0: X2 feeds only the first r2 rows of D (several adapters sharing X stacked into this one job)"""
     assert D.dtype == f32 and D.stride(1) == 1 and T.dtype == f32 and T.stride(1) == 1
     rank = R if R is not None else (D.shape[1] if kmajor else D.shape[0])
     return capi.LoraDownJob(ptr(X, f16), ldx if ldx is not None else X.stride(0), ptr(D), D.stride(0), ptr(T), T.stride(0), toff,
                             M, K, rank, int(accumulate), x_rows, int(kmajor), float(d_scale),
-                            ptr(X2, f16) if X2 is not None else None, X2.stride(0) if X2 is not None else 0, x2_rows)
+                            ptr(X2, f16) if X2 is not None else None, X2.stride(0) if X2 is not None else 0, x2_rows, int(r2))
 
 
 def up_job(base, T, toff, U, Y, M, N, scale, u_tr=False):

@@ -398,6 +398,49 @@ def _stack_rows(ts):
     return torch.cat(ts, 0)
 
 
+MERGE_DOWNS = _os.environ.get("CLORA_MERGE_DOWNS", "1") != "0"      # "0": one job per adapter (A/B runs)
+_STACKED_D = {}     # inference-only cache of row-stacked down matrices (the trainer's flat buffer makes them adjacent views)
+
+
+def _merge_down_jobs(specs):
+    """Adapters of one projection that read the SAME input (q|k|v of a self-attention site, k|v of the text projection) become
+    one job over the row-stacked down matrix [D_q; D_k; D_v] (<= 16 rows: one MFMA column tile): x is streamed once instead
+    of once per adapter.  Only the first adapter of a group may carry a second input (the control term of the q adapter,
+    reference models.py:237-238): the job's r2 limits that pass to its rows."""
+    out = []
+    for j in specs:
+        a = out[-1] if (out and MERGE_DOWNS) else None
+        if (a is not None and j["X2"] is None and j["X"] is a["X"] and a["toff"] + a["R"] == j["toff"] and a["R"] + j["R"] <= 16
+                and j["D"].shape[1] == a["D"].shape[1] and j["D"].is_contiguous() and a["D"].is_contiguous()):
+            parts = a.setdefault("parts", [a["D"]]) + [j["D"]]
+            stacked = None
+            if _adjacent(parts):                                       # the trainer's flat buffer: a zero-copy view
+                stacked = _stack_rows(parts)
+            elif not torch.is_grad_enabled():                          # inference on separate tensors: stack once, keep
+                key = tuple((t.data_ptr(), t._version) for t in parts)
+                stacked = _STACKED_D.get(key)
+                if stacked is None:
+                    if len(_STACKED_D) > 4096:
+                        _STACKED_D.clear()
+                    stacked = _STACKED_D[key] = torch.cat(parts, 0)
+            if stacked is not None:
+                if a["X2"] is not None and a["r2"] == 0:
+                    a["r2"] = a["R"]
+                a["parts"], a["D"], a["R"] = parts, stacked, a["R"] + j["R"]
+                continue
+        out.append(dict(j))
+    return out
+
+
+def _adjacent(ts):
+    ptr = ts[0].data_ptr()
+    for t in ts:
+        if t.data_ptr() != ptr or t.untyped_storage().data_ptr() != ts[0].untyped_storage().data_ptr():
+            return False
+        ptr += t.numel() * t.element_size()
+    return True
+
+
 class _LoraProjFn(torch.autograd.Function):
     """y = x W^T (+b) (+residual) + scale_s * up_s(down_s(xa_s)) on column segment s.
 
@@ -418,7 +461,7 @@ class _LoraProjFn(torch.autograd.Function):
         r = max(ranks + [1])
         full = all(m is not None for m in meta) and all(rk == r for rk in ranks)
         T = (torch.empty if full else torch.zeros)((M, S * r), dtype=f32, device=x.device)
-        pieces, pi, info, djobs = [], 0, [], []
+        pieces, pi, info, dspecs = [], 0, [], []
         for s, m in enumerate(meta):
             if m is None:
                 pieces.append(torch.zeros((seg_w, r), dtype=f32, device=x.device))
@@ -431,8 +474,8 @@ class _LoraProjFn(torch.autograd.Function):
             assert len(xis) <= 2
             if rs <= 16:                              # both inputs of a summed adapter input go through ONE job
                 x2 = xas[xis[1]] if len(xis) > 1 else None          # may hold fewer rows (control batch 1 broadcast, quirk C6)
-                djobs.append(K.down_job(xas[xis[0]], D.detach(), T, s * r, M, D.shape[1], X2=x2,
-                                        x2_rows=x2.shape[0] if (x2 is not None and x2.shape[0] != M) else 0))
+                dspecs.append(dict(X=xas[xis[0]], D=D.detach(), toff=s * r, R=rs, X2=x2, r2=0,
+                                   x2_rows=x2.shape[0] if (x2 is not None and x2.shape[0] != M) else 0))
             else:
                 for n_in, xi in enumerate(xis):       # separate launches: stream order makes the accumulation safe
                     K.lora_down(xas[xi], D.detach(), T, s * r, M, D.shape[1], accumulate=n_in > 0)
@@ -441,8 +484,9 @@ class _LoraProjFn(torch.autograd.Function):
                 u = torch.cat([u, u.new_zeros(seg_w, r - rs)], 1)
             pieces.append(u)
             info.append((xis, sc, rs))
-        if djobs:
-            K.lora_down_multi(djobs)                  # every adapter down-projection of this GEMM in one launch
+        if dspecs:                                    # every adapter down-projection of this GEMM in one launch,
+            K.lora_down_multi([K.down_job(j["X"], j["D"], T, j["toff"], M, j["D"].shape[1], X2=j["X2"], x2_rows=j["x2_rows"],
+                                          R=j["R"], r2=j["r2"]) for j in _merge_down_jobs(dspecs)])   # adapters sharing x in one pass
         U = _stack_rows(pieces)
         y = K.gemm(x, pack.w, M, pack.N, pack.K, bias=pack.bias, residual=residual, lora_t=T, lora_u=U,
                    lora_seg=seg_w, lora_scale=1.0)

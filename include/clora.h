@@ -186,6 +186,9 @@ typedef struct {
     int M, K, R, accumulate, x_rows, d_kmajor; float d_scale;
     const clora_half* X2; int ldx2;   /* optional second input [M, K]: T = (X + X2) . D^T without forming the sum */
     int x2_rows;                      /* > 0: X2 has only x2_rows rows, row m reads X2[m % x2_rows] (control batch 1, quirk C6) */
+    int r2;                           /* > 0: X2 only feeds rows 0..r2-1 of D -- several adapters that share X stacked into ONE job
+                                       * (D = [D_q; D_k; D_v], one pass over X) while only the first of them also reads X2
+                                       * (reference models.py:237-238: the control term enters the q adapter only); 0 = all R rows */
 } clora_lora_down_job_t;
 typedef struct {
     const clora_half* A; int lda; const float* T; int ldt; int toff; float* G; int gs_n, gs_j;

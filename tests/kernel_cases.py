@@ -105,6 +105,24 @@ def case_conv(dev, Bn, H, W, Ci, Co, stride=1, pad=1, ups=False, asym=False, see
             assert float(stage.abs().max()) == 0.0
 
 
+def case_conv_patch_upsampled(dev, Bn, H, W, Ci, Co, tile_cfg, seed=13):
+    """conv3x3_patch_kernel on conv(nearest-2x(x)) (Upsample2D): the patch lives at the output resolution"""
+    from controllora_amd.ops import conv_k_order
+    g = torch.Generator().manual_seed(seed)
+    x = rnd((Bn, Ci, H, W), dev, g)
+    w = rnd((Co, Ci, 3, 3), dev, g, 1 / math.sqrt(Ci * 9))
+    y = F.conv2d(F.interpolate(x.float(), scale_factor=2.0, mode="nearest"), w.float(), padding=1)
+    M = Bn * 4 * H * W
+    xn = x.permute(0, 2, 3, 1).contiguous().reshape(Bn * H * W, Ci)
+    wp = conv_k_order(w.permute(0, 2, 3, 1).contiguous().reshape(Co, 9, Ci), 64)
+    cd, Ho, Wo = K.conv_fwd_desc(H, W, Ci, 3, 1, 1, upsample=True, kchunk=64)
+    assert (Ho, Wo) == (2 * H, 2 * W) and K.conv_patch_eligible(M, cd, tile_cfg)
+    yref = y.permute(0, 2, 3, 1).reshape(M, Co)
+    for sk in (1, 2):
+        out = K.gemm(xn, wp, M, Co, 9 * Ci, conv=cd, tile_cfg=tile_cfg, split_k=sk)
+        assert rel(out, yref) < 6e-4, (sk, rel(out, yref))
+
+
 def case_conv_patch(dev, Bn, H, W, Ci, Co, tile_cfg, seed=12):
     """conv3x3_patch_kernel (tile_cfg 71..75): forward and dgrad of a stride-1 pad-1 conv with the slab-major K order,
     split-K 1..3, bias + residual epilogue, against F.conv2d autograd -- and the shape must really take the patch path."""

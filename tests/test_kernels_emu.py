@@ -54,6 +54,12 @@ def test_conv_patch_kernel(tile, Bn, H, W, Ci, Co):
     KC.case_conv_patch("cpu", Bn, H, W, Ci, Co, tile)
 
 
+@pytest.mark.parametrize("tile", [71, 72, 76])
+def test_conv_patch_kernel_upsampled(tile):
+    KC.case_conv_patch_upsampled("cpu", 2, 8, 8, 128, 72, tile)
+    KC.case_conv_patch_upsampled("cpu", 1, 4, 4, 64, 64, tile)
+
+
 def test_conv_patch_kernel_wide_rows():
     KC.case_conv_patch("cpu", 1, 32, 32, 64, 64, 71)
     KC.case_conv_patch("cpu", 1, 64, 64, 64, 64, 73)

@@ -62,6 +62,12 @@ def test_conv_patch_kernel(tile, Bn, H, W, Ci, Co):
     KC.case_conv_patch(DEV, Bn, H, W, Ci, Co, tile)
 
 
+@pytest.mark.parametrize("tile", [71, 72, 76])
+@pytest.mark.parametrize("Bn,H,Ci", [(2, 32, 640), (2, 16, 1280), (1, 8, 1280)])
+def test_conv_patch_kernel_upsampled(tile, Bn, H, Ci):
+    KC.case_conv_patch_upsampled(DEV, Bn, H, H, Ci, Ci, tile)
+
+
 @pytest.mark.parametrize("B,H,Nq,Nk,D,fused", [
     (1, 8, 4096, 4096, 40, True), (2, 8, 4096, 77, 40, False), (2, 8, 1024, 1024, 80, True), (2, 8, 1024, 77, 80, False),
     (2, 8, 256, 256, 160, True), (2, 8, 64, 77, 160, False), (1, 2, 70, 70, 40, True), (1, 1, 150, 77, 64, False),
