@@ -292,7 +292,7 @@ __device__ __attribute__((aligned(16))) const unsigned g_clora_zero16[4] = {0u, 
 // Epilogue shared by the LDS-DMA main loops (gemm_dma_kernel, conv3x3_patch_kernel): split-K slab, or fp32 accumulators ->
 // LDS (64 rows per pass) -> per row-chunk: bias / time-embedding / rank-r adapter update (float4 operand loads) -> fp16 ->
 // + residual (or the fused GEGLU forms) -> 16-byte coalesced stores.  NT threads = WM x WN waves, wave tile FM x FN MFMA tiles.
-template <int BM, int BN, int WM, int WN, int NT, int SMEM>
+template <int BM, int BN, int WM, int WN, int NT, int SMEM, bool HOIST = false>
 __device__ __forceinline__ void dma_epilogue(const GemmArgs& p, floatx4 (&acc)[BM / WM / 16][BN / WN / 16], int m0, int n0, int split,
                                              half_t* smem, int t) {
     constexpr int FM = BM / WM / 16, FN = BN / WN / 16;
@@ -319,6 +319,31 @@ __device__ __forceinline__ void dma_epilogue(const GemmArgs& p, floatx4 (&acc)[B
     static_assert(PR * F_LD * 2 <= SMEM, "fp32 staging must fit in the LDS allocation");
     float* Cf = reinterpret_cast<float*>(smem);
     constexpr int CPR = BN / 8;
+    constexpr int RPIT = NT / CPR;                             // rows one sweep of the block covers (threads past RPIT*CPR idle: BN = 160 / 320)
+    static_assert(RPIT >= 1, "tile wider than the block");
+    const int nc = t % CPR, n = n0 + nc * 8;
+    // rank-4 adapter in the epilogue (every attention projection): the 32 up-matrix values and the bias of this thread's 8 columns
+    // live in registers for the whole tile -- per output chunk only the 16-byte T row is fetched.  (Fetching U per chunk made the
+    // epilogue's L1 traffic as long as a 5-step main loop: 8 x 16-byte loads per chunk.)
+    // HOIST: only the kernels built for <= 2 blocks per CU have the 40 registers to spare (the others spilled accumulators: measured
+    // +0.6 ms per train step), and a thread must own >= 4 output chunks for the hoist to amortise (2 on the 64x64 tile)
+    constexpr bool HOIST_PAYS = HOIST && (BM * CPR / NT) >= 4 && (BM / WM / 16) * (BN / WN / 16) * 4 < 128;
+    const bool hoist = HOIST_PAYS && p.epi.lora_t != nullptr && p.epi.lora_r == 4 && p.epi.geglu == 0 && n < p.N &&
+                       ((p.epi.ldt | ((n / p.epi.lora_seg) * 4)) & 3) == 0 && (p.epi.lora_u_tr ? (p.epi.ldu & 3) == 0 : p.epi.ldu == 4);
+    floatx4 ureg[8];
+    float bias8[8];
+    int utoff = 0;
+    if (hoist) {
+        utoff = (n / p.epi.lora_seg) * 4;
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            ureg[q] = p.epi.lora_u_tr ? *reinterpret_cast<const floatx4*>(p.epi.lora_u + (size_t)(q >> 1) * p.epi.ldu + n + (q & 1) * 4)
+                                      : *reinterpret_cast<const floatx4*>(p.epi.lora_u + (size_t)(n + q) * 4);
+        floatx4 b0 = zero4f(), b1 = zero4f();
+        if (p.epi.bias) { b0 = *reinterpret_cast<const floatx4*>(p.epi.bias + n); b1 = *reinterpret_cast<const floatx4*>(p.epi.bias + n + 4); }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { bias8[e] = b0[e]; bias8[4 + e] = b1[e]; }
+    }
 #pragma unroll
     for (int ph = 0; ph < NPASS; ++ph) {
         __syncthreads();                                       // ring (or previous pass) fully consumed
@@ -368,14 +393,37 @@ __device__ __forceinline__ void dma_epilogue(const GemmArgs& p, floatx4 (&acc)[B
             }
             continue;
         }
-        for (int c = t; c < PR * CPR; c += NT) {
-            const int ml = c / CPR, nc = c - ml * CPR;
-            const int m = m0 + ph * PR + ml, n = n0 + nc * 8;
+        // one 8-column chunk of one staged row: bias / time embedding / adapter update -> fp16 -> + residual (or GEGLU') -> store
+        auto chunk = [&](int ml, int nc, int n) {
+            const int m = m0 + ph * PR + ml;
             if (m < p.M && n < p.N) {
                 const floatx4 f0 = *reinterpret_cast<const floatx4*>(Cf + ml * F_LD + nc * 8);
                 const floatx4 f1 = *reinterpret_cast<const floatx4*>(Cf + ml * F_LD + nc * 8 + 4);
                 float v[8] = {f0[0], f0[1], f0[2], f0[3], f1[0], f1[1], f1[2], f1[3]};
-                epi_chunk8(v, m, n, p.epi);
+                if (hoist) {
+                    if (p.epi.bias) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += bias8[e];
+                    }
+                    if (p.epi.rowadd) {
+                        const half8 ra = ld8((const half_t*)p.epi.rowadd + (size_t)(m / p.epi.rows_per_batch) * p.epi.ld_rowadd + n);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += (float)ra[e];
+                    }
+                    floatx4 t4 = *reinterpret_cast<const floatx4*>(p.epi.lora_t + (size_t)m * p.epi.ldt + utoff);
+                    t4 *= p.epi.lora_scale;
+                    if (p.epi.lora_u_tr) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[e] += t4[j] * ureg[2 * j + (e >> 2)][e & 3];
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += t4[0] * ureg[e][0] + t4[1] * ureg[e][1] + t4[2] * ureg[e][2] + t4[3] * ureg[e][3];
+                    }
+                } else {
+                    epi_chunk8(v, m, n, p.epi);
+                }
                 half8 o;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o[e] = (half_t)v[e];
@@ -394,7 +442,7 @@ __device__ __forceinline__ void dma_epilogue(const GemmArgs& p, floatx4 (&acc)[B
                     }
                     st8(p.C + (size_t)m * p.ldc + n, da);
                     st8(p.C + (size_t)m * p.ldc + F + n, dg);
-                    continue;
+                    return;
                 }
                 if (p.epi.residual) {
                     const half8 rr = ld8((const half_t*)p.epi.residual + (size_t)m * p.epi.ldr + n);
@@ -402,6 +450,15 @@ __device__ __forceinline__ void dma_epilogue(const GemmArgs& p, floatx4 (&acc)[B
                     for (int e = 0; e < 8; ++e) o[e] = (half_t)((float)o[e] + (float)rr[e]);
                 }
                 st8(p.C + (size_t)m * p.ldc + n, o);
+            }
+        };
+        if constexpr (HOIST_PAYS) {
+            // thread -> one fixed chunk column, rows ml = t / CPR + it * RPIT: what depends on the column only is already in registers
+            for (int ml = t / CPR; ml < PR && t < RPIT * CPR; ml += RPIT) chunk(ml, nc, n);
+        } else {
+            for (int c = t; c < PR * CPR; c += NT) {
+                const int ml = c / CPR, ncc = c - ml * CPR;
+                chunk(ml, ncc, n0 + ncc * 8);
             }
         }
     }
@@ -411,10 +468,10 @@ __device__ __forceinline__ void dma_epilogue(const GemmArgs& p, floatx4 (&acc)[B
 // allocator is told to leave room for them.  (NST = 3, BK = 32: 48 / 36 / 24 KB -> 3 / 4 / 6 blocks; the deep rings for
 // grids that cannot fill a CU with blocks anyway -- 5 x 16 KB, 6 x 12 KB, 8 x 8 KB -- leave 2 blocks per CU but 2-3x the
 // bytes in flight per block; the 256x128 tile holds 128 accumulator registers per lane -> 2 blocks.)
-template <int BM, int BN, int NST, int BK> struct DmaOcc {
+template <int BM, int BN, int NST, int BK, int NW = 4> struct DmaOcc {
     static constexpr int lds = NST * (BM + BN) * BK * 2;
     static constexpr int fit = (160 * 1024) / lds;
-    static constexpr int cap = (BM * BN >= 256 * 128) ? 2 : ((BM * BN >= 128 * 128) ? 3 : ((BM * BN >= 128 * 64) ? 4 : 5));   // 64x64 at 6 would spill (80 VGPRs)
+    static constexpr int cap = NW > 4 ? 1 : ((BM * BN >= 256 * 128) ? 2 : ((BM * BN >= 128 * 128) ? 3 : ((BM * BN >= 128 * 64) ? 4 : 5)));   // 64x64 at 6 would spill (80 VGPRs)
     static constexpr int v = fit < 1 ? 1 : (fit < cap ? fit : cap);
 };
 
@@ -438,14 +495,16 @@ template <int BM, int BN, int NST, int BK> struct DmaOcc {
 // SQ_LDS_BANK_CONFLICT = half of SQ_LDS_IDX_ACTIVE with it, 0 with the default key (-(r >> 2)) & 3
 // (profiles/r02_pmc_gemm_variants.md, tools/lds_bank_check.py).
 template <int BM, int BN, int WM, int WN, int NST, int CONV, int BK = 32, int FLAGS = 0>
-__global__ __launch_bounds__(256, (DmaOcc<BM, BN, NST, BK>::v)) void gemm_dma_kernel(GemmArgs p) {
+__global__ __launch_bounds__(WM * WN * 64, (DmaOcc<BM, BN, NST, BK, WM * WN>::v)) void gemm_dma_kernel(GemmArgs p) {
+    constexpr int NW = WM * WN, NT = NW * 64;                // 4 waves, or 8 for the wide tiles (128x320, 64x320, 128x256: one block per CU)
     constexpr int ORD = FLAGS & 1;
     constexpr bool ALTKEY = (FLAGS & 2) == 0;
     constexpr int FM = BM / WM / 16, FN = BN / WN / 16;
     constexpr int CH = BK / 8;                              // 16-byte chunks per LDS row
     constexpr int RPI = 64 / CH;                            // rows one DMA wave-instruction fills (16 or 8)
     constexpr int KS = BK / 32;                             // MFMA k-substeps per stage
-    constexpr int A_IN = BM / RPI / 4, B_IN = BN / RPI / 4; // DMA wave-instructions per stage per wave
+    constexpr int A_IN = BM / RPI / NW, B_IN = BN / RPI / NW; // DMA wave-instructions per stage per wave
+    static_assert(BM % (RPI * NW) == 0 && BN % (RPI * NW) == 0, "tile rows must split evenly over the waves' DMA instructions");
     constexpr int STAGE = (BM + BN) * BK;                   // halves
     constexpr int SMEM_RING = NST * STAGE;
     constexpr int SMEM_EPI = 64 * (BN + 4) * 2;             // fp32 staging of 64 output rows, in halves
@@ -631,7 +690,7 @@ __global__ __launch_bounds__(256, (DmaOcc<BM, BN, NST, BK>::v)) void gemm_dma_ke
                 for (int j = 0; j < FN; ++j) acc[i][j] = mfma16(af[ks][i], bf[ks][j], acc[i][j]);
     }
     CLORA_WAIT_VMCNT(0);                                       // trailing zero-page stages: LDS is reused below
-    dma_epilogue<BM, BN, WM, WN, 256, SMEM>(p, acc, m0, n0, split, smem, t);
+    dma_epilogue<BM, BN, WM, WN, NT, SMEM, (DmaOcc<BM, BN, NST, BK, NW>::v <= 2)>(p, acc, m0, n0, split, smem, t);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1043,9 +1102,9 @@ int launch_gemm(GemmArgs& a, int splits, hipStream_t s, bool dma) {
     const dim3 grid(tiles_m * a.tiles_n, splits);
     if (dma) {
         const int cm = conv_mode(a, BK);
-        if (cm == 0) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, WM, WN, NST, 0, BK, FLAGS>), grid, dim3(256), 0, s, a);
-        else if (cm == 1) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, WM, WN, NST, 1, BK, FLAGS>), grid, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, WM, WN, NST, 2, BK, FLAGS>), grid, dim3(256), 0, s, a);
+        if (cm == 0) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, WM, WN, NST, 0, BK, FLAGS>), grid, dim3(WM * WN * 64), 0, s, a);
+        else if (cm == 1) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, WM, WN, NST, 1, BK, FLAGS>), grid, dim3(WM * WN * 64), 0, s, a);
+        else hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, WM, WN, NST, 2, BK, FLAGS>), grid, dim3(WM * WN * 64), 0, s, a);
     }
     else hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN>), dim3(tiles_m * a.tiles_n, splits), dim3(256), 0, s, a);
     return clora_check_launch();
@@ -1156,6 +1215,9 @@ extern "C" int clora_gemm_f16_ex(const clora_half* A, int lda, const clora_half*
     //   9 = 1 with the round-1 (2-way conflicted) swizzle key, for A/B runs
     //   21, 22, 23, 26 = BK 64 (128-byte LDS rows, whole-line DMA): 128x128 x2 stages, 128x64 x3, 64x64 x3, 128x64 x2
     //   31..33 = 1..3 and 41..43 = 21..23 with fragment reads before the ring refill
+    //   51..53 = 8-wave blocks (one per CU), BK 64: 128x320 x2 stages, 64x320 x3, 128x256 x3 (wave tiles 32x160 / 32x80 / 32x128) for the
+    //            short-K projections -- with the whole of N = 320 in one tile A is fetched once instead of once per 64 / 128 columns;
+    //            54..56 = the same with fragment reads before the ring refill
     bool dma = true;
     if (tile_cfg >= 11 && tile_cfg <= 13) { dma = false; tile_cfg -= 10; }
     int cfg = tile_cfg > 0 ? tile_cfg : tile + 1;
@@ -1175,7 +1237,7 @@ extern "C" int clora_gemm_f16_ex(const clora_half* A, int lda, const clora_half*
     }
     if (a.epi.geglu) {
         if (!dma) return CLORA_ERR_ARG;
-        const bool wide = cfg == 1 || cfg == 4 || cfg == 7 || cfg == 8 || cfg == 9 || cfg == 21 || cfg == 31 || cfg == 41;
+        const bool wide = cfg == 1 || cfg == 4 || cfg == 7 || cfg == 8 || cfg == 9 || cfg == 21 || cfg == 31 || cfg == 41 || cfg == 53 || cfg == 56;
         if (a.epi.geglu == 1 && !wide) { if (tile_cfg > 0) return CLORA_ERR_ARG; cfg = 1; }
     }
     //   71..76 = conv3x3_patch_kernel (3x3 stride-1 pad-1 convs and their dgrads, input patch staged once per 64-channel slab):
@@ -1212,7 +1274,7 @@ extern "C" int clora_gemm_f16_ex(const clora_half* A, int lda, const clora_half*
             return rc;
         }
     }
-    const int bk = ((cfg >= 21 && cfg <= 26) || (cfg >= 41 && cfg <= 43) || (cfg >= 91 && cfg <= 96)) ? 64 : 32;
+    const int bk = ((cfg >= 21 && cfg <= 26) || (cfg >= 41 && cfg <= 43) || (cfg >= 51 && cfg <= 56) || (cfg >= 91 && cfg <= 96)) ? 64 : 32;
     a.k_per_split = clora_cdiv(clora_cdiv(K, bk), splits) * bk;
     splits = clora_cdiv(K, a.k_per_split);
     if (splits > 1) {
@@ -1237,6 +1299,12 @@ extern "C" int clora_gemm_f16_ex(const clora_half* A, int lda, const clora_half*
         case 32: rc = launch_gemm<128, 64, 4, 1, 3, 32, 1>(a, splits, s, true); break;
         case 33: rc = launch_gemm<64, 64, 2, 2, 3, 32, 1>(a, splits, s, true); break;
         case 9: rc = launch_gemm<128, 128, 2, 2, 3, 32, 2>(a, splits, s, true); break;     // round-1 swizzle key (A/B)
+        case 51: rc = launch_gemm<128, 320, 4, 2, 2, 64, 0>(a, splits, s, true); break;    // 8 waves, the whole of N = 320 per tile: A crosses L2 -> LDS once
+        case 52: rc = launch_gemm<64, 320, 2, 4, 3, 64, 0>(a, splits, s, true); break;
+        case 53: rc = launch_gemm<128, 256, 4, 2, 3, 64, 0>(a, splits, s, true); break;
+        case 54: rc = launch_gemm<128, 320, 4, 2, 2, 64, 1>(a, splits, s, true); break;
+        case 55: rc = launch_gemm<64, 320, 2, 4, 3, 64, 1>(a, splits, s, true); break;
+        case 56: rc = launch_gemm<128, 256, 4, 2, 3, 64, 1>(a, splits, s, true); break;
 #ifdef CLORA_DMA_PROBE
         // timing probes (results are garbage): the A and / or B tiles are fetched from the 16-byte zero page -- the same DMA
         // instruction stream with no L2 -> LDS operand traffic.  Built only by tools/dma_probe.sh.

@@ -33,7 +33,7 @@ def test_conv_small_channels():
     KC.case_conv("cpu", 1, 16, 16, 8, 32)       # hint-encoder conv_in shape class (3 -> padded 8 channels)
 
 
-ALL_TILE_CFGS = [1, 2, 3, 4, 5, 6, 7, 8, 9, 21, 22, 23, 26, 31, 32, 33, 41, 42, 43]
+ALL_TILE_CFGS = [1, 2, 3, 4, 5, 6, 7, 8, 9, 21, 22, 23, 26, 31, 32, 33, 41, 42, 43, 51, 52, 53, 54, 55, 56]
 
 
 @pytest.mark.parametrize("tile", ALL_TILE_CFGS)
@@ -116,7 +116,7 @@ def test_conv_padded_channels_pack_and_oihw_grad():
     KC.case_conv_padded_channels("cpu")
 
 
-@pytest.mark.parametrize("tile", [1, 3, 5, 7, 9, 21, 23, 26, 42, 33])
+@pytest.mark.parametrize("tile", [1, 3, 5, 7, 9, 21, 23, 26, 42, 33, 51, 52, 56])
 def test_conv_fast_path_uniform_taps(tile):
     """3x3 stride-1 convs with Cin % 32 == 0 take the wave-uniform tap walk (CONV == 2) in forward and dgrad"""
     KC.case_conv("cpu", 1, 6, 5, 32, 64, tile_cfg=tile)
@@ -125,7 +125,7 @@ def test_conv_fast_path_uniform_taps(tile):
         KC.case_conv("cpu", 1, 6, 6, 32, 32, tile_cfg=tile, **kw)
 
 
-@pytest.mark.parametrize("tile", [0, 1, 7, 21, 41])
+@pytest.mark.parametrize("tile", [0, 1, 7, 21, 41, 53, 56])
 def test_feed_forward_fused_geglu(tile):
     KC.case_feed_forward_fused("cpu", M=150, C=32, tile_cfg=tile)
     KC.case_feed_forward_fused("cpu", M=70, C=64, tile_cfg=tile)

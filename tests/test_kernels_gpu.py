@@ -41,7 +41,7 @@ def test_conv_small_channels():
     KC.case_conv(DEV, 1, 64, 64, 8, 32)
 
 
-ALL_TILE_CFGS = [1, 2, 3, 4, 5, 6, 7, 8, 9, 21, 22, 23, 26, 31, 32, 33, 41, 42, 43]
+ALL_TILE_CFGS = [1, 2, 3, 4, 5, 6, 7, 8, 9, 21, 22, 23, 26, 31, 32, 33, 41, 42, 43, 51, 52, 53, 54, 55, 56]
 
 
 @pytest.mark.parametrize("tile", ALL_TILE_CFGS)
@@ -130,7 +130,7 @@ def test_conv_fast_path_variants(kw):
     KC.case_conv(DEV, 1, 32, 32, 320, 320, **kw)
 
 
-@pytest.mark.parametrize("tile", [0, 1, 7, 8, 21, 31, 41])
+@pytest.mark.parametrize("tile", [0, 1, 7, 8, 21, 31, 41, 53, 56])
 def test_feed_forward_fused_geglu(tile):
     KC.case_feed_forward_fused(DEV, M=1000, C=320, tile_cfg=tile)
     KC.case_feed_forward_fused(DEV, M=300, C=1280, tile_cfg=tile)

@@ -19,6 +19,7 @@ ap.add_argument("--config", default="fill50k.json")
 ap.add_argument("--merge", action="store_true", help="keep the entries already in the table and add / refresh the measured ones")
 ap.add_argument("--cfgs", default="", help="comma list of tile_cfg values to sweep instead of the full set (with --merge the current "
                 "table entry of a signature is timed too and only replaced by a faster candidate)")
+ap.add_argument("--plain-only", action="store_true", help="only the plain (non-conv) GEMM signatures")
 ap.add_argument("--patch-only", action="store_true", help="only the signatures the patch-staged 3x3 conv kernel can take (tile_cfg 71..75)")
 args = ap.parse_args()
 dev = torch.device("cuda", 0)
@@ -29,6 +30,7 @@ noisy = DDPMScheduler().add_noise(batch["latents"], batch["noise"], batch["times
 
 # 1) record every distinct GEMM signature of a train step (+ the inference forward at the DDIM batch)
 seen = {}
+epis = {}            # signature -> {epilogue shape: count}: each signature is timed with its most frequent epilogue
 orig = K.gemm
 wide_only = set()           # signatures used with the GEGLU-forward epilogue: tiles must be >= 128 columns wide
 def rec(A, Bw, M, N, Kd, **kw):
@@ -36,6 +38,13 @@ def rec(A, Bw, M, N, Kd, **kw):
     ck = tuple(getattr(conv, f) for f, _ in ConvDesc._fields_) if conv is not None else None
     seen.setdefault((M, N, Kd, ck), 0)
     seen[(M, N, Kd, ck)] += 1
+    lt, lu = kw.get("lora_t"), kw.get("lora_u")
+    epi = (lt is not None, bool(kw.get("lora_u_tr")), int(kw.get("lora_seg") or 0),
+           (kw.get("lora_r") or ((lu.shape[0] if kw.get("lora_u_tr") else lu.shape[1]) if lu is not None else 0)),
+           (lt.shape[1] if lt is not None else 0), kw.get("bias") is not None, kw.get("rowadd") is not None,
+           int(kw.get("rows_per_batch") or 0), kw.get("residual") is not None)
+    epis.setdefault((M, N, Kd, ck), {}).setdefault(epi, 0)
+    epis[(M, N, Kd, ck)][epi] += 1
     if kw.get("geglu") == 1:
         wide_only.add((M, N, Kd, ck))
     return orig(A, Bw, M, N, Kd, **kw)
@@ -68,7 +77,7 @@ def timeit(fn, iters=10, warm=2):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / (2 * iters) * 1e3
 
-CFGS = [1, 2, 3, 4, 5, 6, 7, 8, 21, 22, 23, 26, 31, 32, 33, 41, 42, 43, 71, 72, 73, 74, 75]
+CFGS = [1, 2, 3, 4, 5, 6, 7, 8, 21, 22, 23, 26, 31, 32, 33, 41, 42, 43, 51, 52, 53, 54, 55, 56, 71, 72, 73, 74, 75, 76]
 if args.cfgs:
     CFGS = [int(c) for c in args.cfgs.split(",")]
 path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "controllora_amd", "gemm_tuning_gfx950.json")
@@ -84,8 +93,18 @@ for (M, N, Kd, ck), cnt in sorted(seen.items(), key=lambda kv: -kv[0][0] * kv[0]
     out = torch.empty(M, N, device=dev, dtype=torch.float16)
     res_ = torch.randn(M, N, device=dev).half()
     best, err = None, None
-    run = lambda sk, tile: K.gemm(A, Bw, M, N, Kd, conv=conv, out=out, residual=res_, split_k=sk, tile_cfg=tile, _tuned=False)
-    if args.patch_only and not (conv is not None and any(K.conv_patch_eligible(M, conv, c) for c in K.PATCH_TILE_CFGS)):
+    has_lora, u_tr, lseg, lr, tcols, has_bias, has_rowadd, rpb, has_res = max(epis[(M, N, Kd, ck)].items(), key=lambda kv: kv[1])[0]
+    ekw = dict(residual=res_ if has_res else None)
+    if has_bias:
+        ekw["bias"] = torch.randn(N, device=dev)
+    if has_rowadd and rpb > 0:
+        ekw.update(rowadd=torch.randn((M + rpb - 1) // rpb, N, device=dev).half(), rows_per_batch=rpb)
+    if has_lora:                                               # the adapter epilogue of the attention projections
+        ekw.update(lora_t=torch.randn(M, max(tcols, lr), device=dev), lora_seg=lseg, lora_u_tr=u_tr, lora_r=lr,
+                   lora_u=(torch.randn(max(1, tcols), Kd if False else N, device=dev) if u_tr else torch.randn(N, lr, device=dev)))
+    run = lambda sk, tile: K.gemm(A, Bw, M, N, Kd, conv=conv, out=out, split_k=sk, tile_cfg=tile, _tuned=False, **ekw)
+    if (args.patch_only and not (conv is not None and any(K.conv_patch_eligible(M, conv, c) for c in K.PATCH_TILE_CFGS))) or \
+            (args.plain_only and conv is not None):
         del A, Bw, out, res_
         continue
     auto = timeit(lambda: run(0, 0))
