@@ -568,14 +568,12 @@ __global__ __launch_bounds__(256, (DP <= 64 ? 2 : 1)) void attn_bwd_dkv_kernel(A
             for (int dt = 0; dt < DT; ++dt) {
                 const int d = dt * 16 + 4 * g;
                 if (d < D) {
-                    if (p.nsplit > 1) {
+                    if (p.nsplit > 1) {                    // this split's own fp32 slab (plain 16-byte stores: no atomics, deterministic)
                         const size_t o = ((size_t)b * p.Nk + key) * (p.H * D) + h * D + d;
                         const size_t plane = (size_t)p.B * p.Nk * p.H * D;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            atomicAdd(p.acc32 + o + r, dkacc[dt][kg][r] * p.scale);
-                            atomicAdd(p.acc32 + plane + o + r, dvacc[dt][kg][r]);
-                        }
+                        float* dst = p.acc32 + (size_t)blockIdx.z * 2 * plane + o;
+                        *reinterpret_cast<floatx4*>(dst) = dkacc[dt][kg] * p.scale;
+                        *reinterpret_cast<floatx4*>(dst + plane) = dvacc[dt][kg];
                     } else {
                         half4v ok_, ov;
 #pragma unroll
@@ -589,15 +587,21 @@ __global__ __launch_bounds__(256, (DP <= 64 ? 2 : 1)) void attn_bwd_dkv_kernel(A
     }
 }
 
-// split path epilogue: fp32 accumulators -> fp16 dk / dv (row-strided)
+// split path epilogue: fold the per-split fp32 slabs [nsplit][dk | dv][B, Nk, H*D] (fixed order) -> fp16 dk / dv (row-strided).
+// (Round 1 combined the splits with fp32 atomics into one zeroed buffer: 3 M atomics on 0.2 M addresses made the cross-attention
+// dK/dV launch 87 us at N = 4096 -- profiles/r02_attn_trace_by_grid.txt.)
 __global__ __launch_bounds__(256) void attn_dkv_convert_kernel(AttnArgs p) {
     const int HD = p.H * p.D;
     const size_t rows = (size_t)p.B * p.Nk, total = rows * (HD / 4), plane = rows * HD;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const size_t row = i / (HD / 4);
         const int c = (int)(i - row * (HD / 4)) * 4;
-        const floatx4 a = *reinterpret_cast<const floatx4*>(p.acc32 + row * HD + c);
-        const floatx4 bb = *reinterpret_cast<const floatx4*>(p.acc32 + plane + row * HD + c);
+        floatx4 a = zero4f(), bb = zero4f();
+        for (int z = 0; z < p.nsplit; ++z) {
+            const float* q = p.acc32 + (size_t)z * 2 * plane + row * HD + c;
+            a += *reinterpret_cast<const floatx4*>(q);
+            bb += *reinterpret_cast<const floatx4*>(q + plane);
+        }
         half4v ka, va;
 #pragma unroll
         for (int r = 0; r < 4; ++r) { ka[r] = (half_t)a[r]; va[r] = (half_t)bb[r]; }
@@ -680,12 +684,12 @@ extern "C" int clora_attn_bwd_f16(const clora_half* q, int ldq, const clora_half
     if (kv_blocks < 256 && Nq >= 512) {
         int ns = (int)(512 / kv_blocks);
         if (ns > Nq / 128) ns = Nq / 128;
-        const size_t need = (size_t)2 * B * Nk * H * D * sizeof(float);
-        if (ns > 1 && workspace && workspace_bytes >= need) {
+        const size_t slab = (size_t)2 * B * Nk * H * D * sizeof(float);             // one split's dK and dV
+        if (workspace && ns > (int)(workspace_bytes / slab)) ns = (int)(workspace_bytes / slab);
+        if (ns > 1 && workspace && (D & 3) == 0) {
             a.q_per_split = clora_cdiv(clora_cdiv(Nq, ns), 64) * 64;
             a.nsplit = clora_cdiv(Nq, a.q_per_split);
             a.acc32 = (float*)workspace;
-            (void)hipMemsetAsync(workspace, 0, need, s);
         }
     }
     // delta = rowsum(dO * O) is produced by the dQ kernel's prologue and consumed by the dK/dV kernel launched after it

@@ -257,7 +257,7 @@ def attn_fwd(q, k, v, B, H, Nq, Nk, D, scale, out=None):
 
 def attn_bwd(q, k, v, o, dO, lse, B, H, Nq, Nk, D, scale, dq, dk, dv):
     delta = torch.empty((B, H, Nq), dtype=f32, device=q.device)
-    ws = workspace(2 * B * Nk * H * D * 4, q.device) if Nk <= 1024 else None
+    ws = workspace(16 * 2 * B * Nk * H * D * 4, q.device) if Nk <= 1024 else None     # up to 16 query splits, one fp32 slab pair each
     _call("clora_attn_bwd_f16", ptr(q, f16), q.stride(0), ptr(k, f16), k.stride(0), ptr(v, f16), v.stride(0),
           ptr(o, f16), o.stride(0), ptr(dO, f16), dO.stride(0), ptr(lse, f32), ptr(delta),
           ptr(dq, f16), dq.stride(0), ptr(dk, f16), dk.stride(0), ptr(dv, f16), dv.stride(0),

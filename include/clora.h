@@ -131,8 +131,9 @@ int clora_conv_weight_pack_f32(const float* w, int Co, int Ci, int ksize, int Ci
 int clora_attn_fwd_f16(const clora_half* q, int ldq, const clora_half* k, int ldk, const clora_half* v, int ldv,
                        clora_half* o, int ldo, float* lse, int B, int H, int Nq, int Nk, int D, float scale,
                        void* stream);
-/* dq/dk/dv given do (autograd of the same lines). delta: [B,H,Nq] fp32 scratch.  workspace (optional,
- * 2*B*Nk*H*D*4 bytes) lets the dK/dV kernel split its query loop when there are few keys (cross-attention). */
+/* dq/dk/dv given do (autograd of the same lines). delta: [B,H,Nq] fp32 scratch.  workspace (optional, one
+ * 2*B*Nk*H*D*4-byte slab pair per query split, up to 16) lets the dK/dV kernel split its query loop when there are few keys
+ * (cross-attention); the splits are folded in a fixed order (no atomics). */
 int clora_attn_bwd_f16(const clora_half* q, int ldq, const clora_half* k, int ldk, const clora_half* v, int ldv,
                        const clora_half* o, int ldo, const clora_half* dO, int lddo, const float* lse,
                        float* delta, clora_half* dq, int lddq, clora_half* dk, int lddk, clora_half* dv, int lddv,
