@@ -876,10 +876,24 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(GemmArgs p, int spli
         float s[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) s[e] = 0.f;
-        for (int z = 0; z < splits; ++z) {
-            const float* q = p.partial + ((size_t)z * p.M + m) * p.N + n;
-            const floatx4 a = *reinterpret_cast<const floatx4*>(q);
-            const floatx4 b = *reinterpret_cast<const floatx4*>(q + 4);
+        const size_t zs = (size_t)p.M * p.N;                     // floats between consecutive slabs
+        const float* q0 = p.partial + (size_t)m * p.N + n;
+        int z = 0;
+        for (; z + 4 <= splits; z += 4) {                        // four slabs' loads in flight (a load -> wait -> add loop paid one
+            floatx4 a[4], b[4];                                  // L2 / HBM round trip per slab: up to 12 per output chunk)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                a[u] = *reinterpret_cast<const floatx4*>(q0 + (size_t)(z + u) * zs);
+                b[u] = *reinterpret_cast<const floatx4*>(q0 + (size_t)(z + u) * zs + 4);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { s[e] += a[u][e]; s[4 + e] += b[u][e]; }
+        }
+        for (; z < splits; ++z) {
+            const floatx4 a = *reinterpret_cast<const floatx4*>(q0 + (size_t)z * zs);
+            const floatx4 b = *reinterpret_cast<const floatx4*>(q0 + (size_t)z * zs + 4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) { s[e] += a[e]; s[4 + e] += b[e]; }
         }

@@ -164,15 +164,28 @@ __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(GnArgs p) {
 // from L2) into group statistics, derives the per-channel scale/shift of ITS OWN columns into registers and
 // streams its rows: no coefficient table, no separate finalize launch.
 __device__ __forceinline__ void gn_fold_groups(const GnArgs& p, int b, int t, float* out2, float inv_n) {
-    const int g = t >> 2, part = t & 3;
+    // 8 threads per group (4 when G > 32), each folding every 8th (4th) chunk partial with EIGHT loads in flight: the partials sit
+    // in L2 and a load -> wait -> add loop paid one L2 round trip per partial (32 of them at 64x64 maps: ~8 us of the apply
+    // kernels' 10-22 us -- profiles/r02_step_trace_by_grid.txt).  Fixed order: still deterministic.
+    const int sh = p.G > 32 ? 2 : 3, parts = 1 << sh;
+    const int g = t >> sh, part = t & (parts - 1);
     float s = 0.f, q = 0.f;
-    if (g < p.G)
-        for (int c = part; c < p.nchunk; c += 4) {
-            const float* pp = p.partial + (((size_t)b * p.nchunk + c) * p.G + g) * 2;
-            s += pp[0]; q += pp[1];
+    if (g < p.G) {
+        const float* base = p.partial + ((size_t)b * p.nchunk * p.G + g) * 2;
+        const size_t cs = (size_t)p.G * 2;                       // floats between consecutive chunks
+        int c = part;
+        for (; c + 7 * parts < p.nchunk; c += 8 * parts) {
+            float v0[8], v1[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const float* pp = base + (size_t)(c + u * parts) * cs; v0[u] = pp[0]; v1[u] = pp[1]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { s += v0[u]; q += v1[u]; }
         }
+        for (; c < p.nchunk; c += parts) { const float* pp = base + (size_t)c * cs; s += pp[0]; q += pp[1]; }
+    }
     s += __shfl_xor(s, 1); q += __shfl_xor(q, 1);
     s += __shfl_xor(s, 2); q += __shfl_xor(q, 2);
+    if (sh == 3) { s += __shfl_xor(s, 4); q += __shfl_xor(q, 4); }
     if (g < p.G && part == 0) { out2[g * 2] = s * inv_n; out2[g * 2 + 1] = q * inv_n; }
 }
 
@@ -290,7 +303,15 @@ __global__ __launch_bounds__(256) void gn_bwd_params_kernel(GnArgs p) {
     float sa = 0.f, sb = 0.f;
     if (c < p.C) {
         const int n = p.B * p.nchunk;
-        for (int i = part; i < n; i += 8) {
+        int i = part;
+        for (; i + 56 < n; i += 64) {                            // 8 loads in flight (was one L2 round trip per partial, 64 of them)
+            float v0[8], v1[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const float* pp = p.chpart + ((size_t)(i + 8 * u) * p.C + c) * 2; v0[u] = pp[0]; v1[u] = pp[1]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { sa += v0[u]; sb += v1[u]; }
+        }
+        for (; i < n; i += 8) {
             const float* pp = p.chpart + ((size_t)i * p.C + c) * 2;
             sa += pp[0]; sb += pp[1];
         }
