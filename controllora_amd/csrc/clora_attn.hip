@@ -22,6 +22,7 @@
 //     transpose read start on 8 distinct multiples of 8 banks (conflict-free ds_read_b64_tr_b16) and the ds_read_b128
 //     fragment reads are conflict-free for the hardware's real lane groups as well (MI355X_MICROARCH.md section LDS;
 //     the round-1 pitch DP + 8 was 2-way conflicted for both).
+#include <stdlib.h>
 #include "clora_common.h"
 #include "../../include/clora.h"
 
@@ -76,17 +77,17 @@ __device__ __forceinline__ half8 frag_from_acc(floatx4 lo, floatx4 hi) {
 __device__ __attribute__((aligned(16))) const unsigned g_attn_zero16[4] = {0u, 0u, 0u, 0u};
 __device__ __attribute__((aligned(16))) const unsigned short g_attn_one16[8] = {0x3C00u, 0, 0, 0, 0, 0, 0, 0};
 
-template <int ROWS, int LD>
+template <int ROWS, int LD, int NWV = 4>
 struct TileDma {
     static constexpr int PCH = LD / 8;                 // chunks per padded row
     static constexpr int NI = ROWS * PCH / 64;         // wave-instructions per tile
-    static constexpr int NIW = (NI + 3) / 4;           // ... per wave (wave w issues instructions w, w+4, ...)
+    static constexpr int NIW = (NI + NWV - 1) / NWV;   // ... per wave (wave w of NWV issues instructions w, w+NWV, ...)
     static_assert((ROWS * PCH) % 64 == 0, "a tile must be a whole number of DMA wave-instructions");
     int row[NIW], col[NIW];                            // this lane's (row, first column) per instruction; col -1: padding, -2: ones chunk
     __device__ __forceinline__ void init(int w, int l, int D) {
 #pragma unroll
         for (int j = 0; j < NIW; ++j) {
-            const int sl = (w + 4 * j) * 64 + l;
+            const int sl = (w + NWV * j) * 64 + l;
             const int r = sl / PCH, c = sl - r * PCH;
             row[j] = r;
             col[j] = (c * 8 < D) ? c * 8 : (c * 8 == D ? -2 : -1);
@@ -98,7 +99,7 @@ struct TileDma {
         const half_t* one_page = reinterpret_cast<const half_t*>(g_attn_one16);
 #pragma unroll
         for (int j = 0; j < NIW; ++j) {
-            const int i = w + 4 * j;
+            const int i = w + NWV * j;
             if (i < NI) {
                 const bool in = row[j] < rows_valid;       // selects, not branches: the issue path stays straight-line
                 const half_t* src = (in && col[j] >= 0) ? base + row[j] * ld + col[j] : zero_page;
@@ -131,21 +132,24 @@ __device__ __forceinline__ floatx4 splat4f(float x) {
 //     multiplied V.)
 constexpr float kRebase = 8.0f;
 
-template <int DP, int DT, bool ONES>
-__global__ __launch_bounds__(256, (DP <= 64 ? 3 : 1)) void attn_fwd_kernel(AttnArgs p) {
+// NWV waves per block (32 queries each).  The loop is bound by the L2 -> LDS stream of K/V tiles (every block of NWV*32 queries
+// re-streams all keys: 7.5 TB/s at B = 32, the same DMA ceiling the GEMMs hit), so more queries per block = less traffic per flop:
+// 8 waves (256 queries, 126 registers: two blocks per CU = 16 waves) at head dims <= 64 when the grid stays full (-18 % at B = 4, N = 4096).
+template <int DP, int DT, bool ONES, int NWV>
+__global__ __launch_bounds__(NWV * 64, (DP <= 64 ? (NWV == 4 ? 3 : 2) : 1)) void attn_fwd_kernel(AttnArgs p) {
     constexpr int BKV = 64, LDK = DP + 16, DV = DT * 16, LDV = DV + ((DV % 32) == 16 ? 0 : 16), KS = DP / 32;
     constexpr int TILE = BKV * LDK + BKV * LDV;           // one K tile + one V tile; two of them: double buffer
     __shared__ __attribute__((aligned(16))) half_t smem[2 * TILE];
     const int t = threadIdx.x, w = t >> 6, l = t & 63, g = l >> 4, li = l & 15;
     const int b = blockIdx.y / p.H, h = blockIdx.y % p.H;
-    const int q0 = blockIdx.x * 128 + w * 32;
+    const int q0 = blockIdx.x * (NWV * 32) + w * 32;
     const int D = p.D;
     const float c = p.scale * kLog2e;
 
     const half_t* kbase = p.k + (size_t)b * p.Nk * p.ldk + h * D;
     const half_t* vbase = p.v + (size_t)b * p.Nk * p.ldv + h * D;
-    TileDma<BKV, LDK> dk_;
-    TileDma<BKV, LDV> dv_;
+    TileDma<BKV, LDK, NWV> dk_;
+    TileDma<BKV, LDV, NWV> dv_;
     dk_.init(w, l, D);
     dv_.init(w, l, D);
     {
@@ -286,18 +290,18 @@ __global__ __launch_bounds__(256, (DP <= 64 ? 3 : 1)) void attn_fwd_kernel(AttnA
 }
 
 // ------------------------------------------------------------------------------------------ dQ
-template <int DP, int DT, int BKV>
-__global__ __launch_bounds__(256, (DP <= 64 ? 2 : 1)) void attn_bwd_dq_kernel(AttnArgs p) {
+template <int DP, int DT, int BKV, int NWV>
+__global__ __launch_bounds__(NWV * 64, (DP <= 64 && NWV == 4 ? 2 : 1)) void attn_bwd_dq_kernel(AttnArgs p) {
     constexpr int LDK = DP + 16, KS = DP / 32, KT = BKV / 16, NP = BKV / 32;
     constexpr int TILE = 2 * BKV * LDK;                    // K tile + V tile; double buffered (see TileDma)
     __shared__ __attribute__((aligned(16))) half_t smem[2 * TILE];
     const int t = threadIdx.x, w = t >> 6, l = t & 63, g = l >> 4, li = l & 15;
     const int b = blockIdx.y / p.H, h = blockIdx.y % p.H;
-    const int q0 = blockIdx.x * 128 + w * 32;
+    const int q0 = blockIdx.x * (NWV * 32) + w * 32;
     const int D = p.D;
     const half_t* kbase = p.k + (size_t)b * p.Nk * p.ldk + h * D;
     const half_t* vbase = p.v + (size_t)b * p.Nk * p.ldv + h * D;
-    TileDma<BKV, LDK> dma;                                 // K and V tiles share the slot -> (row, column) map
+    TileDma<BKV, LDK, NWV> dma;                            // K and V tiles share the slot -> (row, column) map
     dma.init(w, l, D);
     {
         const int rows0 = p.Nk < BKV ? p.Nk : BKV;
@@ -437,15 +441,15 @@ __global__ __launch_bounds__(256, (DP <= 64 ? 2 : 1)) void attn_bwd_dq_kernel(At
 // ------------------------------------------------------------------------------------------ dK, dV
 // (256, 2): asking for 3 blocks per CU (168 registers) spills ~48 dwords of loop-invariant addresses into the loop --
 // measured 1.75x SLOWER at d = 40 (profiles/r02_attn_ab.json note); with the DMA double buffer two blocks hide the latency.
-template <int DP, int DT, int BQT>
-__global__ __launch_bounds__(256, (DP <= 64 ? 2 : 1)) void attn_bwd_dkv_kernel(AttnArgs p) {
+template <int DP, int DT, int BQT, int NWV>
+__global__ __launch_bounds__(NWV * 64, (DP <= 64 && NWV == 4 ? 2 : 1)) void attn_bwd_dkv_kernel(AttnArgs p) {
     constexpr int LDK = DP + 16, KS = DP / 32, QT = BQT / 16, NP = BQT / 32;
     constexpr int TILE = 2 * BQT * LDK;                    // Q tile + dO tile; double buffered (see TileDma)
     __shared__ __attribute__((aligned(16))) half_t smem[2 * TILE + 2 * 4 * BQT];
     float* LD_ = reinterpret_cast<float*>(smem + 2 * TILE);   // [2 buffers][-LSE*log2e (BQT) | -delta (BQT)]
     const int t = threadIdx.x, w = t >> 6, l = t & 63, g = l >> 4, li = l & 15;
     const int b = blockIdx.y / p.H, h = blockIdx.y % p.H;
-    const int k0 = blockIdx.x * 128 + w * 32;
+    const int k0 = blockIdx.x * (NWV * 32) + w * 32;
     const int D = p.D;
     const float c = p.scale * kLog2e;
 
@@ -454,7 +458,7 @@ __global__ __launch_bounds__(256, (DP <= 64 ? 2 : 1)) void attn_bwd_dkv_kernel(A
     const half_t* qbase = p.q + (size_t)b * p.Nq * p.ldq + h * D;
     const half_t* dobase = p.dO + (size_t)b * p.Nq * p.lddo + h * D;
     const size_t sbase = ((size_t)b * p.H + h) * p.Nq;
-    TileDma<BQT, LDK> dma;                                 // Q and dO tiles share the slot -> (row, column) map
+    TileDma<BQT, LDK, NWV> dma;                            // Q and dO tiles share the slot -> (row, column) map
     dma.init(w, l, D);
     // thread t < BQT carries -LSE*log2(e) of query row t of the tile in flight, thread BQT <= t < 2 BQT carries -delta:
     // they initialise the accumulators (below), so they are kept negated
@@ -612,17 +616,48 @@ __global__ __launch_bounds__(256) void attn_dkv_convert_kernel(AttnArgs p) {
 
 template <int DP, int DT>
 int launch_fwd(const AttnArgs& a, hipStream_t s) {
-    const dim3 grid(clora_cdiv(a.Nq, 128), a.B * a.H);
-    if (a.D == DT * 16 - 8) hipLaunchKernelGGL((attn_fwd_kernel<DP, DT, true>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((attn_fwd_kernel<DP, DT, false>), grid, dim3(256), 0, s, a);
+    // wider blocks when there are enough queries to keep the grid full (A/B: CLORA_ATTN_FWD_WAVES = 4 | 6 | 8)
+    static const int forced = [] { const char* e = getenv("CLORA_ATTN_FWD_WAVES"); return e ? atoi(e) : 0; }();
+    int nw = forced ? forced : ((DP <= 64 && (long)clora_cdiv(a.Nq, 256) * a.B * a.H >= 512) ? 8 : 4);   // measured: 6 waves lose, 8 win 10-18 %
+    if (DP > 64 && nw != 4) nw = 4;                         // larger head dims keep the 4-wave block (LDS / registers)
+    const bool ones = a.D == DT * 16 - 8;
+    const dim3 grid(clora_cdiv(a.Nq, nw * 32), a.B * a.H);
+#define CLORA_FWD_LAUNCH(NWV)                                                                                         \
+    do {                                                                                                              \
+        if (ones) hipLaunchKernelGGL((attn_fwd_kernel<DP, DT, true, NWV>), grid, dim3(NWV * 64), 0, s, a);            \
+        else hipLaunchKernelGGL((attn_fwd_kernel<DP, DT, false, NWV>), grid, dim3(NWV * 64), 0, s, a);                \
+    } while (0)
+    if constexpr (DP <= 64) {
+        if (nw == 8) CLORA_FWD_LAUNCH(8);
+        else if (nw == 6) CLORA_FWD_LAUNCH(6);
+        else CLORA_FWD_LAUNCH(4);
+    } else {
+        CLORA_FWD_LAUNCH(4);
+    }
+#undef CLORA_FWD_LAUNCH
     return clora_check_launch();
 }
 template <int DP, int DT, int BT>
 int launch_bwd(const AttnArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<DP, DT, BT>), dim3(clora_cdiv(a.Nq, 128), a.B * a.H), dim3(256), 0, s, a);
+    // 8-wave blocks (one per CU: the same 8 waves as two 4-wave blocks, half the K/V resp. Q/dO stream per flop) when the grids stay
+    // full; A/B: CLORA_ATTN_BWD_WAVES = 4 | 8
+    static const int forced = [] { const char* e = getenv("CLORA_ATTN_BWD_WAVES"); return e ? atoi(e) : 0; }();
+    const bool wide_q = forced ? forced == 8 : (DP <= 64 && (long)clora_cdiv(a.Nq, 256) * a.B * a.H >= 256);
+    const bool wide_k = forced ? forced == 8 : (DP <= 64 && a.nsplit == 1 && (long)clora_cdiv(a.Nk, 256) * a.B * a.H >= 256);
+    if constexpr (DP <= 64) {
+        if (wide_q) hipLaunchKernelGGL((attn_bwd_dq_kernel<DP, DT, BT, 8>), dim3(clora_cdiv(a.Nq, 256), a.B * a.H), dim3(512), 0, s, a);
+        else hipLaunchKernelGGL((attn_bwd_dq_kernel<DP, DT, BT, 4>), dim3(clora_cdiv(a.Nq, 128), a.B * a.H), dim3(256), 0, s, a);
+    } else {
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<DP, DT, BT, 4>), dim3(clora_cdiv(a.Nq, 128), a.B * a.H), dim3(256), 0, s, a);
+    }
     int rc = clora_check_launch();
     if (rc != CLORA_OK) return rc;
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<DP, DT, BT>), dim3(clora_cdiv(a.Nk, 128), a.B * a.H, a.nsplit), dim3(256), 0, s, a);
+    if constexpr (DP <= 64) {
+        if (wide_k && a.nsplit == 1) hipLaunchKernelGGL((attn_bwd_dkv_kernel<DP, DT, BT, 8>), dim3(clora_cdiv(a.Nk, 256), a.B * a.H, 1), dim3(512), 0, s, a);
+        else hipLaunchKernelGGL((attn_bwd_dkv_kernel<DP, DT, BT, 4>), dim3(clora_cdiv(a.Nk, 128), a.B * a.H, a.nsplit), dim3(256), 0, s, a);
+    } else {
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<DP, DT, BT, 4>), dim3(clora_cdiv(a.Nk, 128), a.B * a.H, a.nsplit), dim3(256), 0, s, a);
+    }
     if (a.nsplit > 1) {
         const size_t total = (size_t)a.B * a.Nk * (a.H * a.D / 4);
         int blocks = (int)((total + 255) / 256);
