@@ -325,6 +325,7 @@ __device__ __forceinline__ void dma_epilogue(const GemmArgs& p, floatx4 (&acc)[B
     // rank-4 adapter in the epilogue (every attention projection): the 32 up-matrix values and the bias of this thread's 8 columns
     // live in registers for the whole tile -- per output chunk only the 16-byte T row is fetched.  (Fetching U per chunk made the
     // epilogue's L1 traffic as long as a 5-step main loop: 8 x 16-byte loads per chunk.)
+    // (Staging U in LDS for the other kernels instead was measured too: 24.24 -> 24.30 ms/step, not kept.)
     // HOIST: only the kernels built for <= 2 blocks per CU have the 40 registers to spare (the others spilled accumulators: measured
     // +0.6 ms per train step), and a thread must own >= 4 output chunks for the hoist to amortise (2 on the 64x64 tile)
     constexpr bool HOIST_PAYS = HOIST && (BM * CPR / NT) >= 4 && (BM / WM / 16) * (BN / WN / 16) * 4 < 128;
@@ -344,23 +345,9 @@ __device__ __forceinline__ void dma_epilogue(const GemmArgs& p, floatx4 (&acc)[B
 #pragma unroll
         for (int e = 0; e < 4; ++e) { bias8[e] = b0[e]; bias8[4 + e] = b1[e]; }
     }
-    // Kernels without the registers to hoist (the 64x64 / 128x64 tiles of the small projections) stage the tile's slice of the
-    // rank-4 up matrix in LDS once instead: 8 x 16-byte L1 fetches per output chunk competed with the operand stream for the
-    // same L1 / TA path (they were ~45 % of a 64x64 tile's L1 requests); now one 1-KB copy per tile and ds_read_b128s.
-    constexpr int US_OFF = PR * F_LD;                          // floats: right behind the fp32 staging rows
-    constexpr bool US_FITS = (US_OFF + BN * 4) * 4 <= SMEM * 2;
-    float* Us = Cf + US_OFF;                                   // [BN][4]: u(n0 + col, j)
-    const bool ulds = US_FITS && !hoist && p.epi.lora_t != nullptr && p.epi.lora_r == 4 && p.epi.geglu == 0 &&
-                      (p.epi.ldt & 3) == 0 && (p.epi.lora_seg & 7) == 0;
 #pragma unroll
     for (int ph = 0; ph < NPASS; ++ph) {
         __syncthreads();                                       // ring (or previous pass) fully consumed
-        if (ph == 0 && ulds) {
-            for (int i = t; i < BN * 4; i += NT) {
-                const int col = i >> 2, j = i & 3, nn = n0 + col;
-                Us[i] = nn < p.N ? (p.epi.lora_u_tr ? p.epi.lora_u[(size_t)j * p.epi.ldu + nn] : p.epi.lora_u[(size_t)nn * p.epi.ldu + j]) : 0.f;
-            }
-        }
         const int wrow0 = wm * FM * 16;                        // first tile row of this wave
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
@@ -434,24 +421,6 @@ __device__ __forceinline__ void dma_epilogue(const GemmArgs& p, floatx4 (&acc)[B
                     } else {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] += t4[0] * ureg[e][0] + t4[1] * ureg[e][1] + t4[2] * ureg[e][2] + t4[3] * ureg[e][3];
-                    }
-                } else if (ulds) {
-                    if (p.epi.bias) {
-                        const floatx4 b0 = *reinterpret_cast<const floatx4*>(p.epi.bias + n), b1 = *reinterpret_cast<const floatx4*>(p.epi.bias + n + 4);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
-                    }
-                    if (p.epi.rowadd) {
-                        const half8 ra = ld8((const half_t*)p.epi.rowadd + (size_t)(m / p.epi.rows_per_batch) * p.epi.ld_rowadd + n);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] += (float)ra[e];
-                    }
-                    floatx4 t4 = *reinterpret_cast<const floatx4*>(p.epi.lora_t + (size_t)m * p.epi.ldt + (n / p.epi.lora_seg) * 4);
-                    t4 *= p.epi.lora_scale;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const floatx4 u = *reinterpret_cast<const floatx4*>(Us + (nc * 8 + e) * 4);
-                        v[e] += t4[0] * u[0] + t4[1] * u[1] + t4[2] * u[2] + t4[3] * u[3];
                     }
                 } else {
                     epi_chunk8(v, m, n, p.epi);
