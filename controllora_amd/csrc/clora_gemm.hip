@@ -1121,7 +1121,9 @@ int launch_gemm(GemmArgs& a, int splits, hipStream_t s, bool dma) {
         else if (cm == 1) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, WM, WN, NST, 1, BK, FLAGS>), grid, dim3(WM * WN * 64), 0, s, a);
         else hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, WM, WN, NST, 2, BK, FLAGS>), grid, dim3(WM * WN * 64), 0, s, a);
     }
-    else hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN>), dim3(tiles_m * a.tiles_n, splits), dim3(256), 0, s, a);
+    else if constexpr (BM * BN <= 128 * 128 && WM * WN == 4)      // the register-staged v1 loop only exists for the round-1 tiles (A/B runs)
+        hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN>), dim3(tiles_m * a.tiles_n, splits), dim3(256), 0, s, a);
+    else return CLORA_ERR_ARG;
     return clora_check_launch();
 }
 
@@ -1232,7 +1234,8 @@ extern "C" int clora_gemm_f16_ex(const clora_half* A, int lda, const clora_half*
     //   31..33 = 1..3 and 41..43 = 21..23 with fragment reads before the ring refill
     //   51..53 = 8-wave blocks (one per CU), BK 64: 128x320 x2 stages, 64x320 x3, 128x256 x3 (wave tiles 32x160 / 32x80 / 32x128) for the
     //            short-K projections -- with the whole of N = 320 in one tile A is fetched once instead of once per 64 / 128 columns;
-    //            54..56 = the same with fragment reads before the ring refill
+    //            54..56 = the same with fragment reads before the ring refill; 57, 58 = 256x320 / 256x256 x2 stages (wave tiles 64x160 /
+    //            64x128) for the M >= 32768 projections of the batch-32 inference forward
     bool dma = true;
     if (tile_cfg >= 11 && tile_cfg <= 13) { dma = false; tile_cfg -= 10; }
     int cfg = tile_cfg > 0 ? tile_cfg : tile + 1;
@@ -1252,7 +1255,7 @@ extern "C" int clora_gemm_f16_ex(const clora_half* A, int lda, const clora_half*
     }
     if (a.epi.geglu) {
         if (!dma) return CLORA_ERR_ARG;
-        const bool wide = cfg == 1 || cfg == 4 || cfg == 7 || cfg == 8 || cfg == 9 || cfg == 21 || cfg == 31 || cfg == 41 || cfg == 53 || cfg == 56;
+        const bool wide = cfg == 1 || cfg == 4 || cfg == 7 || cfg == 8 || cfg == 9 || cfg == 21 || cfg == 31 || cfg == 41 || cfg == 53 || cfg == 56 || cfg == 58;
         if (a.epi.geglu == 1 && !wide) { if (tile_cfg > 0) return CLORA_ERR_ARG; cfg = 1; }
     }
     //   71..76 = conv3x3_patch_kernel (3x3 stride-1 pad-1 convs and their dgrads, input patch staged once per 64-channel slab):
@@ -1289,7 +1292,7 @@ extern "C" int clora_gemm_f16_ex(const clora_half* A, int lda, const clora_half*
             return rc;
         }
     }
-    const int bk = ((cfg >= 21 && cfg <= 26) || (cfg >= 41 && cfg <= 43) || (cfg >= 51 && cfg <= 56) || (cfg >= 91 && cfg <= 96)) ? 64 : 32;
+    const int bk = ((cfg >= 21 && cfg <= 26) || (cfg >= 41 && cfg <= 43) || (cfg >= 51 && cfg <= 58) || (cfg >= 91 && cfg <= 96)) ? 64 : 32;
     a.k_per_split = clora_cdiv(clora_cdiv(K, bk), splits) * bk;
     splits = clora_cdiv(K, a.k_per_split);
     if (splits > 1) {
@@ -1317,6 +1320,8 @@ extern "C" int clora_gemm_f16_ex(const clora_half* A, int lda, const clora_half*
         case 51: rc = launch_gemm<128, 320, 4, 2, 2, 64, 0>(a, splits, s, true); break;    // 8 waves, the whole of N = 320 per tile: A crosses L2 -> LDS once
         case 52: rc = launch_gemm<64, 320, 2, 4, 3, 64, 0>(a, splits, s, true); break;
         case 53: rc = launch_gemm<128, 256, 4, 2, 3, 64, 0>(a, splits, s, true); break;
+        case 57: rc = launch_gemm<256, 320, 4, 2, 2, 64, 1>(a, splits, s, true); break;    // M >= 32768 (batch-32 inference): 142 flop per operand byte
+        case 58: rc = launch_gemm<256, 256, 4, 2, 2, 64, 1>(a, splits, s, true); break;
         case 54: rc = launch_gemm<128, 320, 4, 2, 2, 64, 1>(a, splits, s, true); break;
         case 55: rc = launch_gemm<64, 320, 2, 4, 3, 64, 1>(a, splits, s, true); break;
         case 56: rc = launch_gemm<128, 256, 4, 2, 3, 64, 1>(a, splits, s, true); break;

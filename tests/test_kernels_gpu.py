@@ -41,7 +41,7 @@ def test_conv_small_channels():
     KC.case_conv(DEV, 1, 64, 64, 8, 32)
 
 
-ALL_TILE_CFGS = [1, 2, 3, 4, 5, 6, 7, 8, 9, 21, 22, 23, 26, 31, 32, 33, 41, 42, 43, 51, 52, 53, 54, 55, 56]
+ALL_TILE_CFGS = [1, 2, 3, 4, 5, 6, 7, 8, 9, 21, 22, 23, 26, 31, 32, 33, 41, 42, 43, 51, 52, 53, 54, 55, 56, 57, 58]
 
 
 @pytest.mark.parametrize("tile", ALL_TILE_CFGS)
