@@ -405,12 +405,20 @@ extern "C" int clora_lora_wgrad_multi_f16(const clora_lora_wgrad_job_t* jobs, in
     const int rt = wgrad_rt(jobs[0].R);
     size_t off = 0;
     int gx = 0, gy = 0, maxNRT = 0;
+    // a launch of many jobs already fills the chip: grow the row chunk (fewer, longer blocks: 4x less slab traffic and a deeper load
+    // pipeline per wave) until the launch is down to ~1024 blocks; never below the per-job choice the workspace was sized for
+    int grow = 1;
+    {
+        long total = 0;
+        for (int i = 0; i < njobs; ++i) total += (long)clora_cdiv(jobs[i].N, 512) * clora_cdiv(jobs[i].M, wgrad_rows_per_block(jobs[i].M, jobs[i].N));
+        while (grow < 8 && total / (grow * 2) >= 1024) grow *= 2;
+    }
     for (int i = 0; i < njobs; ++i) {
         const clora_lora_wgrad_job_t& j = jobs[i];
         if (!j.A || !j.T || !j.G || j.M <= 0 || j.N <= 0 || j.R <= 0 || j.R > 16 || (j.N & 7) || (j.lda & 7) || wgrad_rt(j.R) != rt)
             return CLORA_ERR_ARG;
         wj.j[i] = j;
-        wj.rpb[i] = wgrad_rows_per_block(j.M, j.N);
+        wj.rpb[i] = wgrad_rows_per_block(j.M, j.N) * grow;
         wj.nblk[i] = clora_cdiv(j.M, wj.rpb[i]);
         wj.part[i] = (float*)workspace + off;
         off += (size_t)wj.nblk[i] * j.N * rt;
