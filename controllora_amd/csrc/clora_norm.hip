@@ -8,6 +8,7 @@
 //                       scale/shift in registers: two launches, no atomics, no coefficient table)
 //   GroupNorm backward: partial (s1 = sum dy*gamma, s2 = sum dy*gamma*xhat) -> apply (dx = k1*dy' + k2*x + k3)
 //   LayerNorm         : one wave per row, the row lives in registers (two-pass variance), no workspace.
+#include <stdlib.h>
 #include "clora_common.h"
 #include "../../include/clora.h"
 
@@ -467,7 +468,8 @@ int gn_plan(GnArgs& a, void* ws, size_t ws_bytes, bool bwd, bool params) {
         return CLORA_ERR_ARG;
     const int CH = a.C / 8;
     const int nrl = CH >= 256 ? 1 : 256 / CH;
-    long rpc = ((long)a.HW * a.B + 511) / 512;          // ~512 blocks in flight
+    static const long kBlocks = [] { const char* e = getenv("CLORA_GN_BLOCKS"); const long v = e ? atol(e) : 0; return v >= 64 ? v : 512; }();
+    long rpc = ((long)a.HW * a.B + kBlocks - 1) / kBlocks;   // ~512 blocks in flight (A/B: CLORA_GN_BLOCKS)
     if (rpc < 32) rpc = 32;
     if (rpc < 2 * nrl) rpc = 2 * nrl;
     if (rpc > a.HW) rpc = a.HW;
@@ -482,7 +484,7 @@ int gn_plan(GnArgs& a, void* ws, size_t ws_bytes, bool bwd, bool params) {
         int nslab = 1;
         if (a.G % unit_groups == 0) {
             const int nunits = a.G / unit_groups;
-            const long want = (512 + (long)a.B * a.nchunk - 1) / ((long)a.B * a.nchunk);
+            const long want = (kBlocks + (long)a.B * a.nchunk - 1) / ((long)a.B * a.nchunk);
             for (int d = 1; d <= nunits; ++d) {
                 if (nunits % d) continue;
                 if (d <= want || a.C / nslab > 2048) nslab = d;   // largest divisor <= want, grown until a slab fits
