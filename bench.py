@@ -191,11 +191,16 @@ def rocprof_child_trace(args, steps=6, warmup=2):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import rocprof_summary
     rows = rocprof_summary.load(dbs[0])
-    # the child runs 2 eager warm-up steps inside capture() + `warmup` + `steps` replays: all issue the same kernels
+    # the child runs 2 eager warm-up steps inside capture() + `warmup` + `steps` replays: all issue the same kernels.  Kernels
+    # whose launch count is not a multiple of the step count belong to the set-up (weight initialisation, operand packing, the
+    # flat parameter buffer): they are reported apart instead of being averaged into the step.
     n_steps = 2 + warmup + steps
-    res = {"steps_in_trace": n_steps, "total_kernel_ms_per_step": sum(r_["total_ms"] for r_ in rows) / n_steps,
-           "launches_per_step": round(sum(r_["calls"] for r_ in rows) / n_steps),
-           "kernels": rows, "db": dbs[0]}
+    step_rows = [r_ for r_ in rows if r_["calls"] % n_steps == 0]
+    setup_rows = [r_ for r_ in rows if r_["calls"] % n_steps != 0]
+    res = {"steps_in_trace": n_steps, "total_kernel_ms_per_step": sum(r_["total_ms"] for r_ in step_rows) / n_steps,
+           "launches_per_step": round(sum(r_["calls"] for r_ in step_rows) / n_steps),
+           "setup_kernel_ms_total": round(sum(r_["total_ms"] for r_ in setup_rows), 3),
+           "kernels": step_rows, "db": dbs[0]}
     shutil.rmtree(out, ignore_errors=True)
     return res
 
@@ -334,10 +339,11 @@ def main():
             if args.trace_out:
                 json.dump({"command": "rocprofv3 --kernel-trace -- python bench.py --trace-child ...", "steps_in_trace": n_st,
                            "total_kernel_ms_per_step": trace["total_kernel_ms_per_step"], "launches_per_step": trace["launches_per_step"],
+                           "setup_kernel_ms_total": trace["setup_kernel_ms_total"],
                            "kernels": [dict(r_, ms_per_step=round(r_["total_ms"] / n_st, 4), calls_per_step=round(r_["calls"] / n_st, 2))
                                        for r_ in trace["kernels"]]}, open(args.trace_out, "w"), indent=1)
             kt = {"total_kernel_ms_per_step": round(trace["total_kernel_ms_per_step"], 3),
-                  "launches_per_step": trace["launches_per_step"],
+                  "launches_per_step": trace["launches_per_step"], "setup_kernel_ms_total": trace["setup_kernel_ms_total"],
                   "top": [{"kernel": r_["kernel"][:60], "calls_per_step": round(r_["calls"] / n_st, 1),
                            "ms_per_step": round(r_["total_ms"] / n_st, 3), "avg_us": r_["avg_us"]} for r_ in trace["kernels"][:12]]}
         elif trace:

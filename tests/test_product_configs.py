@@ -52,3 +52,30 @@ def test_product_save_load_roundtrip_full_config(name, tmp_path):
     again = M.ControlLoRA.from_pretrained(str(tmp_path))
     for (k, a), (_, b) in zip(prod.state_dict().items(), again.state_dict().items()):
         assert torch.equal(a, b), k
+
+
+def test_adapter_down_jobs_sharing_an_input_are_stacked():
+    """host logic of ops._merge_down_jobs: q|k|v adapters reading the same x become one job over the row-stacked down matrix
+    (adjacent views of the trainer's flat buffer); only the first may carry the control term, which then feeds its rows only"""
+    import torch
+    from controllora_amd import ops
+    flat = torch.randn(3 * 4 * 32)
+    Dq, Dk, Dv = (flat[i * 128:(i + 1) * 128].view(4, 32) for i in range(3))
+    x, c, other = torch.zeros(8, 32), torch.zeros(8, 32), torch.zeros(8, 32)
+    mk = lambda X, D, toff, X2=None: dict(X=X, D=D, toff=toff, R=4, X2=X2, r2=0, x2_rows=0)
+    with torch.enable_grad():
+        out = ops._merge_down_jobs([mk(x, Dq, 0, c), mk(x, Dk, 4), mk(x, Dv, 8)])
+    assert len(out) == 1 and out[0]["R"] == 12 and out[0]["r2"] == 4 and out[0]["X2"] is c
+    assert out[0]["D"].shape == (12, 32) and out[0]["D"].data_ptr() == Dq.data_ptr()          # a view, not a copy
+    # a second input on a later adapter, a different x, or a gap in the T columns keeps the jobs apart
+    assert len(ops._merge_down_jobs([mk(x, Dq, 0), mk(x, Dk, 4, c)])) == 2
+    assert len(ops._merge_down_jobs([mk(x, Dq, 0), mk(other, Dk, 4)])) == 2
+    assert len(ops._merge_down_jobs([mk(x, Dq, 0), mk(x, Dk, 8)])) == 2
+    # separate tensors: stacked (and cached) only without autograd
+    A, B = torch.randn(4, 32), torch.randn(4, 32)
+    with torch.enable_grad():
+        assert len(ops._merge_down_jobs([mk(x, A, 0), mk(x, B, 4)])) == 2
+    with torch.no_grad():
+        m1 = ops._merge_down_jobs([mk(x, A, 0), mk(x, B, 4)])
+        m2 = ops._merge_down_jobs([mk(x, A, 0), mk(x, B, 4)])
+    assert len(m1) == 1 and m1[0]["D"] is m2[0]["D"] and torch.equal(m1[0]["D"], torch.cat([A, B], 0))
