@@ -160,3 +160,52 @@ def fp16_oracle_floor(o_unet, o_clora, guide, cond, uncond, steps, guidance_scal
     h_unet.set_attn_processor(omap(h_unet, h_clora))
     out, _ = oracle_ddim(h_unet, h_clora, guide.half(), cond.half(), uncond.half(), steps, guidance_scale, lat0.half())
     return rel(out, ref)
+
+
+def full_size_properties(dev, config_name="fill50k.json", res=512, batch=4):
+    """BASELINE configs[1] at its FULL size (SD-1.5 topology, 512x512, batch 4: the shapes of the tuned launch table, the
+    patch-staged convs, the 8-wave attention blocks) through properties that do not need an oracle run of that size:
+      identity   : fresh adapters (zero `up`, reference models.py:45 init) leave the UNet prediction bit-identical to the plain UNet;
+      batch      : sample i of the batch-4 prediction equals the batch-1 prediction of sample i (other launch shapes / tiles / split-K);
+      additivity : the flat gradient of the batch-4 MSE step equals the mean of the four batch-1 gradients (loss is a mean);
+      scaling    : doubling the loss scale doubles the raw gradient (the backward is linear in its seed)."""
+    _, o_clora, p_unet, p_clora = build_pair(config_name, dev)
+    inp = inputs(res, batch, seed=7)
+    g16 = lambda k: inp[k].to(dev).to(f16)
+    noisy = unet_ref.DDPMSchedule().add_noise(inp["latents"], inp["noise"], inp["timesteps"]).to(dev).to(f16)
+    ts = inp["timesteps"].to(dev)
+    out = {}
+    with torch.no_grad():
+        # identity: zero the up matrices of a copy of the adapters
+        fresh = M.ControlLoRA.from_config(os.path.join(ROOT, "configs", config_name)).to(dev)
+        p_unet.set_attn_processor(M.map_processors_to_unet(p_unet, fresh))
+        fresh(g16("guide"))
+        with_adapters = p_unet(noisy, ts, g16("ehs")).sample.clone()
+        p_unet.set_attn_processor(U.CrossAttnProcessor())
+        plain = p_unet(noisy, ts, g16("ehs")).sample.clone()
+        out["identity_bit_exact"] = bool(torch.equal(with_adapters, plain))
+        # batch independence with the trained-like (non-zero up) adapters
+        p_unet.set_attn_processor(M.map_processors_to_unet(p_unet, p_clora))
+        p_clora(g16("guide"))
+        pred4 = p_unet(noisy, ts, g16("ehs")).sample.clone()
+        errs = []
+        for i in range(batch):
+            p_clora(g16("guide")[i:i + 1])
+            errs.append(rel(p_unet(noisy[i:i + 1], ts[i:i + 1], g16("ehs")[i:i + 1]).sample, pred4[i:i + 1]))
+        out["batch_vs_single_pred"] = max(errs)
+    # gradients
+    def grads(sl, scale):
+        tr = ControlLoRATrainer(p_unet, p_clora, init_scale=scale, dynamic_scale=False)
+        tr.flat.zero_grad()
+        tr.forward_backward(noisy[sl], ts[sl], g16("ehs")[sl], g16("guide")[sl], inp["noise"].to(dev)[sl])
+        return tr.unscaled_grads_module_order().clone(), tr.flat.grad.clone()
+    g4, raw1 = grads(slice(0, batch), 1024.0)
+    _, raw2 = grads(slice(0, batch), 2048.0)
+    out["seed_linearity"] = rel(raw2, 2.0 * raw1)
+    gsum = None
+    for i in range(batch):
+        gi, _ = grads(slice(i, i + 1), 1024.0)
+        gsum = gi if gsum is None else gsum + gi
+    out["grad_additivity"] = rel(g4, gsum / batch)
+    out["grad_norm"] = float(g4.norm())
+    return out
