@@ -90,8 +90,16 @@ typedef struct {
 int clora_gemm_f16(const clora_half* A, int lda, const clora_half* B, clora_half* C, int ldc,
                    int M, int N, int K, const clora_conv_t* conv, const clora_epilogue_t* epi,
                    int split_k, void* workspace, size_t workspace_bytes, void* stream);
-/* same, with the main-loop variant forced (tile_cfg 1: 128x128, 2: 128x64, 3: 64x64 tiles with the 3-stage LDS ring;
- * 4-6: the same tiles with the deep 5/6/8-stage ring; 11-13: register-staged v1 loop; 0 = automatic) -- tuning / tests */
+/* same, with the main-loop variant forced -- tuning / tests (0 = automatic: the library's latency model, or the patch-staged conv
+ * kernel for the 3x3 convs it can take).  tile_cfg:
+ *   1-3   128x128 / 128x64 / 64x64 tiles, BK 32, 3-stage LDS-DMA ring        4-6  the same with the deep 5/6/8-stage ring
+ *   7, 8  256x128 (wave tile 128x64)                                         9    1 with the round-1 swizzle key (A/B)
+ *   11-13 register-staged round-1 loop (A/B)
+ *   21, 22, 23, 26  BK 64 (128-byte LDS rows): 128x128 x2 stages, 128x64 x3, 64x64 x3, 128x64 x2
+ *   31-33 = 1-3 and 41-43 = 21-23 with the fragment reads before the ring refill
+ *   51-58 8-wave blocks (one per CU), BK 64: 128x320, 64x320, 128x256 (54-56: fragment-first), 256x320, 256x256
+ *   71-76 conv3x3_patch_kernel (3x3 stride-1 pad-1 convs, their dgrads, conv(nearest-2x(x))): 256x128, 128x128 (two wave layouts),
+ *         256x64, 128x64, 128x160; a shape it cannot take falls back to 21 (clora_conv_patch_eligible tells) */
 int clora_gemm_f16_ex(const clora_half* A, int lda, const clora_half* B, clora_half* C, int ldc,
                       int M, int N, int K, const clora_conv_t* conv, const clora_epilogue_t* epi,
                       int split_k, int tile_cfg, void* workspace, size_t workspace_bytes, void* stream);

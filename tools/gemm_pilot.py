@@ -14,7 +14,7 @@ import torch
 from controllora_amd import kernels as K
 
 dev = torch.device("cuda", 0)
-CFGS = [1, 2, 3, 4, 5, 6, 7, 8, 21, 22, 23, 24, 25, 26, 31, 32, 33, 41, 42, 43, 51, 52, 53, 57, 61, 62, 63, 67]
+CFGS = [1, 2, 3, 4, 5, 6, 7, 8, 21, 22, 23, 26, 31, 32, 33, 41, 42, 43, 51, 52, 53, 54, 55, 56, 57, 58, 71, 72, 73, 74, 75, 76]
 # (M, N, K, conv side H (0 = plain GEMM), Cin)
 SHAPES = [
     (16384, 320, 320, 0, 0), (4096, 640, 640, 0, 0), (1024, 1280, 1280, 0, 0),
@@ -61,7 +61,7 @@ def main():
     outp = next((a for a in sys.argv[1:] if not a.startswith("--")), None)
     rows = []
     shapes = SHAPES if not pmc else [SHAPES[0], SHAPES[3], SHAPES[14], SHAPES[2]]
-    cfgs = CFGS if not pmc else [1, 51, 61, 21, 41, 7, 57, 3, 53, 23]
+    cfgs = CFGS if not pmc else [1, 21, 41, 7, 8, 3, 23, 51, 53, 71, 76]
     for (M, N, Kd, H, Cin) in shapes:
         A, Bw, out, res, cd = operands(M, N, Kd, H, Cin)
         ksteps = Kd // 32
