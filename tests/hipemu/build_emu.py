@@ -24,6 +24,37 @@ def _host_isa_flags():
     return ["-mf16c", "-mavx2", "-mfma"] if all(f" {f}" in flags for f in ("f16c", "avx2", "fma")) else []
 
 
+def build_mutant(out_dir: str, file_name: str, edits) -> str:
+    """The emulator library with some source lines of ``csrc/<file_name>`` replaced (``edits`` = [(old, new)], each ``old`` must
+    occur exactly once): used by the
+    tests that prove the emulator's pessimistic LDS-DMA model catches a weakened ``s_waitcnt`` (tests/test_emu_async_model.py)."""
+    import shutil
+    src_dir = os.path.join(out_dir, "controllora_amd", "csrc")      # same depth as the real tree: the sources include
+    shutil.copytree(CSRC, src_dir)                                  # "../../include/clora.h"
+    shutil.copytree(os.path.join(ROOT, "include"), os.path.join(out_dir, "include"))
+    path = os.path.join(src_dir, file_name)
+    text = open(path).read()
+    for old, new in edits:
+        if text.count(old) != 1:
+            raise ValueError(f"{file_name}: mutation anchor {old!r} occurs {text.count(old)} times")
+        text = text.replace(old, new)
+    open(path, "w").write(text)
+    objs = []
+    for src in sorted(glob.glob(os.path.join(src_dir, "*.hip"))):
+        base = os.path.basename(src).rsplit(".", 1)[0] + ".emu.o"
+        if os.path.basename(src) != file_name and os.path.exists(os.path.join(OUT_DIR, base)):
+            objs.append(os.path.join(OUT_DIR, base))          # untouched translation units: reuse the regular build
+            continue
+        obj = os.path.join(out_dir, base)
+        subprocess.check_call([CLANG, "-O2", "-g0", *_host_isa_flags(), "-std=c++17", "-fPIC", "-I", HERE,
+                               "-Wno-unknown-pragmas", "-Wno-pass-failed", "-x", "c++", "-c", src, "-o", obj])
+        objs.append(obj)
+    objs.append(os.path.join(OUT_DIR, "hipemu.emu.o"))
+    lib = os.path.join(out_dir, "libclora_emu_mutant.so")
+    subprocess.check_call([CLANG, "-shared", "-fPIC", *objs, "-o", lib])
+    return lib
+
+
 def build(verbose: bool = False) -> str:
     os.makedirs(OUT_DIR, exist_ok=True)
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))

@@ -1,7 +1,7 @@
 // hipemu.cpp -- TEST INFRASTRUCTURE ONLY: fiber scheduler behind tests/hipemu/hipemu.h.
-#include "hipemu.h"
-
 #include <vector>
+
+#include "hipemu.h"
 
 extern "C" void hipemu_switch(void** save_sp, void* load_sp);
 asm(R"(
@@ -28,7 +28,15 @@ hipemu_switch:
 
 namespace hipemu {
 
+struct PendingDma {                 // one queued global_load_lds_dwordx4 wave-instruction
+    char* base;
+    const void* src[64];
+    bool lane[64];
+};
+
 struct Wave {
+    std::vector<PendingDma> pending; // issued, not yet landed (oldest first)
+    int wait_n = 0;
     const void* gsrc[64];
     void* ldst[64];
     int live = 0, count = 0;
@@ -63,12 +71,22 @@ dim3& cur_tid() { return cur->tid; }
 
 static void yield() { hipemu_switch(&cur->sp, sched_sp); }
 
+static void land(Wave* w, size_t keep) {          // retire all but the `keep` newest queued copies, oldest first
+    while (w->pending.size() > keep) {
+        const PendingDma& d = w->pending.front();
+        for (int i = 0; i < 64; ++i)
+            if (d.lane[i]) memcpy(d.base + 16 * i, d.src[i], 16);
+        w->pending.erase(w->pending.begin());
+    }
+}
+
 static void release_checks_on_exit(Fiber* f) {
     blk_live--;
     if (blk_live > 0 && blk_count == blk_live) { blk_count = 0; blk_gen++; }
     Wave* w = f->wave;
     w->live--;
     w->present[f->lane] = false;
+    if (w->live == 0) land(w, 0);
     if (w->live > 0 && w->count == w->live) {
         fprintf(stderr, "hipemu: a lane exited while its wave waits in a collective\n");
         abort();
@@ -125,10 +143,17 @@ void glds16(const void* gptr, void* lptr) {
     collective([](Wave* w) {
         int first = 0;
         while (first < 64 && !w->present[first]) ++first;
-        char* base = (char*)w->ldst[first];
-        for (int i = 0; i < 64; ++i)
-            if (w->present[i]) memcpy(base + 16 * i, w->gsrc[i], 16);
+        PendingDma d;
+        d.base = (char*)w->ldst[first];
+        for (int i = 0; i < 64; ++i) { d.lane[i] = w->present[i]; d.src[i] = w->gsrc[i]; }
+        w->pending.push_back(d);
     });
+}
+
+void wait_vmcnt(int n) {
+    Wave* w = cur->wave;
+    w->wait_n = n;                                 // wave-uniform by construction (an immediate operand on the hardware)
+    collective([](Wave* w) { land(w, (size_t)w->wait_n); });
 }
 
 // ds_read_b64_tr_b16 as measured on gfx950 (tools/probes/tr16_probe.hip): every lane supplies the LDS address of a

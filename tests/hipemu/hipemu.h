@@ -61,7 +61,10 @@ inline void launch(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t, hipS
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
     hipemu::launch(kernel, grid, block, shmem, stream, __VA_ARGS__)
 
-static inline void __syncthreads() { hipemu::sync_threads(); }
+// __syncthreads() is a fence + barrier: the compiler drains vmcnt (incl. LDS-DMA loads) before s_barrier; the raw barrier
+// (CLORA_RAW_BARRIER) does not -- the emulator models both (see glds16 / wait_vmcnt below)
+namespace hipemu { void wait_vmcnt(int n); }
+static inline void __syncthreads() { hipemu::wait_vmcnt(0); hipemu::sync_threads(); }
 
 template <typename T> static inline T hipemu_shfl(T v, int a, int mode) {
     static_assert(sizeof(T) == 4, "emulator shuffles 32-bit values");
@@ -88,12 +91,15 @@ static inline hipemu_floatx4 __builtin_amdgcn_mfma_f32_16x16x32_f16(hipemu_half8
 
 static inline int __builtin_amdgcn_readfirstlane(int x) { return x; }
 
-// host stand-ins for the asynchronous-copy primitives of clora_common.h: the copy happens immediately (the
-// emulator has no memory latency), destination = first lane's LDS pointer + lane*16 like the hardware.
+// host stand-ins for the asynchronous-copy primitives of clora_common.h, PESSIMISTIC about latency: an LDS-DMA copy is queued
+// per wave and only lands when that wave executes a counted wait that covers it (s_waitcnt vmcnt(n): all but the n newest
+// land, oldest first) or a __syncthreads(); until then LDS keeps its old bytes.  A kernel that waits for too few loads, or
+// reads a stage another wave has not waited for yet, computes garbage here -- on the hardware the same bug is an intermittent
+// race.  Destination = first lane's LDS pointer + lane*16 like the hardware.
 namespace hipemu { void glds16(const void* gptr, void* lptr); }
 #define CLORA_ASYNC_PRIMS
 #define CLORA_GLDS16(gptr, lptr) hipemu::glds16((const void*)(gptr), (void*)(lptr))
-#define CLORA_WAIT_VMCNT(n) ((void)0)
+#define CLORA_WAIT_VMCNT(n) hipemu::wait_vmcnt(n)
 #define CLORA_RAW_BARRIER() hipemu::sync_threads()
 namespace hipemu { uint64_t ds_read_tr16_b64(const void* lptr); }
 typedef _Float16 hipemu_half4 __attribute__((ext_vector_type(4)));
