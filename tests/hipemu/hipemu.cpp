@@ -71,6 +71,11 @@ dim3& cur_tid() { return cur->tid; }
 
 static void yield() { hipemu_switch(&cur->sp, sched_sp); }
 
+// hipemu_set_dma_eager(1): copies land at issue (the other extreme of the latency range; a DMA into a ring stage that a slower
+// wave still reads corrupts that wave's operands).  Default: copies land as late as the waits allow.
+static int g_dma_eager = 0;
+static bool dma_eager() { return g_dma_eager != 0; }
+
 static void land(Wave* w, size_t keep) {          // retire all but the `keep` newest queued copies, oldest first
     while (w->pending.size() > keep) {
         const PendingDma& d = w->pending.front();
@@ -147,6 +152,7 @@ void glds16(const void* gptr, void* lptr) {
         d.base = (char*)w->ldst[first];
         for (int i = 0; i < 64; ++i) { d.lane[i] = w->present[i]; d.src[i] = w->gsrc[i]; }
         w->pending.push_back(d);
+        if (dma_eager()) land(w, 0);                  // zero-latency mode: exposes write-after-read on a stage still being read
     });
 }
 
@@ -249,3 +255,5 @@ void run_grid(dim3 grid, dim3 block, const std::function<void()>& body) {
 }
 
 }  // namespace hipemu
+
+extern "C" void hipemu_set_dma_eager(int on) { hipemu::g_dma_eager = on; }

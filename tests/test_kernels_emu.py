@@ -72,6 +72,33 @@ def test_attention(B, H, Nq, Nk, D, fused):
     KC.case_attention("cpu", B, H, Nq, Nk, D, fused_qkv=fused)
 
 
+@pytest.fixture
+def zero_latency_dma():
+    """LDS-DMA copies land at issue instead of at the covering wait (tests/hipemu/hipemu.cpp): the other end of the latency
+    range.  A copy issued into a ring stage / double-buffer half that a slower wave still reads corrupts that wave's operands."""
+    from tests.emu_fixture import emu_lib
+    emu_lib().cdll.hipemu_set_dma_eager(1)
+    yield
+    emu_lib().cdll.hipemu_set_dma_eager(0)
+
+
+@pytest.mark.parametrize("tile", [21, 33, 43, 53, 57])
+def test_gemm_rings_zero_latency_dma(tile, zero_latency_dma):
+    KC.case_gemm_plain("cpu", 70, 136, 424, 3, tile_cfg=tile)
+    KC.case_gemm_epilogue("cpu", split_k=1, tile_cfg=tile)
+
+
+@pytest.mark.parametrize("tile", [71, 72, 75, 76])
+def test_conv_patch_zero_latency_dma(tile, zero_latency_dma):
+    KC.case_conv_patch("cpu", 2, 8, 8, 128, 64, tile)
+    KC.case_conv_patch_upsampled("cpu", 1, 4, 4, 64, 64, tile) if tile in (71, 72, 76) else None
+
+
+@pytest.mark.parametrize("B,H,Nq,Nk,D", [(1, 2, 70, 300, 40), (1, 2, 640, 77, 40), (1, 1, 150, 200, 64)])
+def test_attention_zero_latency_dma(B, H, Nq, Nk, D, zero_latency_dma):
+    KC.case_attention("cpu", B, H, Nq, Nk, D)
+
+
 @pytest.mark.parametrize("D", [40, 80])
 def test_attention_rising_maxima(D):
     """forward: lazy exponent reference, rebased on later KV tiles for a subset of the queries (D = 40: rowsum from the ones column)"""
