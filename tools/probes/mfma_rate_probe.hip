@@ -9,6 +9,9 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef float f16v __attribute__((ext_vector_type(16)));
 
+// The MFMAs are inline asm on "+v" accumulators: the compiler can neither merge the identical chains nor move the
+// accumulators between the VGPR and AGPR files inside the loop (both happened with the builtins and made the first
+// version of this probe meaningless).
 template <int MODE>
 __global__ __launch_bounds__(256) void k(float* out, int iters) {
     const int l = threadIdx.x;
@@ -19,24 +22,24 @@ __global__ __launch_bounds__(256) void k(float* out, int iters) {
     float r = 0.f;
     if (MODE == 0 || MODE == 1) {
         f4 acc[8];
-        for (int i = 0; i < 8; ++i) acc[i] = f4{(float)i, 0.f, (float)l, 0.f};       // distinct chains: no CSE across accumulators
+        for (int i = 0; i < 8; ++i) acc[i] = f4{(float)i, 0.f, (float)l, 0.f};
         for (int it = 0; it < iters; ++it) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                if (MODE == 0) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a8, b8, acc[i], 0, 0, 0);
-                else acc[i] = __builtin_amdgcn_mfma_f32_16x16x16f16(a4, b4, acc[i], 0, 0, 0);
+                if (MODE == 0) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a8), "v"(b8));
+                else asm volatile("v_mfma_f32_16x16x16_f16 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a4), "v"(b4));
             }
         }
         for (int i = 0; i < 8; ++i) r += acc[i][0] + acc[i][3];
     } else {
         f16v acc[4];
         for (int i = 0; i < 4; ++i)
-            for (int e = 0; e < 16; ++e) acc[i][e] = (float)(i + e);                  // distinct chains
+            for (int e = 0; e < 16; ++e) acc[i][e] = (float)(i + e);
         for (int it = 0; it < iters; ++it) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                if (MODE == 2) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a8, b8, acc[i], 0, 0, 0);
-                else acc[i] = __builtin_amdgcn_mfma_f32_32x32x8f16(a4, b4, acc[i], 0, 0, 0);
+                if (MODE == 2) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a8), "v"(b8));
+                else asm volatile("v_mfma_f32_32x32x8_f16 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a4), "v"(b4));
             }
         }
         for (int i = 0; i < 4; ++i) r += acc[i][0] + acc[i][15];
