@@ -27,6 +27,7 @@ struct GemmArgs {
     int lda, ldc, M, N, K;
     int k_per_split;
     int tiles_n;
+    int tiles_m, n_major;      // n_major: logical tile t = n * tiles_m + m (else m * tiles_n + n); see pick_tile_order
     clora_conv_t conv;
     clora_epilogue_t epi;
 };
@@ -522,7 +523,7 @@ __global__ __launch_bounds__(WM * WN * 64, (DmaOcc<BM, BN, NST, BK, WM * WN>::v)
     const int xq = nwg >> 3, xr = nwg & 7, xcd = lin & 7;
     const int logical = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (lin >> 3);
     const int split = logical / tiles, tile = logical - split * tiles;
-    const int tile_m = tile / p.tiles_n, tile_n = tile % p.tiles_n;
+    const int tile_m = p.n_major ? tile % p.tiles_m : tile / p.tiles_n, tile_n = p.n_major ? tile / p.tiles_m : tile % p.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int kbeg = split * p.k_per_split;
     const int kend = (kbeg + p.k_per_split < p.K) ? kbeg + p.k_per_split : p.K;
@@ -738,7 +739,7 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void conv3x3_patch_kernel(GemmArgs
     const int xq = nwg >> 3, xr = nwg & 7, xcd = lin & 7;
     const int logical = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (lin >> 3);
     const int split = logical / tiles, tile = logical - split * tiles;
-    const int tile_m = tile / p.tiles_n, tile_n = tile % p.tiles_n;
+    const int tile_m = p.n_major ? tile % p.tiles_m : tile / p.tiles_n, tile_n = p.n_major ? tile / p.tiles_m : tile % p.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int w = t >> 6, l = t & 63, g = l >> 4, li = l & 15;
     const int wm = w / WN, wn = w % WN;
@@ -1110,10 +1111,65 @@ int conv_mode(const GemmArgs& a, int bk) {
     return fast ? 2 : 1;
 }
 
+// Which XCD fetches what.  Workgroup L runs on XCD L % 8 (tools/probes/xcc_map_probe.hip) and the kernels hand every XCD a
+// contiguous range of logical tiles.  A panel of A rows / B rows is fetched through the fabric once per XCD that touches it:
+// sharers on one XCD are served by one fetch, sharers on different XCDs are not, and the MALL multiplies nothing
+// (profiles/r02_l2_share_probe.txt).  m-major ranges (n fastest) fetch A about once and B up to eight times -- right for the
+// 64x64 / 32x32 levels (activations 5-30 MB, weights 2-7 MB); at 16x16 / 8x8 the weights are 29-59 MB against 1-3 MB of
+// activations and n-major ranges (m fastest) are the cheaper assignment.  The model counts, per XCD and split, the distinct
+// panels of its range under either order.   g_tile_order: 0 m-major always (default until A/B-measured), 1 n-major always
+// (tests), 2 pick by the model.
+int g_tile_order = -1;
+int tile_order_mode() {
+    if (g_tile_order < 0) {
+        const char* e = getenv("CLORA_TILE_ORDER");
+        g_tile_order = !e ? 0 : (e[0] == 'n' ? 1 : (e[0] == 'a' ? 2 : 0));
+    }
+    return g_tile_order;
+}
+
+double fabric_model_bytes(int tiles_m, int tiles_n, int splits, double a_panel, double b_panel, bool n_major) {
+    const int tiles = tiles_m * tiles_n, nwg = tiles * splits;
+    const int inner = n_major ? tiles_m : tiles_n;
+    const int xq = nwg >> 3, xr = nwg & 7;
+    double bytes = 0.0;
+    int beg = 0;
+    for (int x = 0; x < 8; ++x) {
+        const int end = beg + xq + (x < xr ? 1 : 0);
+        for (int sp = beg / tiles; sp * tiles < end && sp < splits; ++sp) {
+            const int t0 = (beg > sp * tiles ? beg : sp * tiles) - sp * tiles, t1 = (end < (sp + 1) * tiles ? end : (sp + 1) * tiles) - sp * tiles;
+            if (t1 <= t0) continue;
+            const int outer = (t1 - 1) / inner - t0 / inner + 1;
+            const int inn = (t1 - t0 < inner) ? t1 - t0 : inner;
+            bytes += n_major ? outer * b_panel + inn * a_panel : outer * a_panel + inn * b_panel;
+        }
+        beg = end;
+    }
+    return bytes;
+}
+
+void pick_tile_order(GemmArgs& a, int BM, int BN, int splits, bool patch) {
+    a.tiles_m = clora_cdiv(a.M, BM);
+    a.n_major = 0;
+    const int mode = tile_order_mode();
+    if (mode == 0 || a.tiles_m == 1 || a.tiles_n == 1) return;
+    if (mode == 1) { a.n_major = 1; return; }
+    // bytes of one panel per split: the implicit-GEMM conv re-reads its input rows per tap from L2, the fabric sees them once
+    // (x ~1.5 halo); the patch kernel counts k_per_split in 64-channel slabs
+    const double kper = patch ? (double)a.k_per_split * 576 : (double)a.k_per_split;
+    const double a_panel = a.conv.enabled && a.conv.ksize == 3 ? BM * (kper / 9.0) * 2.0 * 1.5 : BM * kper * 2.0;
+    const double b_panel = BN * kper * 2.0;
+    const double m_cost = fabric_model_bytes(a.tiles_m, a.tiles_n, splits, a_panel, b_panel, false);
+    const double n_cost = fabric_model_bytes(a.tiles_m, a.tiles_n, splits, a_panel, b_panel, true);
+    a.n_major = n_cost < 0.85 * m_cost;
+}
+
 template <int BM, int BN, int WM, int WN, int NST = 3, int BK = 32, int FLAGS = 0>
 int launch_gemm(GemmArgs& a, int splits, hipStream_t s, bool dma) {
     a.tiles_n = clora_cdiv(a.N, BN);
     const int tiles_m = clora_cdiv(a.M, BM);
+    pick_tile_order(a, BM, BN, splits, false);
+    if (!dma) a.n_major = 0;                                       // the v1 loop decodes blockIdx directly
     const dim3 grid(tiles_m * a.tiles_n, splits);
     if (dma) {
         const int cm = conv_mode(a, BK);
@@ -1148,6 +1204,7 @@ bool patch_eligible(const GemmArgs& a, int bm) {
 template <int BM, int BN, int WM, int WN, int NST>
 int launch_patch(GemmArgs& a, int splits, hipStream_t s) {
     a.tiles_n = clora_cdiv(a.N, BN);
+    pick_tile_order(a, BM, BN, splits, true);
     const dim3 grid(clora_cdiv(a.M, BM) * a.tiles_n, splits);
     hipLaunchKernelGGL((conv3x3_patch_kernel<BM, BN, WM, WN, NST>), grid, dim3(WM * WN * 64), 0, s, a);
     return clora_check_launch();
@@ -1195,6 +1252,7 @@ extern "C" int clora_gemm_f16_ex(const clora_half* A, int lda, const clora_half*
     GemmArgs a;
     a.A = (const half_t*)A; a.B = (const half_t*)B; a.C = (half_t*)C; a.partial = nullptr;
     a.lda = lda; a.ldc = ldc; a.M = M; a.N = N; a.K = K;
+    a.tiles_m = 0; a.n_major = 0;
     if (conv && conv->enabled) {
         a.conv = *conv;
         if ((conv->Cin & 7) || K != conv->ksize * conv->ksize * conv->Cin) return CLORA_ERR_ARG;
@@ -1349,6 +1407,12 @@ extern "C" int clora_gemm_f16_ex(const clora_half* A, int lda, const clora_half*
         rc = clora_check_launch();
     }
     return rc;
+}
+
+extern "C" int clora_set_tile_order(int mode) {
+    if (mode < 0 || mode > 2) return CLORA_ERR_ARG;
+    g_tile_order = mode;
+    return CLORA_OK;
 }
 
 extern "C" int clora_conv_patch_eligible(int M, const clora_conv_t* conv, int tile_cfg) {

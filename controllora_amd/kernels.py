@@ -193,6 +193,14 @@ def conv_patch_eligible(M: int, conv: ConvDesc, tile_cfg: int) -> bool:
     return bool(capi.lib().cdll.clora_conv_patch_eligible(M, C.byref(conv), tile_cfg))
 
 
+TILE_ORDERS = {"m": 0, "n": 1, "auto": 2}
+
+
+def set_tile_order(mode: str) -> None:
+    """tile -> XCD assignment of the GEMM / conv launches that follow: "m" (default), "n", or "auto" (clora_set_tile_order)."""
+    capi.lib().call("clora_set_tile_order", TILE_ORDERS[mode])
+
+
 def conv_wgrad(dY: torch.Tensor, X: torch.Tensor, M: int, N: int, K: int, conv: Optional[ConvDesc],
                ldx: Optional[int] = None, with_bias: bool = False):
     """dW [N, K] (and the bias gradient [N] when with_bias) of a trainable conv / linear, one pass over dY and X."""

@@ -109,6 +109,12 @@ int clora_gemm_f16_ex(const clora_half* A, int lda, const clora_half* B, clora_h
  * reference op is the same F.conv2d of upstream ResnetBlock2D; tuner / tests use this to know what they time. */
 int clora_conv_patch_eligible(int M, const clora_conv_t* conv, int tile_cfg);
 
+/* Tuning knob, no reference counterpart (results do not depend on it): how clora_gemm_f16[_ex] assigns output tiles to the
+ * eight XCDs.  0 = every XCD a contiguous range of tiles in m-major order (default; also CLORA_TILE_ORDER unset / "m"),
+ * 1 = n-major ("n"), 2 = per launch whichever order fetches fewer distinct A / B panels per XCD ("auto").  Process-wide;
+ * takes effect for the launches that follow (a captured hipGraph keeps the order it was captured with). */
+int clora_set_tile_order(int mode);
+
 /* dW[N, K] += dY[M,N]^T . gather(X)[M,K] and (db != NULL) db[N] += column sums of dY  (fp32 atomics; caller
  * zeroes dW / db).
  * Weight gradient of the trainable hint-encoder convolutions (reference models.py:470,529,594-597,684:

@@ -158,6 +158,43 @@ def case_conv_patch(dev, Bn, H, W, Ci, Co, tile_cfg, seed=12):
             assert rel(dx, xin.grad.permute(0, 2, 3, 1).reshape(M, Ci)) < 6e-4, (sk,)
 
 
+def case_tile_order(dev, tile_cfg, order, seed=21):
+    """the tile -> XCD assignment permutes which workgroup computes which tile and nothing else: plain GEMM with split-K and the
+    adapter epilogue, and a 3x3 conv (patch kernel for tile_cfg 71..76), give the same bits under every order"""
+    from controllora_amd.ops import conv_k_order
+    g = torch.Generator().manual_seed(seed)
+    M, N, K_ = 600, 336, 192                       # several tiles each way, ragged edges (N % 16 == 0 for the adapter epilogue)
+    A, B = rnd((M, K_), dev, g), rnd((N, K_), dev, g, 1 / math.sqrt(K_))
+    bias, res = rnd((N,), dev, g, dtype=f32), rnd((M, N), dev, g)
+    T, U = rnd((M, 4), dev, g, dtype=f32), rnd((N, 4), dev, g, dtype=f32)
+    Bn, H, W, Ci, Co = 4, 8, 8, 128, 136
+    x = rnd((Bn * H * W, Ci), dev, g)
+    w = conv_k_order(rnd((Co, 9, Ci), dev, g, 1 / math.sqrt(Ci * 9)), 64)
+    cd, _, _ = K.conv_fwd_desc(H, W, Ci, 3, 1, 1, kchunk=64)
+    patch = tile_cfg >= 71
+
+    def run():
+        outs = []
+        if not patch:
+            for sk in (1, 3):
+                outs.append(K.gemm(A, B, M, N, K_, split_k=sk, tile_cfg=tile_cfg))
+            outs.append(K.gemm(A, B, M, N, K_, bias=bias, residual=res, lora_t=T, lora_u=U, lora_scale=0.5, split_k=1, tile_cfg=tile_cfg))
+        for sk in (1, 2):
+            outs.append(K.gemm(x, w, Bn * H * W, Co, 9 * Ci, conv=cd, tile_cfg=tile_cfg, split_k=sk))
+        return outs
+
+    try:
+        K.set_tile_order("m")
+        base = run()
+        K.set_tile_order(order)
+        other = run()
+    finally:
+        K.set_tile_order("m")
+    assert rel(base[0], A.float() @ B.float().T) < 6e-4 if not patch else True
+    for a, b in zip(base, other):
+        assert torch.equal(a, b)
+
+
 def case_conv_padded_channels(dev, seed=9):
     """3 -> padded 8 input channels (the hint encoder's conv_in): packing pads with zeros, the OIHW gradient drops them"""
     g = torch.Generator().manual_seed(seed)

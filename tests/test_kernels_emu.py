@@ -45,6 +45,13 @@ def test_gemm_tile_configs(tile):
     KC.case_conv("cpu", 1, 8, 8, 16, 24, tile_cfg=tile)
 
 
+@pytest.mark.parametrize("order", ["n", "auto"])
+@pytest.mark.parametrize("tile", [21, 43, 53, 72, 76])
+def test_tile_order_does_not_change_results(tile, order):
+    """the tile -> XCD assignment (clora_set_tile_order) only permutes which workgroup computes which tile: bit-identical outputs"""
+    KC.case_tile_order("cpu", tile, order)
+
+
 @pytest.mark.parametrize("tile", [71, 72, 73, 74, 75, 76])
 @pytest.mark.parametrize("Bn,H,W,Ci,Co", [(2, 8, 8, 128, 64), (1, 16, 16, 64, 72), (3, 4, 4, 64, 64)])
 def test_conv_patch_kernel(tile, Bn, H, W, Ci, Co):
