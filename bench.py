@@ -44,6 +44,10 @@ def hot_path_tflop_per_image(res):
     cfg = json.load(open(os.path.join(ROOT, "configs", "fill50k.json")))
     return R.train_step_flops_per_image(res, cfg, 1.51 * (res / 512) ** 2)["total"] / 1e12
 MFMA_PEAK_TFLOPS = 2500.0                # dense fp16, MI355X_MICROARCH.md
+# measured ceilings of this chip (stand-alone probes, profiles/r02_{mfma_rate,stream_rate}_probe.txt): reported beside `frac`,
+# never instead of it
+MFMA_SUSTAINED_TFLOPS = 1860.0           # v_mfma_f32_16x16x32_f16 back to back on every SIMD
+FABRIC_TBS = 6.3                         # L2 <- MALL / HBM stream, all XCDs
 HBM_PEAK_GBS = 8000.0
 
 
@@ -353,7 +357,7 @@ def main():
         # (tools/pmc_traffic.sh -> tools/pmc_summary.py); the committed result of the latest passes is reported with
         # "static": true and the commit / round it was measured at -- it does not move with this run.
         traffic, traffic_src = None, None
-        pmc_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+        pmc_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic*.json")))
         if dom_name.startswith("clora_gemm") and pmc_files:
             pmc = json.load(open(pmc_files[-1]))
             ks = [v for k, v in pmc["kernels"].items() if any(t in k for t in GEMM_FAMILY)]
@@ -373,6 +377,11 @@ def main():
                     "event_timed": {"achieved": round(ev_ach, 1), "frac": round(ev_ach / MFMA_PEAK_TFLOPS, 4),
                                     "family_ms": round(dom["ms"], 3), "all_kernels_ms": round(ev_total_ms, 2),
                                     "note": "HIP events around each eager launch: includes launch gaps, upper bound on kernel time"},
+                    "measured_ceilings": {"mfma_sustained_TFLOPs": MFMA_SUSTAINED_TFLOPS, "frac_of_sustained": round(ach / MFMA_SUSTAINED_TFLOPS, 4),
+                                          "fabric_TB_per_s": FABRIC_TBS,
+                                          "traffic_time_share": (round(traffic / (FABRIC_TBS * 1e12) / (fam_ms * 1e-3 / max(1, fam_launches)), 3)
+                                                                 if traffic else None),
+                                          "source": "tools/probes/{mfma_rate,stream_rate}_probe.hip, profiles/r02_*_probe.txt"},
                     "families": fam, "kernel_trace": kt,
                     "whole_step_frac_of_mfma_peak": round(
                         images_per_s / world * hot_path_tflop_per_image(args.res) / MFMA_PEAK_TFLOPS, 4),
