@@ -38,7 +38,23 @@ struct AttnArgs {
     float scale;
     int nsplit, q_per_split;   // dK/dV: split the query loop over grid.z (cross-attention: few keys, many queries)
     float* acc32;              // [2][B, Nk, H*D] fp32 accumulators for the split path
+    int xcd_heads;             // block order: whole (batch, head) pairs per XCD (see attn_block_ids)
 };
+
+// The blocks of one (batch, head) read the same K / V (forward, dQ) or Q / dO (dK/dV) stream.  Workgroup L runs on XCD L % 8
+// and a line is fetched through the fabric once per XCD that asks for it (tools/probes/l2_share_probe.hip): in launch order
+// the blocks of a head sit on all eight XCDs.  With xcd_heads every XCD walks a contiguous range of (head, block) pairs, so
+// a head's stream is fetched by one XCD (two at a range boundary).  Same remap as the GEMM tile order; results do not change.
+__device__ __forceinline__ void attn_block_ids(const AttnArgs& p, int& bx, int& by) {
+    bx = blockIdx.x; by = blockIdx.y;
+    if (!p.xcd_heads || gridDim.z != 1) return;
+    const int nx = gridDim.x, nwg = nx * gridDim.y;
+    const int lin = by * nx + bx;
+    const int xq = nwg >> 3, xr = nwg & 7, xcd = lin & 7;
+    const int logical = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (lin >> 3);
+    by = logical / nx;
+    bx = logical - by * nx;
+}
 
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kLn2 = 0.6931471805599453f;
@@ -141,8 +157,10 @@ __global__ __launch_bounds__(NWV * 64, (DP <= 64 ? (NWV == 4 ? 3 : 2) : 1)) void
     constexpr int TILE = BKV * LDK + BKV * LDV;           // one K tile + one V tile; two of them: double buffer
     __shared__ __attribute__((aligned(16))) half_t smem[2 * TILE];
     const int t = threadIdx.x, w = t >> 6, l = t & 63, g = l >> 4, li = l & 15;
-    const int b = blockIdx.y / p.H, h = blockIdx.y % p.H;
-    const int q0 = blockIdx.x * (NWV * 32) + w * 32;
+    int bx, by;
+    attn_block_ids(p, bx, by);
+    const int b = by / p.H, h = by % p.H;
+    const int q0 = bx * (NWV * 32) + w * 32;
     const int D = p.D;
     const float c = p.scale * kLog2e;
 
@@ -296,8 +314,10 @@ __global__ __launch_bounds__(NWV * 64, (DP <= 64 && NWV == 4 ? 2 : 1)) void attn
     constexpr int TILE = 2 * BKV * LDK;                    // K tile + V tile; double buffered (see TileDma)
     __shared__ __attribute__((aligned(16))) half_t smem[2 * TILE];
     const int t = threadIdx.x, w = t >> 6, l = t & 63, g = l >> 4, li = l & 15;
-    const int b = blockIdx.y / p.H, h = blockIdx.y % p.H;
-    const int q0 = blockIdx.x * (NWV * 32) + w * 32;
+    int bx, by;
+    attn_block_ids(p, bx, by);
+    const int b = by / p.H, h = by % p.H;
+    const int q0 = bx * (NWV * 32) + w * 32;
     const int D = p.D;
     const half_t* kbase = p.k + (size_t)b * p.Nk * p.ldk + h * D;
     const half_t* vbase = p.v + (size_t)b * p.Nk * p.ldv + h * D;
@@ -448,8 +468,10 @@ __global__ __launch_bounds__(NWV * 64, (DP <= 64 && NWV == 4 ? 2 : 1)) void attn
     __shared__ __attribute__((aligned(16))) half_t smem[2 * TILE + 2 * 4 * BQT];
     float* LD_ = reinterpret_cast<float*>(smem + 2 * TILE);   // [2 buffers][-LSE*log2e (BQT) | -delta (BQT)]
     const int t = threadIdx.x, w = t >> 6, l = t & 63, g = l >> 4, li = l & 15;
-    const int b = blockIdx.y / p.H, h = blockIdx.y % p.H;
-    const int k0 = blockIdx.x * (NWV * 32) + w * 32;
+    int bx, by;
+    attn_block_ids(p, bx, by);
+    const int b = by / p.H, h = by % p.H;
+    const int k0 = bx * (NWV * 32) + w * 32;
     const int D = p.D;
     const float c = p.scale * kLog2e;
 
@@ -688,6 +710,7 @@ extern "C" int clora_attn_fwd_f16(const clora_half* q, int ldq, const clora_half
                                   float scale, void* stream) {
     if (!q || !k || !v || !o || bad_dims(B, H, Nq, Nk, D) || ((ldq | ldk | ldv | ldo) & 7)) return CLORA_ERR_ARG;
     AttnArgs a = AttnArgs();
+    a.xcd_heads = clora_xcd_policy() != 0;
     a.q = (const half_t*)q; a.k = (const half_t*)k; a.v = (const half_t*)v; a.out = (half_t*)o; a.lse = lse;
     a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
     a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.D = D; a.scale = scale;
@@ -706,6 +729,7 @@ extern "C" int clora_attn_bwd_f16(const clora_half* q, int ldq, const clora_half
         ((ldq | ldk | ldv | ldo | lddo | lddq | lddk | lddv) & 7))
         return CLORA_ERR_ARG;
     AttnArgs a = AttnArgs();
+    a.xcd_heads = clora_xcd_policy() != 0;
     a.q = (const half_t*)q; a.k = (const half_t*)k; a.v = (const half_t*)v; a.o = (const half_t*)o;
     a.dO = (const half_t*)dO; a.lse_in = lse; a.delta = delta;
     a.dq = (half_t*)dq; a.dk = (half_t*)dk; a.dv = (half_t*)dv;

@@ -1409,6 +1409,8 @@ extern "C" int clora_gemm_f16_ex(const clora_half* A, int lda, const clora_half*
     return rc;
 }
 
+int clora_xcd_policy() { return tile_order_mode(); }
+
 extern "C" int clora_set_tile_order(int mode) {
     if (mode < 0 || mode > 2) return CLORA_ERR_ARG;
     g_tile_order = mode;

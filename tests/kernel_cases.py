@@ -263,6 +263,31 @@ def case_attention(dev, B, H, Nq, Nk, D, seed=3, fused_qkv=False, tol=2e-3, ramp
         assert e < 2 * tol, (name, e)
 
 
+def case_attention_block_order(dev, B, H, Nq, Nk, D, seed=23):
+    """whole heads per XCD (clora_set_tile_order != "m") only permutes which workgroup handles which (head, block): the forward
+    output, LSE and the three gradients are bit-identical; the grid (3 x 6 blocks at Nq = 300, B*H = 6) is not a multiple of 8"""
+    g = torch.Generator().manual_seed(seed)
+    scale = D ** -0.5
+    q2, k2, v2 = rnd((B * Nq, H * D), dev, g), rnd((B * Nk, H * D), dev, g), rnd((B * Nk, H * D), dev, g)
+    dO = rnd((B * Nq, H * D), dev, g)
+
+    def run():
+        o, lse = K.attn_fwd(q2, k2, v2, B, H, Nq, Nk, D, scale)
+        dq, dk, dv = torch.empty_like(q2), torch.empty_like(k2), torch.empty_like(v2)
+        K.attn_bwd(q2, k2, v2, o, dO, lse, B, H, Nq, Nk, D, scale, dq, dk, dv)
+        return o, lse, dq, dk, dv
+
+    try:
+        K.set_tile_order("m")
+        base = run()
+        K.set_tile_order("auto")
+        other = run()
+    finally:
+        K.set_tile_order("m")
+    for a, b_ in zip(base, other):
+        assert torch.equal(a, b_)
+
+
 def case_groupnorm(dev, B, HW, C, G, silu, eps=1e-5, seed=4, train_params=False):
     g = torch.Generator().manual_seed(seed)
     x = (rnd((B, HW, C), dev, g).float() * 1.5 + 0.3).half()

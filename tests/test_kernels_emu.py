@@ -106,6 +106,11 @@ def test_attention_zero_latency_dma(B, H, Nq, Nk, D, zero_latency_dma):
     KC.case_attention("cpu", B, H, Nq, Nk, D)
 
 
+@pytest.mark.parametrize("B,H,Nq,Nk,D", [(2, 3, 300, 300, 40), (1, 5, 200, 77, 80), (3, 1, 130, 130, 160)])
+def test_attention_block_order_does_not_change_results(B, H, Nq, Nk, D):
+    KC.case_attention_block_order("cpu", B, H, Nq, Nk, D)
+
+
 @pytest.mark.parametrize("D", [40, 80])
 def test_attention_rising_maxima(D):
     """forward: lazy exponent reference, rebased on later KV tiles for a subset of the queries (D = 40: rowsum from the ones column)"""

@@ -68,6 +68,18 @@ def test_conv_patch_kernel_upsampled(tile, Bn, H, Ci):
     KC.case_conv_patch_upsampled(DEV, Bn, H, H, Ci, Ci, tile)
 
 
+@pytest.mark.parametrize("order", ["n", "auto"])
+@pytest.mark.parametrize("tile", [21, 43, 53, 58, 72, 76])
+def test_tile_order_does_not_change_results(tile, order):
+    """clora_set_tile_order: which XCD computes which tile is a permutation -- bit-identical GEMM / conv outputs"""
+    KC.case_tile_order(DEV, tile, order)
+
+
+@pytest.mark.parametrize("B,H,Nq,Nk,D", [(2, 8, 4096, 4096, 40), (2, 8, 1024, 77, 80), (3, 5, 300, 300, 160)])
+def test_attention_block_order_does_not_change_results(B, H, Nq, Nk, D):
+    KC.case_attention_block_order(DEV, B, H, Nq, Nk, D)
+
+
 @pytest.mark.parametrize("B,H,Nq,Nk,D,fused", [
     (1, 8, 4096, 4096, 40, True), (2, 8, 4096, 77, 40, False), (2, 8, 1024, 1024, 80, True), (2, 8, 1024, 77, 80, False),
     (2, 8, 256, 256, 160, True), (2, 8, 64, 77, 160, False), (1, 2, 70, 70, 40, True), (1, 1, 150, 77, 64, False),

@@ -60,6 +60,14 @@ for Bn, H, W, Ci, Co in CONVS:
     w = (torch.randn(Co, 9 * Ci, device=dev) / math.sqrt(9 * Ci)).half()
     out = torch.empty(M, Co, device=dev, dtype=torch.float16)
     ab(f"conv3x3 {H}x{W} {Ci}->{Co}", lambda: K.gemm(x, w, M, Co, 9 * Ci, conv=cd, out=out), 2.0 * M * Co * 9 * Ci)
+# attention: whole heads per XCD ("auto" / "n") against launch order ("m")
+for B, H, Nq, Nk, D in [(4, 8, 4096, 4096, 40), (4, 8, 1024, 1024, 80), (4, 8, 256, 256, 160), (32, 8, 4096, 4096, 40)]:
+    q, k, v = (torch.randn(B * n, H * D, device=dev).half() for n in (Nq, Nk, Nk))
+    dO = torch.randn(B * Nq, H * D, device=dev).half()
+    o, lse = K.attn_fwd(q, k, v, B, H, Nq, Nk, D, D ** -0.5)
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    ab(f"attn_fwd B{B} N{Nq} D{D}", lambda: K.attn_fwd(q, k, v, B, H, Nq, Nk, D, D ** -0.5), 4.0 * B * H * Nq * Nk * D)
+    ab(f"attn_bwd B{B} N{Nq} D{D}", lambda: K.attn_bwd(q, k, v, o, dO, lse, B, H, Nq, Nk, D, D ** -0.5, dq, dk, dv), 10.0 * B * H * Nq * Nk * D)
 if args.json:
     json.dump({"what": "tools/tile_order_ab.py: us per launch under each tile -> XCD order, table-chosen tile / split-K", "rows": rows},
               open(args.json, "w"), indent=1)
