@@ -67,7 +67,7 @@ _PROTOS = {
     "clora_gemm_f16": [_P, _I, _P, _P, _I, _I, _I, _I, C.POINTER(ConvDesc), C.POINTER(Epilogue), _I, _P, _Z, _P],
     "clora_gemm_f16_ex": [_P, _I, _P, _P, _I, _I, _I, _I, C.POINTER(ConvDesc), C.POINTER(Epilogue), _I, _I, _P, _Z, _P],
     "clora_conv_patch_eligible": [_I, C.POINTER(ConvDesc), _I],
-    "clora_set_tile_order": [_I],
+    "clora_set_option": [C.c_char_p, _I],
     "clora_conv_wgrad_f16": [_P, _I, _P, _I, _P, _P, _I, _I, _I, C.POINTER(ConvDesc), _I, _P],
     "clora_conv_weight_pack_f32": [_P, _I, _I, _I, _I, _I, _P, _P, _P],
     "clora_conv_wgrad_unpack_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _P],

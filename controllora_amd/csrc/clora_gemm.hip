@@ -14,6 +14,7 @@
 // (conflict-free ds_read_b128 fragments from unpadded rows), XCD-aware tile order, accumulators staged through LDS in
 // the epilogue so C / residual traffic is 16-byte coalesced.  split-K (grid.y) writes fp32 slabs that a second kernel
 // reduces + finishes.  gemm_kernel below is the round-1 register-staged loop, kept for A/B runs (tile_cfg 11..13).
+#include <string.h>
 #include "clora_common.h"
 #include "../../include/clora.h"
 
@@ -1411,10 +1412,28 @@ extern "C" int clora_gemm_f16_ex(const clora_half* A, int lda, const clora_half*
 
 int clora_xcd_policy() { return tile_order_mode(); }
 
-extern "C" int clora_set_tile_order(int mode) {
-    if (mode < 0 || mode > 2) return CLORA_ERR_ARG;
-    g_tile_order = mode;
-    return CLORA_OK;
+static int g_ln_rows = -1;
+int clora_ln_rows() {
+    if (g_ln_rows < 0) {
+        const char* e = getenv("CLORA_LN_ROWS");
+        g_ln_rows = (e && atoi(e) > 0) ? 1 : 0;
+    }
+    return g_ln_rows;
+}
+
+extern "C" int clora_set_option(const char* name, int value) {
+    if (!name) return CLORA_ERR_ARG;
+    if (!strcmp(name, "tile_order")) {
+        if (value < 0 || value > 2) return CLORA_ERR_ARG;
+        g_tile_order = value;
+        return CLORA_OK;
+    }
+    if (!strcmp(name, "ln_rows")) {
+        if (value < 0 || value > 1) return CLORA_ERR_ARG;
+        g_ln_rows = value;
+        return CLORA_OK;
+    }
+    return CLORA_ERR_ARG;
 }
 
 extern "C" int clora_conv_patch_eligible(int M, const clora_conv_t* conv, int tile_cfg) {

@@ -416,6 +416,130 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs p) {
     }
 }
 
+// Several rows per wave.  One row of C = 320 is 640 bytes: with a single row per wave a CU has ~20 KB in flight and the
+// kernel sits at a third of the fabric rate (profiles/r02_stream_rate_probe.txt vs r02_kernel_stats_final.json: 17 us for
+// 42 MB).  Here a wave issues the loads of ROWS rows (and gamma / beta, once) before the first reduction; per row the
+// arithmetic and its order are exactly those of layernorm_kernel, so the results are bit-identical.
+//   NC = 16-byte chunks per lane (C <= 512: 1, <= 1024: 2, <= 1536: 3)
+template <bool BWD, int NC, int ROWS>
+__global__ __launch_bounds__(256) void layernorm_rows_kernel(LnArgs p) {
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int row0 = (blockIdx.x * 4 + w) * ROWS;
+    if (row0 >= p.M) return;                                     // wave-uniform
+    const int CH = p.C / 8;
+    half8 xv[ROWS][NC], gv[ROWS][NC], rv[ROWS][NC];
+    float gam[NC][8], bet[NC][8];
+    const bool has_res = BWD && p.dres != nullptr;               // kernel-uniform
+    const half_t* res = has_res ? p.dres : p.x;                  // a valid address either way: the loads stay unconditional
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        const bool rok = row0 + r < p.M;
+        const size_t off = (size_t)(rok ? row0 + r : row0) * p.C;
+#pragma unroll
+        for (int j = 0; j < NC; ++j) {                           // branch-free: lanes past the row re-read chunk 0 (never used),
+            const int cc = l + 64 * j, cl = cc < CH ? cc : 0;    // so every load of the wave is issued back to back
+            xv[r][j] = ld8(p.x + off + cl * 8);
+            if (BWD) { gv[r][j] = ld8(p.dy + off + cl * 8); rv[r][j] = ld8(res + off + cl * 8); }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+        const int cc = l + 64 * j, cl = cc < CH ? cc : 0;
+        const floatx4 g0 = *reinterpret_cast<const floatx4*>(p.gamma + cl * 8), g1 = *reinterpret_cast<const floatx4*>(p.gamma + cl * 8 + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { gam[j][e] = g0[e]; gam[j][4 + e] = g1[e]; bet[j][e] = 0.f; bet[j][4 + e] = 0.f; }
+        if (!BWD) {
+            const floatx4 b0 = *reinterpret_cast<const floatx4*>(p.beta + cl * 8), b1 = *reinterpret_cast<const floatx4*>(p.beta + cl * 8 + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { bet[j][e] = b0[e]; bet[j][4 + e] = b1[e]; }
+        }
+    }
+    float mean[ROWS], rstd[ROWS];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < NC; ++j)
+            if (l + 64 * j < CH) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s += (float)xv[r][j][e];
+            }
+        mean[r] = wave_sum(s) / (float)p.C;
+    }
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < NC; ++j)
+            if (l + 64 * j < CH) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float d = (float)xv[r][j][e] - mean[r]; q += d * d; }
+            }
+        rstd[r] = rsqrtf(wave_sum(q) / (float)p.C + p.eps);
+    }
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        const bool rok = row0 + r < p.M;
+        const size_t off = (size_t)(rok ? row0 + r : row0) * p.C;
+        if (!BWD) {
+#pragma unroll
+            for (int j = 0; j < NC; ++j) {
+                const int cc = l + 64 * j;
+                if (cc < CH && rok) {
+                    half8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = (half_t)(((float)xv[r][j][e] - mean[r]) * rstd[r] * gam[j][e] + bet[j][e]);
+                    st8(p.y + off + cc * 8, o);
+                }
+            }
+        } else {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int j = 0; j < NC; ++j)
+                if (l + 64 * j < CH) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float gg = (float)gv[r][j][e] * gam[j][e];
+                        s1 += gg;
+                        s2 += gg * ((float)xv[r][j][e] - mean[r]) * rstd[r];
+                    }
+                }
+            s1 = wave_sum(s1) / (float)p.C;
+            s2 = wave_sum(s2) / (float)p.C;
+#pragma unroll
+            for (int j = 0; j < NC; ++j) {
+                const int cc = l + 64 * j;
+                if (cc < CH && rok) {
+                    half8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float xh = ((float)xv[r][j][e] - mean[r]) * rstd[r];
+                        o[e] = (half_t)(rstd[r] * ((float)gv[r][j][e] * gam[j][e] - s1 - xh * s2));
+                    }
+                    if (has_res) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o[e] = (half_t)((float)o[e] + (float)rv[r][j][e]);
+                    }
+                    st8(p.y + off + cc * 8, o);
+                }
+            }
+        }
+    }
+}
+
+template <bool BWD>
+void launch_layernorm(const LnArgs& a, hipStream_t s) {
+    const int CH = a.C / 8;
+    const bool al16 = (((uintptr_t)a.gamma | (uintptr_t)(BWD ? a.gamma : a.beta)) & 15) == 0;
+    if (clora_ln_rows() && CH <= 192 && a.M >= 2048 && al16) {           // enough rows to keep the chip full with fewer, fatter waves
+        if (CH <= 64) hipLaunchKernelGGL((layernorm_rows_kernel<BWD, 1, 4>), dim3(clora_cdiv(a.M, 16)), dim3(256), 0, s, a);
+        else if (CH <= 128) hipLaunchKernelGGL((layernorm_rows_kernel<BWD, 2, 2>), dim3(clora_cdiv(a.M, 8)), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((layernorm_rows_kernel<BWD, 3, 2>), dim3(clora_cdiv(a.M, 8)), dim3(256), 0, s, a);
+        return;
+    }
+    hipLaunchKernelGGL((layernorm_kernel<BWD>), dim3(clora_cdiv(a.M, 4)), dim3(256), 0, s, a);
+}
+
 // ------------------------------------------------------------------------------------------ row softmax
 // y[r, :] = softmax(scale * x[r, :]) for the single-head d=512 attention of the VAE mid block (upstream
 // AutoencoderKL AttentionBlock; reference call sites train_text_to_image_control_lora.py:403,753 and
@@ -557,7 +681,7 @@ extern "C" int clora_layernorm_fwd_f16(const clora_half* x, clora_half* y, const
     if (!x || !y || !gamma || !beta || M <= 0 || C <= 0 || (C & 7) || C / 8 > 64 * kLnCols) return CLORA_ERR_ARG;
     LnArgs a = LnArgs();
     a.x = (const half_t*)x; a.y = (half_t*)y; a.gamma = gamma; a.beta = beta; a.M = M; a.C = C; a.eps = eps;
-    hipLaunchKernelGGL((layernorm_kernel<false>), dim3(clora_cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, a);
+    launch_layernorm<false>(a, (hipStream_t)stream);
     return clora_check_launch();
 }
 
@@ -566,7 +690,7 @@ extern "C" int clora_layernorm_bwd_f16(const clora_half* x, const clora_half* dy
     if (!x || !dy || !dx || !gamma || M <= 0 || C <= 0 || (C & 7) || C / 8 > 64 * kLnCols) return CLORA_ERR_ARG;
     LnArgs a = LnArgs();
     a.x = (const half_t*)x; a.dy = (const half_t*)dy; a.dres = (const half_t*)dres; a.y = (half_t*)dx; a.gamma = gamma; a.M = M; a.C = C; a.eps = eps;
-    hipLaunchKernelGGL((layernorm_kernel<true>), dim3(clora_cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, a);
+    launch_layernorm<true>(a, (hipStream_t)stream);
     return clora_check_launch();
 }
 

@@ -196,9 +196,14 @@ def conv_patch_eligible(M: int, conv: ConvDesc, tile_cfg: int) -> bool:
 TILE_ORDERS = {"m": 0, "n": 1, "auto": 2}
 
 
+def set_option(name: str, value: int) -> None:
+    """a tuning knob of the kernel library (clora_set_option): results never depend on it"""
+    capi.lib().call("clora_set_option", name.encode(), int(value))
+
+
 def set_tile_order(mode: str) -> None:
-    """tile -> XCD assignment of the GEMM / conv launches that follow: "m" (default), "n", or "auto" (clora_set_tile_order)."""
-    capi.lib().call("clora_set_tile_order", TILE_ORDERS[mode])
+    """tile / attention-block -> XCD assignment of the launches that follow: 'm' (default), 'n' or 'auto'"""
+    set_option("tile_order", TILE_ORDERS[mode])
 
 
 def conv_wgrad(dY: torch.Tensor, X: torch.Tensor, M: int, N: int, K: int, conv: Optional[ConvDesc],

@@ -109,11 +109,15 @@ int clora_gemm_f16_ex(const clora_half* A, int lda, const clora_half* B, clora_h
  * reference op is the same F.conv2d of upstream ResnetBlock2D; tuner / tests use this to know what they time. */
 int clora_conv_patch_eligible(int M, const clora_conv_t* conv, int tile_cfg);
 
-/* Tuning knob, no reference counterpart (results do not depend on it): how clora_gemm_f16[_ex] assigns output tiles to the
- * eight XCDs.  0 = every XCD a contiguous range of tiles in m-major order (default; also CLORA_TILE_ORDER unset / "m"),
- * 1 = n-major ("n"), 2 = per launch whichever order fetches fewer distinct A / B panels per XCD ("auto").  Process-wide;
- * takes effect for the launches that follow (a captured hipGraph keeps the order it was captured with). */
-int clora_set_tile_order(int mode);
+/* Tuning knobs, no reference counterpart: results never depend on them (bit-identical outputs, tests/test_kernels_*.py).
+ * Process-wide; they take effect for the launches that follow (a captured hipGraph keeps what it was captured with).
+ *   "tile_order"  how clora_gemm_f16[_ex] assigns output tiles -- and the attention kernels their (batch, head) blocks -- to the
+ *                 eight XCDs.  0 = every XCD a contiguous range of tiles in m-major order, attention blocks in launch order
+ *                 (default; CLORA_TILE_ORDER unset / "m"); 1 = n-major tile ranges ("n"); 2 = per launch the order that
+ *                 fetches fewer distinct A / B panels per XCD ("auto").  1 and 2 also give every XCD whole attention heads.
+ *   "ln_rows"     1 = LayerNorm keeps several rows in flight per wave (CLORA_LN_ROWS=1), 0 = one row per wave (default).
+ * Unknown names / values: CLORA_ERR_ARG. */
+int clora_set_option(const char* name, int value);
 
 /* dW[N, K] += dY[M,N]^T . gather(X)[M,K] and (db != NULL) db[N] += column sums of dY  (fp32 atomics; caller
  * zeroes dW / db).

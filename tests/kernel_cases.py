@@ -264,7 +264,7 @@ def case_attention(dev, B, H, Nq, Nk, D, seed=3, fused_qkv=False, tol=2e-3, ramp
 
 
 def case_attention_block_order(dev, B, H, Nq, Nk, D, seed=23):
-    """whole heads per XCD (clora_set_tile_order != "m") only permutes which workgroup handles which (head, block): the forward
+    """whole heads per XCD (tile_order != "m") only permutes which workgroup handles which (head, block): the forward
     output, LSE and the three gradients are bit-identical; the grid (3 x 6 blocks at Nq = 300, B*H = 6) is not a multiple of 8"""
     g = torch.Generator().manual_seed(seed)
     scale = D ** -0.5
@@ -336,6 +336,31 @@ def case_layernorm(dev, M, C, seed=5):
     assert rel(K.layernorm_bwd(x, dy, gamma, 1e-5), x32.grad) < 1e-3
     dres = rnd((M, C), dev, g)                      # fused residual-branch gradient
     assert rel(K.layernorm_bwd(x, dy, gamma, 1e-5, dres=dres), x32.grad + dres.float()) < 1e-3
+
+
+def case_layernorm_rows(dev, M, C, seed=25):
+    """several rows in flight per wave (clora_set_option "ln_rows"): same per-row arithmetic as the one-row kernel, ragged last
+    block (M not a multiple of the rows per block), forward / backward / backward with the residual-branch gradient"""
+    g = torch.Generator().manual_seed(seed)
+    x, dy, dres = rnd((M, C), dev, g), rnd((M, C), dev, g), rnd((M, C), dev, g)
+    gamma, beta = (1 + 0.2 * rnd((C,), dev, g, dtype=f32)), 0.2 * rnd((C,), dev, g, dtype=f32)
+
+    def run():
+        return (K.layernorm_fwd(x, gamma, beta, 1e-5), K.layernorm_bwd(x, dy, gamma, 1e-5), K.layernorm_bwd(x, dy, gamma, 1e-5, dres=dres))
+
+    try:
+        K.set_option("ln_rows", 0)
+        base = run()
+        K.set_option("ln_rows", 1)
+        rows = run()
+    finally:
+        K.set_option("ln_rows", 0)
+    x32 = x.float().clone().requires_grad_(True)
+    y = F.layer_norm(x32, (C,), gamma, beta, 1e-5)
+    y.backward(dy.float())
+    assert rel(rows[0], y.detach()) < 6e-4 and rel(rows[1], x32.grad) < 1e-3
+    for a, b_ in zip(base, rows):
+        assert rel(a, b_) < 1e-5, rel(a, b_)
 
 
 def case_geglu(dev, M, Fdim, seed=6):

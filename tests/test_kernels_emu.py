@@ -48,7 +48,7 @@ def test_gemm_tile_configs(tile):
 @pytest.mark.parametrize("order", ["n", "auto"])
 @pytest.mark.parametrize("tile", [21, 43, 53, 72, 76])
 def test_tile_order_does_not_change_results(tile, order):
-    """the tile -> XCD assignment (clora_set_tile_order) only permutes which workgroup computes which tile: bit-identical outputs"""
+    """the tile -> XCD assignment (clora_set_option "tile_order") only permutes which workgroup computes which tile: bit-identical outputs"""
     KC.case_tile_order("cpu", tile, order)
 
 
@@ -127,6 +127,11 @@ def test_groupnorm(B, HW, C, G, silu, train):
 @pytest.mark.parametrize("M,C", [(37, 320), (9, 1280), (5, 64)])
 def test_layernorm(M, C):
     KC.case_layernorm("cpu", M, C)
+
+
+@pytest.mark.parametrize("M,C", [(2051, 320), (2050, 640), (2049, 1280)])
+def test_layernorm_rows_in_flight(M, C):
+    KC.case_layernorm_rows("cpu", M, C)
 
 
 def test_geglu():

@@ -71,7 +71,7 @@ def test_conv_patch_kernel_upsampled(tile, Bn, H, Ci):
 @pytest.mark.parametrize("order", ["n", "auto"])
 @pytest.mark.parametrize("tile", [21, 43, 53, 58, 72, 76])
 def test_tile_order_does_not_change_results(tile, order):
-    """clora_set_tile_order: which XCD computes which tile is a permutation -- bit-identical GEMM / conv outputs"""
+    """clora_set_option("tile_order"): which XCD computes which tile is a permutation -- bit-identical GEMM / conv outputs"""
     KC.case_tile_order(DEV, tile, order)
 
 
@@ -106,6 +106,11 @@ def test_groupnorm(B, HW, C, G, silu, train):
 @pytest.mark.parametrize("M,C", [(4096, 320), (1024, 640), (259, 1280)])
 def test_layernorm(M, C):
     KC.case_layernorm(DEV, M, C)
+
+
+@pytest.mark.parametrize("M,C", [(16384, 320), (4099, 640), (2049, 1280)])
+def test_layernorm_rows_in_flight(M, C):
+    KC.case_layernorm_rows(DEV, M, C)
 
 
 def test_geglu():

@@ -1,4 +1,4 @@
-"""Same-process A/B of the tile -> XCD assignment (clora_set_tile_order: "m" = contiguous m-major tile ranges per XCD,
+"""Same-process A/B of the tile -> XCD assignment (clora_set_option "tile_order": "m" = contiguous m-major tile ranges per XCD,
 "n" = n-major, "auto" = the fabric-bytes model of clora_gemm.hip pick_tile_order) on the weight-heavy GEMM / conv shapes of
 the SD-1.5 step (batch 4, 512^2) and a few activation-heavy controls.  Every shape runs with the tile / split-K the tuning table
 gives it; each order is captured into its own hipGraph (the order is fixed at capture) and replayed.
