@@ -56,6 +56,10 @@ __device__ __forceinline__ half4v clora_ds_read_tr16(const half_t* lptr) {
 // five extra VALU instructions per element); softmax probabilities below 2^-126 may flush to zero.
 #define CLORA_EXP2(x) __builtin_amdgcn_exp2f(x)
 #define CLORA_RCP(x) __builtin_amdgcn_rcpf(x)      // v_rcp_f32 (1 ulp) instead of the IEEE division sequence
+// Pin a loaded vector register: the value is "used and redefined" here, so the load that produced it cannot be sunk into a
+// later conditional block.  (CodeGenPrepare turns `ok ? load : 0` and loads whose only use is a conditional store into
+// branch + load -- in a batch of loads that puts load -> s_waitcnt vmcnt(0) back into every row.)  Costs no instruction.
+#define CLORA_KEEP(x) asm volatile("" : "+v"(x))
 #endif
 
 __device__ __forceinline__ floatx4 mfma16(half8 a, half8 b, floatx4 c) {

@@ -42,15 +42,25 @@ __device__ __forceinline__ void gn_thread_map(int t, int CH, int& rl, int& nrl, 
     else { nrl = 256 / CH; rl = t / CH; c0 = t - rl * CH; cstep = CH; active = rl < nrl; }
 }
 
+// Row loops of the four GroupNorm passes.  A thread owns rows r_beg + rl + it * nrl; written as `for (r = ...; r < r_end; r += nrl)`
+// the trip count differs per thread, every unrolled copy gets its own exit branch and the compiler emits load -> s_waitcnt
+// vmcnt(0) -> use per row: ONE 16-byte load in flight per thread (seen in the ISA of all four kernels; 6-10 dependent
+// L2 / fabric round trips per launch).  Here the trip count nit is block-uniform, rows past r_end re-read row r_beg
+// (a valid address) and are masked out of the sums / not stored, and kGnU rows are loaded before the first one is used.
+// The per-thread order of the accumulations is unchanged, so the results are bit-identical to the branchy loops.
+// NJ = column chunks per thread: 2 only for slabs wider than 2048 channels (gn_plan keeps slabs <= 2048 when it can).
+constexpr int kGnU = 4;
+
 // Deterministic block reduction: per-thread per-channel pairs -> LDS [nrl][C][2] -> per-channel totals in
 // red[0][c][*] -> per-group sums (optionally weighted by gamma) written to out_group[g*2 + {0,1}].
-__device__ __forceinline__ void gn_block_reduce(float* red, const float (&a)[kMaxCols][8], const float (&b)[kMaxCols][8],
+template <int NJ>
+__device__ __forceinline__ void gn_block_reduce(float* red, const float (&a)[NJ][8], const float (&b)[NJ][8],
                                                 int t, int C, int G, int rl, int nrl, int c0, int cstep, bool active,
                                                 const float* weight, float* out_group, float* out_channel) {
     const int CH = C / 8, cpg = C / G;
     if (active) {
 #pragma unroll
-        for (int j = 0; j < kMaxCols; ++j) {
+        for (int j = 0; j < NJ; ++j) {
             const int cc = c0 + j * cstep;
             if (cc < CH && (j == 0 || cstep == 256)) {
 #pragma unroll
@@ -82,6 +92,7 @@ __device__ __forceinline__ void gn_block_reduce(float* red, const float (&a)[kMa
 constexpr int kRedFloats = 2 * 4096;   // LDS: max(nrl*C, C) * 2 floats with nrl*C <= 2048 for CH < 256
 
 // ---- forward, pass 1
+template <int NJ>
 __global__ __launch_bounds__(256) void gn_fwd_partial_kernel(GnArgs p) {
     __shared__ float red[kRedFloats];
     const int t = threadIdx.x, b = blockIdx.z, chunk = blockIdx.x, cb = blockIdx.y * p.CS;
@@ -90,31 +101,46 @@ __global__ __launch_bounds__(256) void gn_fwd_partial_kernel(GnArgs p) {
     gn_thread_map(t, CH, rl, nrl, c0, cstep, active);
     const int r_beg = chunk * p.rows_per_chunk;
     const int r_end = (r_beg + p.rows_per_chunk < p.HW) ? r_beg + p.rows_per_chunk : p.HW;
-    float s[kMaxCols][8], q[kMaxCols][8];
+    const int nit = (r_end - r_beg + nrl - 1) / nrl;              // block-uniform
+    float s[NJ][8], q[NJ][8];
 #pragma unroll
-    for (int j = 0; j < kMaxCols; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int e = 0; e < 8; ++e) { s[j][e] = 0.f; q[j][e] = 0.f; }
     if (active) {
-#pragma unroll 4
-        for (int r = r_beg + rl; r < r_end; r += nrl) {
-            const half_t* row = p.x + ((size_t)b * p.HW + r) * p.C + cb;
+        const half_t* base = p.x + (size_t)b * p.HW * p.C + cb;
+        for (int it0 = 0; it0 < nit; it0 += kGnU) {
+            half8 v[kGnU][NJ];
 #pragma unroll
-            for (int j = 0; j < kMaxCols; ++j) {
-                const int cc = c0 + j * cstep;
-                if (cc < CH && (j == 0 || cstep == 256)) {
-                    const half8 v = ld8(row + cc * 8);
+            for (int u = 0; u < kGnU; ++u) {                     // every load of the batch first ...
+                const int r = r_beg + rl + (it0 + u) * nrl;
+                const half_t* row = base + (size_t)(r < r_end ? r : r_beg) * p.C;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) { const float f = (float)v[e]; s[j][e] += f; q[j][e] += f * f; }
+                for (int j = 0; j < NJ; ++j) {
+                    const int cc = c0 + j * cstep;
+                    v[u][j] = ld8(row + (cc < CH ? cc : c0) * 8);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < kGnU; ++u) {                     // ... then the sums, rows past the chunk masked to zero
+                const bool ok = r_beg + rl + (it0 + u) * nrl < r_end;
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    CLORA_KEEP(v[u][j]);
+                    if (c0 + j * cstep < CH) {                   // thread-constant
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { const float f = ok ? (float)v[u][j][e] : 0.f; s[j][e] += f; q[j][e] += f * f; }
+                    }
                 }
             }
         }
     }
-    gn_block_reduce(red, s, q, t, p.CS, gps, rl, nrl, c0, cstep, active, nullptr,
-                    p.partial + (((size_t)b * p.nchunk + chunk) * p.G + blockIdx.y * gps) * 2, nullptr);
+    gn_block_reduce<NJ>(red, s, q, t, p.CS, gps, rl, nrl, c0, cstep, active, nullptr,
+                        p.partial + (((size_t)b * p.nchunk + chunk) * p.G + blockIdx.y * gps) * 2, nullptr);
 }
 
 // ---- backward, pass 1: per channel a1 = sum dyp, a2 = sum dyp*xhat over this block's rows
+template <int NJ>
 __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(GnArgs p) {
     __shared__ float red[kRedFloats];
     const int t = threadIdx.x, b = blockIdx.z, chunk = blockIdx.x, cb = blockIdx.y * p.CS;
@@ -123,10 +149,11 @@ __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(GnArgs p) {
     gn_thread_map(t, CH, rl, nrl, c0, cstep, active);
     const int r_beg = chunk * p.rows_per_chunk;
     const int r_end = (r_beg + p.rows_per_chunk < p.HW) ? r_beg + p.rows_per_chunk : p.HW;
-    float a1[kMaxCols][8], a2[kMaxCols][8];
-    float kmean[kMaxCols][8], krstd[kMaxCols][8], kg[kMaxCols][8], kb[kMaxCols][8];
+    const int nit = (r_end - r_beg + nrl - 1) / nrl;              // block-uniform
+    float a1[NJ][8], a2[NJ][8];
+    float kmean[NJ][8], krstd[NJ][8], kg[NJ][8], kb[NJ][8];
 #pragma unroll
-    for (int j = 0; j < kMaxCols; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             a1[j][e] = 0.f; a2[j][e] = 0.f;
@@ -136,29 +163,45 @@ __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(GnArgs p) {
             kmean[j][e] = st[0]; krstd[j][e] = st[1]; kg[j][e] = p.gamma[ch]; kb[j][e] = p.beta[ch];
         }
     if (active) {
-#pragma unroll 2
-        for (int r = r_beg + rl; r < r_end; r += nrl) {
-            const size_t off = ((size_t)b * p.HW + r) * p.C + cb;
+        const size_t boff = (size_t)b * p.HW * p.C + cb;
+        constexpr int U = 2;                                     // two tensors per row: 4 * NJ loads in flight
+        for (int it0 = 0; it0 < nit; it0 += U) {
+            half8 xv[U][NJ], gv[U][NJ];
 #pragma unroll
-            for (int j = 0; j < kMaxCols; ++j) {
-                const int cc = c0 + j * cstep;
-                if (cc < CH && (j == 0 || cstep == 256)) {
-                    const half8 xv = ld8(p.x + off + cc * 8), gv = ld8(p.dy + off + cc * 8);
+            for (int u = 0; u < U; ++u) {
+                const int r = r_beg + rl + (it0 + u) * nrl;
+                const size_t off = boff + (size_t)(r < r_end ? r : r_beg) * p.C;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const float xh = ((float)xv[e] - kmean[j][e]) * krstd[j][e];
-                        float d = (float)gv[e];
-                        if (p.fuse_silu) d *= dsilu_f(xh * kg[j][e] + kb[j][e]);
-                        a1[j][e] += d;
-                        a2[j][e] += d * xh;
+                for (int j = 0; j < NJ; ++j) {
+                    const int cc = c0 + j * cstep, cl = (cc < CH ? cc : c0) * 8;
+                    xv[u][j] = ld8(p.x + off + cl);
+                    gv[u][j] = ld8(p.dy + off + cl);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const bool ok = r_beg + rl + (it0 + u) * nrl < r_end;
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    CLORA_KEEP(xv[u][j]);
+                    CLORA_KEEP(gv[u][j]);
+                    if (c0 + j * cstep < CH) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float xh = ((float)xv[u][j][e] - kmean[j][e]) * krstd[j][e];
+                            float d = ok ? (float)gv[u][j][e] : 0.f;
+                            if (p.fuse_silu) d *= dsilu_f(xh * kg[j][e] + kb[j][e]);
+                            a1[j][e] += d;
+                            a2[j][e] += d * xh;
+                        }
                     }
                 }
             }
         }
     }
-    gn_block_reduce(red, a1, a2, t, p.CS, gps, rl, nrl, c0, cstep, active, p.gamma + cb,
-                    p.partial + (((size_t)b * p.nchunk + chunk) * p.G + blockIdx.y * gps) * 2,
-                    p.chpart ? p.chpart + (((size_t)b * p.nchunk + chunk) * p.C + cb) * 2 : nullptr);
+    gn_block_reduce<NJ>(red, a1, a2, t, p.CS, gps, rl, nrl, c0, cstep, active, p.gamma + cb,
+                        p.partial + (((size_t)b * p.nchunk + chunk) * p.G + blockIdx.y * gps) * 2,
+                        p.chpart ? p.chpart + (((size_t)b * p.nchunk + chunk) * p.C + cb) * 2 : nullptr);
 }
 
 // ---- fused finalize + apply (forward): every block re-folds the chunk partials of its batch element (a few KB
@@ -190,6 +233,7 @@ __device__ __forceinline__ void gn_fold_groups(const GnArgs& p, int b, int t, fl
     if (g < p.G && part == 0) { out2[g * 2] = s * inv_n; out2[g * 2 + 1] = q * inv_n; }
 }
 
+template <int NJ>
 __global__ __launch_bounds__(256) void gn_fwd_apply2_kernel(GnArgs p) {
     __shared__ float mr[64 * 2];
     const int t = threadIdx.x, b = blockIdx.z, chunk = blockIdx.x, cb = blockIdx.y * p.CS;
@@ -207,9 +251,9 @@ __global__ __launch_bounds__(256) void gn_fwd_apply2_kernel(GnArgs p) {
     __syncthreads();
     int rl, nrl, c0, cstep; bool active;
     gn_thread_map(t, CH, rl, nrl, c0, cstep, active);
-    float sc[kMaxCols][8], sh[kMaxCols][8];
+    float sc[NJ][8], sh[NJ][8];
 #pragma unroll
-    for (int j = 0; j < kMaxCols; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int cc = c0 + j * cstep;
@@ -220,28 +264,43 @@ __global__ __launch_bounds__(256) void gn_fwd_apply2_kernel(GnArgs p) {
     if (!active) return;
     const int r_beg = chunk * p.rows_per_chunk;
     const int r_end = (r_beg + p.rows_per_chunk < p.HW) ? r_beg + p.rows_per_chunk : p.HW;
-#pragma unroll 4
-    for (int r = r_beg + rl; r < r_end; r += nrl) {
-        const size_t off = ((size_t)b * p.HW + r) * p.C + cb;
+    const int nit = (r_end - r_beg + nrl - 1) / nrl;              // block-uniform
+    const size_t boff = (size_t)b * p.HW * p.C + cb;
+    for (int it0 = 0; it0 < nit; it0 += kGnU) {
+        half8 v[kGnU][NJ];
 #pragma unroll
-        for (int j = 0; j < kMaxCols; ++j) {
-            const int cc = c0 + j * cstep;
-            if (cc < CH && (j == 0 || cstep == 256)) {
-                const half8 v = ld8(p.x + off + cc * 8);
-                half8 o;
+        for (int u = 0; u < kGnU; ++u) {
+            const int r = r_beg + rl + (it0 + u) * nrl;
+            const size_t off = boff + (size_t)(r < r_end ? r : r_beg) * p.C;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int cc = c0 + j * cstep;
+                v[u][j] = ld8(p.x + off + (cc < CH ? cc : c0) * 8);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kGnU; ++u) {
+            const int r = r_beg + rl + (it0 + u) * nrl;
+            const size_t off = boff + (size_t)(r < r_end ? r : r_beg) * p.C;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int cc = c0 + j * cstep;
+                CLORA_KEEP(v[u][j]);
+                half8 o;                                         // computed unconditionally (keeps the loads above the branch) ...
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    float yv = (float)v[e] * sc[j][e] + sh[j][e];
+                    float yv = (float)v[u][j][e] * sc[j][e] + sh[j][e];
                     if (p.fuse_silu) yv = silu_f(yv);
                     o[e] = (half_t)yv;
                 }
-                st8(p.y + off + cc * 8, o);
+                if (r < r_end && cc < CH) st8(p.y + off + cc * 8, o);   // ... only the store is conditional
             }
         }
     }
 }
 
 // ---- fused finalize + apply (backward): dx = k1*dyp + k2*x + k3 with per-channel coefficients in registers
+template <int NJ>
 __global__ __launch_bounds__(256) void gn_bwd_apply2_kernel(GnArgs p) {
     __shared__ float gs[64 * 2];
     const int t = threadIdx.x, b = blockIdx.z, chunk = blockIdx.x, cb = blockIdx.y * p.CS;
@@ -250,9 +309,9 @@ __global__ __launch_bounds__(256) void gn_bwd_apply2_kernel(GnArgs p) {
     __syncthreads();
     int rl, nrl, c0, cstep; bool active;
     gn_thread_map(t, CH, rl, nrl, c0, cstep, active);
-    float sc[kMaxCols][8], sh[kMaxCols][8], k1[kMaxCols][8], k2[kMaxCols][8], k3[kMaxCols][8];
+    float sc[NJ][8], sh[NJ][8], k1[NJ][8], k2[NJ][8], k3[NJ][8];
 #pragma unroll
-    for (int j = 0; j < kMaxCols; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int cc = c0 + j * cstep;
@@ -268,28 +327,48 @@ __global__ __launch_bounds__(256) void gn_bwd_apply2_kernel(GnArgs p) {
     if (!active) return;
     const int r_beg = chunk * p.rows_per_chunk;
     const int r_end = (r_beg + p.rows_per_chunk < p.HW) ? r_beg + p.rows_per_chunk : p.HW;
-#pragma unroll 2
-    for (int r = r_beg + rl; r < r_end; r += nrl) {
-        const size_t off = ((size_t)b * p.HW + r) * p.C + cb;
+    const int nit = (r_end - r_beg + nrl - 1) / nrl;              // block-uniform
+    const size_t boff = (size_t)b * p.HW * p.C + cb;
+    const bool has_res = p.dres != nullptr;                      // kernel-uniform
+    const half_t* res = has_res ? p.dres : p.dy;                 // a valid address either way: the loads stay unconditional
+    constexpr int U = 2;                                         // three tensors per row: 6 * NJ loads in flight
+    for (int it0 = 0; it0 < nit; it0 += U) {
+        half8 xv[U][NJ], gv[U][NJ], rv[U][NJ];
 #pragma unroll
-        for (int j = 0; j < kMaxCols; ++j) {
-            const int cc = c0 + j * cstep;
-            if (cc < CH && (j == 0 || cstep == 256)) {
-                const half8 xv = ld8(p.x + off + cc * 8), gv = ld8(p.dy + off + cc * 8);
+        for (int u = 0; u < U; ++u) {
+            const int r = r_beg + rl + (it0 + u) * nrl;
+            const size_t off = boff + (size_t)(r < r_end ? r : r_beg) * p.C;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int cc = c0 + j * cstep, cl = (cc < CH ? cc : c0) * 8;
+                xv[u][j] = ld8(p.x + off + cl);
+                gv[u][j] = ld8(p.dy + off + cl);
+                rv[u][j] = ld8(res + off + cl);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int r = r_beg + rl + (it0 + u) * nrl;
+            const size_t off = boff + (size_t)(r < r_end ? r : r_beg) * p.C;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int cc = c0 + j * cstep;
+                CLORA_KEEP(xv[u][j]);
+                CLORA_KEEP(gv[u][j]);
+                CLORA_KEEP(rv[u][j]);
                 half8 o;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    const float xf = (float)xv[e];
-                    float d = (float)gv[e];
+                    const float xf = (float)xv[u][j][e];
+                    float d = (float)gv[u][j][e];
                     if (p.fuse_silu) d *= dsilu_f(xf * sc[j][e] + sh[j][e]);
                     o[e] = (half_t)(k1[j][e] * d + k2[j][e] * xf + k3[j][e]);
                 }
-                if (p.dres) {
-                    const half8 rr = ld8(p.dres + off + cc * 8);
+                if (has_res) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) o[e] = (half_t)((float)o[e] + (float)rr[e]);
+                    for (int e = 0; e < 8; ++e) o[e] = (half_t)((float)o[e] + (float)rv[u][j][e]);
                 }
-                st8(p.y + off + cc * 8, o);
+                if (r < r_end && cc < CH) st8(p.y + off + cc * 8, o);
             }
         }
     }
@@ -653,8 +732,14 @@ extern "C" int clora_groupnorm_fwd_f16(const clora_half* x, clora_half* y, const
     int rc = gn_plan(a, workspace, workspace_bytes, false, false);
     if (rc != CLORA_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(gn_fwd_partial_kernel, dim3(a.nchunk, a.nslab, B), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(gn_fwd_apply2_kernel, dim3(a.nchunk, a.nslab, B), dim3(256), 0, s, a);
+    const dim3 grid(a.nchunk, a.nslab, B);
+    if (a.CS / 8 > 256) {                                        // slabs wider than 2048 channels: two column chunks per thread
+        hipLaunchKernelGGL(gn_fwd_partial_kernel<2>, grid, dim3(256), 0, s, a);
+        hipLaunchKernelGGL(gn_fwd_apply2_kernel<2>, grid, dim3(256), 0, s, a);
+    } else {
+        hipLaunchKernelGGL(gn_fwd_partial_kernel<1>, grid, dim3(256), 0, s, a);
+        hipLaunchKernelGGL(gn_fwd_apply2_kernel<1>, grid, dim3(256), 0, s, a);
+    }
     return clora_check_launch();
 }
 
@@ -670,9 +755,13 @@ extern "C" int clora_groupnorm_bwd_f16(const clora_half* x, const clora_half* dy
     int rc = gn_plan(a, workspace, workspace_bytes, true, dgamma != nullptr);
     if (rc != CLORA_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(gn_bwd_partial_kernel, dim3(a.nchunk, a.nslab, B), dim3(256), 0, s, a);
+    const dim3 grid(a.nchunk, a.nslab, B);
+    const bool two = a.CS / 8 > 256;                             // slabs wider than 2048 channels
+    if (two) hipLaunchKernelGGL(gn_bwd_partial_kernel<2>, grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(gn_bwd_partial_kernel<1>, grid, dim3(256), 0, s, a);
     if (dgamma) hipLaunchKernelGGL(gn_bwd_params_kernel, dim3(clora_cdiv(C, 32)), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(gn_bwd_apply2_kernel, dim3(a.nchunk, a.nslab, B), dim3(256), 0, s, a);
+    if (two) hipLaunchKernelGGL(gn_bwd_apply2_kernel<2>, grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(gn_bwd_apply2_kernel<1>, grid, dim3(256), 0, s, a);
     return clora_check_launch();
 }
 
