@@ -60,6 +60,10 @@ __device__ __forceinline__ half4v clora_ds_read_tr16(const half_t* lptr) {
 // later conditional block.  (CodeGenPrepare turns `ok ? load : 0` and loads whose only use is a conditional store into
 // branch + load -- in a batch of loads that puts load -> s_waitcnt vmcnt(0) back into every row.)  Costs no instruction.
 #define CLORA_KEEP(x) asm volatile("" : "+v"(x))
+// The same without `volatile`: does not count as a memory clobber, so uniform loads that FOLLOW it can still be scalar
+// (s_load needs a provably unclobbered address range; MemorySSA treats volatile asm as a write).  Only where the kept value
+// feeds a select, not a conditional block (a pure asm may be sunk together with its load).
+#define CLORA_KEEP_PURE(x) asm("" : "+v"(x))
 #endif
 
 __device__ __forceinline__ floatx4 mfma16(half8 a, half8 b, floatx4 c) {

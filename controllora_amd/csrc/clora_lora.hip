@@ -221,29 +221,47 @@ __global__ __launch_bounds__(256) void lora_wgrad_kernel(WgradJobs jobs) {
 #pragma unroll
         for (int j = 0; j < RT; ++j) acc[e][j] = 0.f;
     constexpr int UN = (RT <= 8) ? 16 : 8;     // rows in flight per wave
+    const int nc = nok ? n : 0;                                  // lanes past N re-read column 0 and are masked: branch-free loads
     for (int mb = m_beg; mb < m_end; mb += UN) {
         half8 a[UN];
         float tv[UN][RT];
+        // Every load of the batch is issued before the first use.  (With `if (nok && m < m_end) a[u] = ld8(...)` the
+        // compiler emitted load -> s_waitcnt vmcnt(0) per row pair: the "16 rows in flight" were 2; rows past m_end now
+        // re-read row m_end - 1 and are zeroed afterwards, CLORA_KEEP_PURE keeps the loads out of the masked branch.)
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
-            const int m = mb + u;
-            a[u] = zero8();
-            if (nok && m < m_end) {
-                const int ar = a_rows > 0 ? m % a_rows : m;
-                a[u] = ld8(A + (size_t)ar * lda + n);
-                if (A2) {                                    // adapter input = fp16(A + A2), as the reference forms it
-                    const half8 a2 = ld8(A2 + (size_t)m * lda2 + n);
+            const int m = (mb + u < m_end) ? mb + u : m_end - 1;
+            const int ar = a_rows > 0 ? m % a_rows : m;
+            a[u] = ld8(A + (size_t)ar * lda + nc);
+        }
+        half8 a2[UN];
+        if (A2) {                                                // adapter input = fp16(A + A2), as the reference forms it (job-uniform)
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) a[u][e] = (half_t)((float)a[u][e] + (float)a2[e]);
-                }
+            for (int u = 0; u < UN; ++u) {
+                const int m = (mb + u < m_end) ? mb + u : m_end - 1;
+                a2[u] = ld8(A2 + (size_t)m * lda2 + nc);
             }
         }
+        // wave-uniform T rows (scalar loads), issued while the vector loads are in flight
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             const int m = (mb + u < m_end) ? mb + u : m_end - 1;
             const float* tr = T + (size_t)m * ldt + toff;
 #pragma unroll
             for (int j = 0; j < RT; ++j) tv[u][j] = (j < R && mb + u < m_end && m_end > m_beg) ? tr[j] : 0.f;
+        }
+        if (A2) {
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                CLORA_KEEP_PURE(a2[u]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) a[u][e] = (half_t)((float)a[u][e] + (float)a2[u][e]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            CLORA_KEEP_PURE(a[u]);
+            if (!(nok && mb + u < m_end)) a[u] = zero8();
         }
 #pragma unroll
         for (int u = 0; u < UN; ++u)
