@@ -137,7 +137,7 @@ __device__ __forceinline__ float wave_max(float v) {
 // 0 = launch-order defaults, 1 = n-major GEMM tiles (tests), 2 = fewest distinct operand panels per XCD; non-zero also gives
 // every XCD whole attention heads (clora_attn.hip attn_block_ids)
 __attribute__((visibility("hidden"))) int clora_xcd_policy();
-// LayerNorm with several rows in flight per wave (clora_set_option("ln_rows") / CLORA_LN_ROWS): 0 = one row per wave
+// LayerNorm with several rows in flight per wave (default 1; clora_set_option("ln_rows") / CLORA_LN_ROWS=0: one row per wave)
 __attribute__((visibility("hidden"))) int clora_ln_rows();
 
 static inline int clora_check_launch() { return hipGetLastError() == hipSuccess ? CLORA_OK : CLORA_ERR_LAUNCH; }

@@ -1494,8 +1494,8 @@ int clora_xcd_policy() { return tile_order_mode(); }
 static int g_ln_rows = -1;
 int clora_ln_rows() {
     if (g_ln_rows < 0) {
-        const char* e = getenv("CLORA_LN_ROWS");
-        g_ln_rows = (e && atoi(e) > 0) ? 1 : 0;
+        const char* e = getenv("CLORA_LN_ROWS");                 // default on; "0" = one row per wave (A/B)
+        g_ln_rows = (e && atoi(e) == 0) ? 0 : 1;
     }
     return g_ln_rows;
 }

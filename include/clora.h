@@ -115,7 +115,7 @@ int clora_conv_patch_eligible(int M, const clora_conv_t* conv, int tile_cfg);
  *                 eight XCDs.  0 = every XCD a contiguous range of tiles in m-major order, attention blocks in launch order
  *                 (default; CLORA_TILE_ORDER unset / "m"); 1 = n-major tile ranges ("n"); 2 = per launch the order that
  *                 fetches fewer distinct A / B panels per XCD ("auto").  1 and 2 also give every XCD whole attention heads.
- *   "ln_rows"     1 = LayerNorm keeps several rows in flight per wave (CLORA_LN_ROWS=1), 0 = one row per wave (default).
+ *   "ln_rows"     1 = LayerNorm keeps several rows in flight per wave (default), 0 = one row per wave (CLORA_LN_ROWS=0).
  * Unknown names / values: CLORA_ERR_ARG. */
 int clora_set_option(const char* name, int value);
 

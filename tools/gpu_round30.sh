@@ -10,10 +10,18 @@ for order in m auto m auto; do
   CLORA_TILE_ORDER=$order timeout 600 python bench.py --no-cpu-baseline --no-ddim --no-roofline --no-full-step --steps 30 --warmup 5 \
     >> gpurun_out/r03_bench_order_${order}.json 2>> gpurun_out/r03_bench_order_${order}.err
 done
-# LayerNorm with several rows in flight per wave (CLORA_LN_ROWS=1; bit-compatible, clora_norm.hip layernorm_rows_kernel)
+# LayerNorm with several rows in flight per wave (default; CLORA_LN_ROWS=0 = the one-row kernel; clora_norm.hip layernorm_rows_kernel)
 for rows in 0 1 0 1; do
   CLORA_LN_ROWS=$rows timeout 600 python bench.py --no-cpu-baseline --no-ddim --no-roofline --no-full-step --steps 30 --warmup 5 \
     >> gpurun_out/r03_bench_ln_rows_${rows}.json 2>> gpurun_out/r03_bench_ln_rows_${rows}.err
 done
+# GroupNorm / adapter-wgrad loops with loads in flight (HEAD) against the load -> wait -> use loops: build the "before" library
+# in the dev container first:  tools/build_prev_lib.sh 62e4530 clora_norm.hip clora_lora.hip
+if [ -f controllora_amd/_build_prev/libclora.so ]; then
+  for lib in controllora_amd/_build_prev/libclora.so "" controllora_amd/_build_prev/libclora.so ""; do
+    CLORA_LIB_PATH=$lib timeout 600 python bench.py --no-cpu-baseline --no-ddim --no-roofline --no-full-step --steps 30 --warmup 5 \
+      >> gpurun_out/r03_bench_lib_$( [ -n "$lib" ] && echo prev || echo head ).json 2>> gpurun_out/r03_bench_lib.err
+  done
+fi
 timeout 1500 python -m pytest tests -m gpu -x -q > gpurun_out/r03_gputest.log 2>&1
 tail -3 gpurun_out/r03_gputest.log
