@@ -16,7 +16,7 @@ for rows in 0 1 0 1; do
     >> gpurun_out/r03_bench_ln_rows_${rows}.json 2>> gpurun_out/r03_bench_ln_rows_${rows}.err
 done
 # GroupNorm / adapter-wgrad loops with loads in flight (HEAD) against the load -> wait -> use loops: build the "before" library
-# in the dev container first:  tools/build_prev_lib.sh 62e4530 clora_norm.hip clora_lora.hip
+# in the dev container first:  tools/build_prev_lib.sh 62e4530:clora_norm.hip b00c262:clora_lora.hip
 if [ -f controllora_amd/_build_prev/libclora.so ]; then
   for lib in controllora_amd/_build_prev/libclora.so "" controllora_amd/_build_prev/libclora.so ""; do
     CLORA_LIB_PATH=$lib timeout 600 python bench.py --no-cpu-baseline --no-ddim --no-roofline --no-full-step --steps 30 --warmup 5 \
