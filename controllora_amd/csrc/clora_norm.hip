@@ -610,10 +610,16 @@ template <bool BWD>
 void launch_layernorm(const LnArgs& a, hipStream_t s) {
     const int CH = a.C / 8;
     const bool al16 = (((uintptr_t)a.gamma | (uintptr_t)(BWD ? a.gamma : a.beta)) & 15) == 0;
-    if (clora_ln_rows() && CH <= 192 && a.M >= 2048 && al16) {           // enough rows to keep the chip full with fewer, fatter waves
-        if (CH <= 64) hipLaunchKernelGGL((layernorm_rows_kernel<BWD, 1, 4>), dim3(clora_cdiv(a.M, 16)), dim3(256), 0, s, a);
-        else if (CH <= 128) hipLaunchKernelGGL((layernorm_rows_kernel<BWD, 2, 2>), dim3(clora_cdiv(a.M, 8)), dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((layernorm_rows_kernel<BWD, 3, 2>), dim3(clora_cdiv(a.M, 8)), dim3(256), 0, s, a);
+    if (clora_ln_rows() && CH <= 192 && al16) {
+        if (a.M >= 2048) {                                       // enough rows to keep the chip full with fewer, fatter waves
+            if (CH <= 64) hipLaunchKernelGGL((layernorm_rows_kernel<BWD, 1, 4>), dim3(clora_cdiv(a.M, 16)), dim3(256), 0, s, a);
+            else if (CH <= 128) hipLaunchKernelGGL((layernorm_rows_kernel<BWD, 2, 2>), dim3(clora_cdiv(a.M, 8)), dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((layernorm_rows_kernel<BWD, 3, 2>), dim3(clora_cdiv(a.M, 8)), dim3(256), 0, s, a);
+        } else {                                                 // few rows (16x16 level, text tokens): one row per wave, but its 1-3 chunk
+            if (CH <= 64) hipLaunchKernelGGL((layernorm_rows_kernel<BWD, 1, 1>), dim3(clora_cdiv(a.M, 4)), dim3(256), 0, s, a);        // loads (and dy, dres, gamma)
+            else if (CH <= 128) hipLaunchKernelGGL((layernorm_rows_kernel<BWD, 2, 1>), dim3(clora_cdiv(a.M, 4)), dim3(256), 0, s, a);  // issued together instead of
+            else hipLaunchKernelGGL((layernorm_rows_kernel<BWD, 3, 1>), dim3(clora_cdiv(a.M, 4)), dim3(256), 0, s, a);                 // one block per chunk
+        }
         return;
     }
     hipLaunchKernelGGL((layernorm_kernel<BWD>), dim3(clora_cdiv(a.M, 4)), dim3(256), 0, s, a);

@@ -129,7 +129,7 @@ def test_layernorm(M, C):
     KC.case_layernorm("cpu", M, C)
 
 
-@pytest.mark.parametrize("M,C", [(2051, 320), (2050, 640), (2049, 1280)])
+@pytest.mark.parametrize("M,C", [(2051, 320), (2050, 640), (2049, 1280), (309, 320), (77, 1280), (130, 768)])
 def test_layernorm_rows_in_flight(M, C):
     KC.case_layernorm_rows("cpu", M, C)
 

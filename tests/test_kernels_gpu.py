@@ -108,7 +108,7 @@ def test_layernorm(M, C):
     KC.case_layernorm(DEV, M, C)
 
 
-@pytest.mark.parametrize("M,C", [(16384, 320), (4099, 640), (2049, 1280)])
+@pytest.mark.parametrize("M,C", [(16384, 320), (4099, 640), (2049, 1280), (1024, 1280), (308, 768)])
 def test_layernorm_rows_in_flight(M, C):
     KC.case_layernorm_rows(DEV, M, C)
 
