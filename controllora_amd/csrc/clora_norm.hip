@@ -641,11 +641,17 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const half_t* x, half
     half_t* yr = y + (size_t)row * ld;
     half8 v[kSmCols];
     float mx = -3.0e38f;
+    // all chunk loads of the row first (lanes past the row re-read chunk l, unused): under `if (cc < CH)` each chunk was its own
+    // load -> s_waitcnt vmcnt(0) block, eight dependent round trips per 4096-wide row
 #pragma unroll
     for (int j = 0; j < kSmCols; ++j) {
         const int cc = l + 64 * j;
-        if (cc < CH) {
-            v[j] = ld8(xr + cc * 8);
+        v[j] = ld8(xr + (cc < CH ? cc : (l < CH ? l : 0)) * 8);
+    }
+#pragma unroll
+    for (int j = 0; j < kSmCols; ++j) {
+        CLORA_KEEP(v[j]);
+        if (l + 64 * j < CH) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) mx = fmaxf(mx, (float)v[j][e]);
         }
