@@ -623,8 +623,21 @@ __global__ __launch_bounds__(256) void attn_dkv_convert_kernel(AttnArgs p) {
         const size_t row = i / (HD / 4);
         const int c = (int)(i - row * (HD / 4)) * 4;
         floatx4 a = zero4f(), bb = zero4f();
-        for (int z = 0; z < p.nsplit; ++z) {
-            const float* q = p.acc32 + (size_t)z * 2 * plane + row * HD + c;
+        const float* q0 = p.acc32 + row * HD + c;
+        int z = 0;
+        for (; z + 4 <= p.nsplit; z += 4) {                      // four slab pairs in flight (was load, load, wait per split: up to 16
+            floatx4 ta[4], tb[4];                                // dependent round trips per output chunk); same summation order
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float* q = q0 + (size_t)(z + u) * 2 * plane;
+                ta[u] = *reinterpret_cast<const floatx4*>(q);
+                tb[u] = *reinterpret_cast<const floatx4*>(q + plane);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { a += ta[u]; bb += tb[u]; }
+        }
+        for (; z < p.nsplit; ++z) {
+            const float* q = q0 + (size_t)z * 2 * plane;
             a += *reinterpret_cast<const floatx4*>(q);
             bb += *reinterpret_cast<const floatx4*>(q + plane);
         }
