@@ -1,10 +1,13 @@
 #!/bin/bash
 # Next measurement session, first call: same-box A/B of the tile -> XCD assignment (CLORA_TILE_ORDER: m = current default,
 # auto = fewest distinct operand panels per XCD; model in clora_gemm.hip pick_tile_order, motivation in DESIGN.md section 5
-# "Hardware ceilings") per shape and on the bench line, then the GPU suite.
+# "Hardware ceilings") per shape and on the bench line, after the GPU suite.
 set -x
 mkdir -p gpurun_out
 python tools/box_calib.py > gpurun_out/r03_box_calib.txt 2>&1
+# correctness of everything that changed without a GPU at the end of round 2 (GroupNorm / LayerNorm / wgrad / finish loops, order options)
+timeout 1500 python -m pytest tests -m gpu -x -q > gpurun_out/r03_gputest.log 2>&1
+tail -3 gpurun_out/r03_gputest.log
 timeout 600 python tools/tile_order_ab.py --json gpurun_out/r03_tile_order_ab.json > gpurun_out/r03_tile_order_ab.txt 2>&1
 for order in m auto m auto; do
   CLORA_TILE_ORDER=$order timeout 600 python bench.py --no-cpu-baseline --no-ddim --no-roofline --no-full-step --steps 30 --warmup 5 \
@@ -23,5 +26,3 @@ if [ -f controllora_amd/_build_prev/libclora.so ]; then
       >> gpurun_out/r03_bench_lib_$( [ -n "$lib" ] && echo prev || echo head ).json 2>> gpurun_out/r03_bench_lib.err
   done
 fi
-timeout 1500 python -m pytest tests -m gpu -x -q > gpurun_out/r03_gputest.log 2>&1
-tail -3 gpurun_out/r03_gputest.log
