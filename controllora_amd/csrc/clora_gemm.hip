@@ -391,7 +391,16 @@ __device__ __forceinline__ void dma_epilogue(const GemmArgs& p, floatx4 (&acc)[B
     // ---- fp32 accumulators -> LDS (64 rows per pass) -> per row-chunk: bias / time-embedding / rank-r
     // adapter update (float4 operand loads) -> fp16 -> + residual -> 16-byte coalesced stores.  Doing the fused
     // math AFTER the LDS hop keeps it out of the main loop's register budget.
-    constexpr int PR = 64, F_LD = BN + 4, NPASS = BM / PR;
+    constexpr int F_LD = BN + 4;
+#ifdef CLORA_EPI_SINGLE_PASS
+    // experiment build (tools/build_variant_lib.sh -DCLORA_EPI_SINGLE_PASS, A/B through CLORA_LIB_PATH): the whole tile is staged at once
+    // where the ring allocation has room, so every accumulator is dead before the first chunk is processed.  Compiled figures in
+    // DESIGN.md section 7 (peak VGPRs 255 -> 186 on 128x256, the 128x64 BK32 spills disappear); untimed, hence not the default.
+    constexpr int PR = (BM * F_LD * 2 <= SMEM) ? BM : 64;
+#else
+    constexpr int PR = 64;
+#endif
+    constexpr int NPASS = BM / PR;
     static_assert(PR * F_LD * 2 <= SMEM, "fp32 staging must fit in the LDS allocation");
     float* Cf = reinterpret_cast<float*>(smem);
     constexpr int CPR = BN / 8;

@@ -48,3 +48,21 @@ def test_weakened_wait_is_caught(name, mutant_lib):
             CASES[name]()
     with _use(build_emu.build()):
         CASES[name]()                                   # and the unmodified sources pass the very same case
+
+
+# ---- experiment build of the GEMM epilogue (CLORA_EPI_SINGLE_PASS: the whole tile staged to LDS in one pass) gives the same results
+@pytest.fixture(scope="module")
+def single_pass_lib(tmp_path_factory):
+    build_emu.build()
+    return build_emu.build_mutant(str(tmp_path_factory.mktemp("epi1")), "clora_gemm.hip", [("#ifdef CLORA_EPI_SINGLE_PASS", "#if 1")])
+
+
+@pytest.mark.parametrize("tile", [3, 23, 43, 53, 72, 76])
+def test_single_pass_epilogue_variant(tile, single_pass_lib):
+    with _use(single_pass_lib):
+        if tile < 70:
+            KC.case_gemm_plain("cpu", 150, 72, 104, 1, tile_cfg=tile)
+            KC.case_gemm_epilogue("cpu", split_k=1, tile_cfg=tile)
+            KC.case_conv("cpu", 1, 8, 8, 16, 24, tile_cfg=tile)
+        else:
+            KC.case_conv_patch("cpu", 2, 8, 8, 128, 64, tile)

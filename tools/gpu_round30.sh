@@ -26,3 +26,10 @@ if [ -f controllora_amd/_build_prev/libclora.so ]; then
       >> gpurun_out/r03_bench_lib_$( [ -n "$lib" ] && echo prev || echo head ).json 2>> gpurun_out/r03_bench_lib.err
   done
 fi
+# single-pass accumulator staging in the GEMM epilogue (experiment macro): build first with tools/build_variant_lib.sh -DCLORA_EPI_SINGLE_PASS
+if [ -f controllora_amd/_build_variant/libclora.so ]; then
+  for lib in controllora_amd/_build_variant/libclora.so "" controllora_amd/_build_variant/libclora.so ""; do
+    CLORA_LIB_PATH=$lib timeout 600 python bench.py --no-cpu-baseline --no-ddim --no-roofline --no-full-step --steps 30 --warmup 5 \
+      >> gpurun_out/r03_bench_epi_$( [ -n "$lib" ] && echo single || echo head ).json 2>> gpurun_out/r03_bench_epi.err
+  done
+fi
