@@ -119,7 +119,9 @@ def test_attention_rising_maxima(D):
 
 @pytest.mark.parametrize("B,HW,C,G,silu,train", [(2, 50, 320, 32, True, False), (1, 37, 64, 8, False, False),
                                                  (2, 64, 32, 32, True, True), (1, 9, 2560, 32, True, False),
-                                                 (2, 300, 64, 8, True, False), (2, 256, 320, 32, False, False)])
+                                                 (2, 300, 64, 8, True, False), (2, 256, 320, 32, False, False),
+                                                 (1, 40, 2056, 8, True, True),      # one 2056-channel slab: two column chunks per thread
+                                                 (3, 70, 1280, 32, True, False)])   # row chunks that end inside a load batch
 def test_groupnorm(B, HW, C, G, silu, train):
     KC.case_groupnorm("cpu", B, HW, C, G, silu, train_params=train)
 
