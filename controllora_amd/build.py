@@ -26,7 +26,18 @@ def _stale(target, deps):
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
+    """Serialised across processes (file lock): concurrent first builds must not link half-written objects."""
+    import fcntl
     os.makedirs(OUT_DIR, exist_ok=True)
+    with open(os.path.join(OUT_DIR, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            return _build_locked(force, verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(force: bool, verbose: bool) -> str:
     deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(os.path.dirname(HERE), "include", "clora.h")]
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs = []

@@ -241,7 +241,9 @@ __global__ __launch_bounds__(NWV * 64, (DP <= 64 ? (NWV == 4 ? 3 : 2) : 1)) void
 #pragma unroll
             for (int qg = 0; qg < 2; ++qg) {
                 const float d = (first || mx[qg] > kRebase) ? mx[qg] : 0.f;
-                const float alpha = CLORA_EXP2(-d);
+                // first tile: O and l are still zero and d may be hugely negative (every logit of the tile below -88:
+                // exp2(-d) = +inf and 0 * inf = NaN) -- nothing to rescale yet
+                const float alpha = first ? 1.f : CLORA_EXP2(-d);
                 mref[qg] += d;
                 lrun[qg] *= alpha;
 #pragma unroll

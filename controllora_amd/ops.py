@@ -418,11 +418,14 @@ def _merge_down_jobs(specs):
                 stacked = _stack_rows(parts)
             elif not torch.is_grad_enabled():                          # inference on separate tensors: stack once, keep
                 key = tuple((t.data_ptr(), t._version) for t in parts)
-                stacked = _STACKED_D.get(key)
-                if stacked is None:
+                hit = _STACKED_D.get(key)
+                if hit is None:
                     if len(_STACKED_D) > 4096:
                         _STACKED_D.clear()
-                    stacked = _STACKED_D[key] = torch.cat(parts, 0)
+                    # the entry keeps the source tensors alive: their addresses cannot be handed to another model's
+                    # adapters while the key is cached; in-place updates bump _version and miss
+                    hit = _STACKED_D[key] = (torch.cat(parts, 0), tuple(parts))
+                stacked = hit[0]
             if stacked is not None:
                 if a["X2"] is not None and a["r2"] == 0:
                     a["r2"] = a["R"]

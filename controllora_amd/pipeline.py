@@ -11,7 +11,7 @@ from .schedulers import DDIMScheduler, DPMSolverMultistepScheduler
 
 @torch.no_grad()
 def ddim_sample(unet, control_lora, guide, cond_emb, uncond_emb, steps=50, guidance_scale=9.0, latents=None,
-                generator=None, sampler="ddim", graph=None, cache_text_kv=True):
+                generator=None, sampler="ddim", graph=None, cache_text_kv=True, callback=None):
     """guide [Bc,3,H,W] (control batch 1 broadcasts over the CFG batch, quirk C6); cond/uncond [B,77,768].
     sampler: "ddim" (BASELINE inference config) or "dpm" (DPM-Solver++(2M), what the reference apps select).
 
@@ -19,7 +19,9 @@ def ddim_sample(unet, control_lora, guide, cond_emb, uncond_emb, steps=50, guida
     apps/gradio_canny2image.py:84 -- the processors keep the control states), and with `cache_text_kv` the cross-attention
     K/V projections of the text embedding with their adapters (16 sites; they depend on neither the latents nor the
     timestep).  graph: replay ONE captured hipGraph of the UNet forward per step (default: on a GPU); the timestep lives
-    in a device tensor, so all steps replay the same graph."""
+    in a device tensor, so all steps replay the same graph (default: on a GPU when steps >= 8).
+    callback(i, latents, eps): called after scheduler step i = 1..steps (tests record the trajectory with it).
+    Returns the denoised latents in **fp32** (the scheduler state is kept in fp32 between steps)."""
     from . import models
     B = cond_emb.shape[0]
     dev = cond_emb.device
@@ -32,16 +34,26 @@ def ddim_sample(unet, control_lora, guide, cond_emb, uncond_emb, steps=50, guida
     # 50 updates do not each add an fp16 rounding of the latents (denoised-latent parity, tests/full_cases.py)
     latents = latents.float()
     if control_lora is not None:
+        # validated ONCE here (the per-site check in models._control_tokens is bypassed by precomputed control terms): a
+        # control batch of 1 broadcasts; one guide per image is tiled the way the CFG batch is (uncond..., cond...), which
+        # makes the batches equal; anything else has no defined pairing (reference quirk C6) and is rejected
+        if guide.shape[0] == B and B > 1:
+            guide = torch.cat([guide, guide], 0)
+        elif guide.shape[0] not in (1, 2 * B):
+            raise ValueError(f"guide batch {guide.shape[0]}: expected 1 (broadcast) or one guide per image ({B})")
         control_lora(guide)
     ehs = torch.cat([uncond_emb, cond_emb], 0).half().contiguous()
     if graph is None:
-        graph = dev.type == "cuda"
+        # capture costs one extra warm-up forward + the capture itself: only worth it for real sampling runs
+        graph = dev.type == "cuda" and steps >= 8
     with models.text_kv_cache(enabled=cache_text_kv):
         if not graph:
-            for t in sched.timesteps:
+            for i, t in enumerate(sched.timesteps, 1):
                 eps = unet(torch.cat([latents, latents], 0).half(), t, ehs).sample
                 eps_u, eps_c = eps.float().chunk(2)
                 latents = sched.step(eps_u + guidance_scale * (eps_c - eps_u), t, latents)
+                if callback is not None:
+                    callback(i, latents, eps)
             return latents
         x_in = torch.empty((2 * B, 4, H, W), device=dev, dtype=torch.float16)
         t_in = torch.zeros(1, device=dev, dtype=torch.long)
@@ -55,12 +67,14 @@ def ddim_sample(unet, control_lora, guide, cond_emb, uncond_emb, steps=50, guida
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             eps_out = unet(x_in, t_in, ehs).sample
-        for t in sched.timesteps:
+        for i, t in enumerate(sched.timesteps, 1):
             x_in.copy_(torch.cat([latents, latents], 0))
             t_in.fill_(int(t))
             g.replay()
             eps_u, eps_c = eps_out.float().chunk(2)
             latents = sched.step(eps_u + guidance_scale * (eps_c - eps_u), t, latents)
+            if callback is not None:
+                callback(i, latents, eps_out)
         return latents
 
 
@@ -96,7 +110,8 @@ class ControlLoRAPipeline:
     @torch.no_grad()
     def __call__(self, prompt, guide, a_prompt="", n_prompt="", num_samples=1, ddim_steps=50, scale=9.0, seed=None,
                  output_type="uint8", sampler="ddim"):
-        """guide: float tensor [1 or N, 3, H, W] in [-1, 1] (H, W multiples of 64)"""
+        """guide: float tensor [1, 3, H, W] (broadcast over the samples) or [num_samples, 3, H, W] (one guide per image), in
+        [-1, 1]; H, W multiples of 64"""
         dev = next(self.text_encoder.parameters()).device
         gen = torch.Generator(device=dev)
         if seed is not None:

@@ -79,13 +79,26 @@ def inputs(res=256, batch=1, seed=42):
                 ehs=torch.randn(batch, 77, 768, generator=g).half().float())
 
 
+def product_add_noise(inp, dev):
+    """The PRODUCT's DDPM `add_noise` (controllora_amd/schedulers.py; reference train...:765) on the device, the way the
+    entry point calls it (fp16 latents / noise), asserted against the oracle's: the fp32 oracle result rounded
+    to fp16 may differ from the fp16 evaluation by one rounding of each product and of the sum."""
+    from controllora_amd.schedulers import DDPMScheduler
+    ts = inp["timesteps"].to(dev)
+    noisy = DDPMScheduler().add_noise(inp["latents"].to(dev).to(f16), inp["noise"].to(dev).to(f16), ts).to(f16)
+    ref = unet_ref.DDPMSchedule().add_noise(inp["latents"], inp["noise"], inp["timesteps"])
+    e = rel(noisy, ref)
+    assert e < 6e-4, f"product add_noise vs oracle: rel-L2 {e:.2e}"
+    return noisy
+
+
 def train_step_parity(config_name, dev, res=256, batch=1):
     """One reference train step (train...:757-790) on the SD-1.5 topology: returns rel-L2 of the control maps, the UNet
     prediction, the loss and the flat gradient of every trainable parameter (adapters + hint encoder)."""
     o_unet, o_clora, p_unet, p_clora = build_pair(config_name, dev)
     inp = inputs(res, batch)
     gold = cases.oracle_train_step(o_unet, o_clora, o_clora, inp)
-    noisy = unet_ref.DDPMSchedule().add_noise(inp["latents"], inp["noise"], inp["timesteps"]).to(dev).to(f16)
+    noisy = product_add_noise(inp, dev)
     trainer = ControlLoRATrainer(p_unet, p_clora, init_scale=1024.0, dynamic_scale=False)
     pred = trainer.forward_backward(noisy, inp["timesteps"].to(dev), inp["ehs"].to(dev).to(f16),
                                     inp["guide"].to(dev).to(f16), inp["noise"].to(dev))
@@ -209,3 +222,89 @@ def full_size_properties(dev, config_name="fill50k.json", res=512, batch=4):
     out["grad_additivity"] = rel(g4, gsum / batch)
     out["grad_norm"] = float(g4.norm())
     return out
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# BASELINE's own sizes against COMMITTED oracle fixtures (oracle/make_fullsize_golden.py, written in the build container)
+def _checksum(t):
+    t = t.detach().double().reshape(-1).cpu()
+    return torch.stack([t.sum(), t.abs().sum()])
+
+
+def _assert_same_inputs(fx, name, t):
+    got, want = _checksum(t), fx[name].double()
+    assert torch.allclose(got, want, rtol=1e-9, atol=1e-6), f"{name}: seeded input differs from the fixture's ({got} vs {want})"
+
+
+def load_fixture(name):
+    from safetensors import safe_open
+    path = os.path.join(ROOT, "tests", "golden", name)
+    with safe_open(path, "pt") as f:
+        return {k: f.get_tensor(k) for k in f.keys()}, f.metadata()
+
+
+def train_step_vs_fixture(dev):
+    """BASELINE configs[1] (configs/fill50k.json, SD-1.5 topology, 512x512, batch 4; reference train...:751-796): the product
+    train step on the GPU against tests/golden/full_train_512_bs4.safetensors -- prediction, loss, the four control maps
+    (strided sample + norm), the flat 6,047,040-element gradient (strided sample, norm, per-parameter norms)."""
+    from oracle import cases as ocases
+    fx, meta = load_fixture("full_train_512_bs4.safetensors")
+    sg, sc = int(meta["stride_grad"]), int(meta["stride_ctrl"])
+    o_unet, o_clora, p_unet, p_clora = build_pair(meta["config"], dev)
+    assert torch.allclose(ocases.weight_checksum(o_unet), fx["weights_checksum_unet"].double(), rtol=1e-9), "seeded UNet weights differ"
+    assert torch.allclose(ocases.weight_checksum(o_clora), fx["weights_checksum_clora"].double(), rtol=1e-9), "seeded adapters differ"
+    inp = inputs(int(meta["res"]), int(meta["batch"]), seed=int(meta["input_seed"]))
+    for k in ("guide", "latents", "noise", "ehs"):
+        _assert_same_inputs(fx, f"in_{k}_checksum", inp[k])
+    assert torch.equal(inp["timesteps"], fx["in_timesteps"])
+    noisy = product_add_noise(inp, dev)
+    trainer = ControlLoRATrainer(p_unet, p_clora, init_scale=1024.0, dynamic_scale=False)
+    pred = trainer.forward_backward(noisy, inp["timesteps"].to(dev), inp["ehs"].to(dev).to(f16),
+                                    inp["guide"].to(dev).to(f16), inp["noise"].to(dev))
+    grads = trainer.unscaled_grads_module_order().float().cpu()
+    errs = {"pred": rel(pred, fx["pred"]),
+            "loss": abs(trainer.loss(pred.numel()) - float(fx["loss"])) / float(fx["loss"]),
+            "grads_sample": rel(grads[::sg], fx["grads_sample"]),
+            "grads_norm": abs(float(grads.double().norm()) - float(fx["grads_norm"])) / float(fx["grads_norm"])}
+    for i, c in enumerate(p_clora(inp["guide"].to(dev).to(f16)).control_states):
+        c = c.float().cpu()                              # NCHW view: same element order as the oracle's maps
+        errs[f"control_{i}"] = rel(c.reshape(-1)[::sc], fx[f"control_{i}_sample"])
+        errs[f"control_{i}_norm"] = abs(float(c.double().norm()) - float(fx[f"control_{i}_norm"])) / float(fx[f"control_{i}_norm"])
+    # per-parameter gradient norms: an error confined to one small tensor cannot hide inside the global rel-L2
+    names = meta["param_names"].split("\n")
+    sizes = [p.numel() for _, p in p_clora.named_parameters()]
+    assert names == [n for n, _ in p_clora.named_parameters()] and sum(sizes) == grads.numel()
+    want = fx["grads_param_norms"].double()
+    got = torch.stack([c.double().norm() for c in torch.split(grads, sizes)])
+    big = want > 1e-3 * want.max()
+    errs["param_norm_worst"] = float(((got - want).abs() / want)[big].max())
+    errs["param_norm_small_abs_worst"] = float(((got - want).abs()[~big]).max() / want.max()) if bool((~big).any()) else 0.0
+    errs["n_params"] = len(names)
+    errs["oracle_seconds"] = float(fx["oracle_seconds"])
+    return errs
+
+
+def ddim_vs_fixture(dev, graph=True):
+    """BASELINE inference geometry (reference apps/gradio_canny2image.py:83-89): 50 DDIM steps, CFG 9.0, 512x512, UNet batch 4
+    (2 images), product `pipeline.ddim_sample` vs tests/golden/full_ddim_512_50.safetensors: the first UNet evaluation, the
+    trajectory at 8 steps and the final denoised latents (the quantity north_star states 1e-3 for)."""
+    from controllora_amd.pipeline import ddim_sample
+    from oracle import cases as ocases
+    from oracle.make_fullsize_golden import ddim_inputs
+    fx, meta = load_fixture("full_ddim_512_50.safetensors")
+    o_unet, o_clora, p_unet, p_clora = build_pair(meta["config"], dev)
+    assert torch.allclose(ocases.weight_checksum(o_unet), fx["weights_checksum_unet"].double(), rtol=1e-9)
+    assert torch.allclose(ocases.weight_checksum(o_clora), fx["weights_checksum_clora"].double(), rtol=1e-9)
+    guide, cond, uncond, lat0 = ddim_inputs(int(meta["res"]), int(meta["images"]), int(meta["input_seed"]))
+    for k, v in (("guide", guide), ("cond", cond), ("uncond", uncond), ("lat0", lat0)):
+        _assert_same_inputs(fx, f"in_{k}_checksum", v)
+    traj = {}
+    out = ddim_sample(p_unet, p_clora, guide.to(dev).half(), cond.to(dev).half(), uncond.to(dev).half(),
+                      steps=int(meta["steps"]), guidance_scale=float(meta["guidance_scale"]), latents=lat0.to(dev).half(),
+                      graph=graph, callback=lambda i, x, eps: traj.__setitem__(i, (x.float().cpu().clone(), eps.float().cpu().clone())))
+    errs = {"latents": rel(out, fx["latents"]), "eps_step01": rel(traj[1][1], fx["eps_step01"]),
+            "latent_norm": float(fx["latents"].norm()), "oracle_seconds": float(fx["oracle_seconds"])}
+    for k in sorted(fx):
+        if k.startswith("latents_step"):
+            errs[k] = rel(traj[int(k[-2:])][0], fx[k])
+    return errs

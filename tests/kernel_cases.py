@@ -263,6 +263,30 @@ def case_attention(dev, B, H, Nq, Nk, D, seed=3, fused_qkv=False, tol=2e-3, ramp
         assert e < 2 * tol, (name, e)
 
 
+def case_attention_negative_logits(dev, B, H, Nq, Nk, D, seed=31):
+    """every logit of the FIRST KV tile far below -88 (q = +8, k = -8 on every channel: logit
+    -64 * sqrt(D)): the lazy exponent reference must not rescale the still-empty accumulators by exp2(+huge) = inf
+    (0 * inf = NaN).  Later tiles carry ordinary keys, so the result is an ordinary softmax over those."""
+    g = torch.Generator().manual_seed(seed)
+    scale = D ** -0.5
+    q2 = torch.full((B * Nq, H * D), 8.0, dtype=f16, device=dev)
+    k2 = rnd((B * Nk, H * D), dev, g, scale=0.05)
+    v2 = rnd((B * Nk, H * D), dev, g)
+    k3 = k2.reshape(B, Nk, H * D).clone()
+    k3[:, :min(64, Nk)] = -8.0                               # the whole first tile (or every key when Nk <= 64)
+    k2 = k3.reshape(B * Nk, H * D).contiguous()
+    ref = _attn_ref(q2.reshape(B, Nq, H * D), k2.reshape(B, Nk, H * D), v2.reshape(B, Nk, H * D), H, scale)
+    o, lse = K.attn_fwd(q2, k2, v2, B, H, Nq, Nk, D, scale)
+    assert bool(torch.isfinite(o.float()).all()) and bool(torch.isfinite(lse).all())
+    e = rel(o, ref.reshape(B * Nq, H * D))
+    assert e < 2e-3, e
+    dO = rnd((B * Nq, H * D), dev, g)
+    dq, dk, dv = torch.empty_like(q2), torch.empty_like(k2), torch.empty_like(v2)
+    K.attn_bwd(q2, k2, v2, o, dO, lse, B, H, Nq, Nk, D, scale, dq, dk, dv)
+    for t_ in (dq, dk, dv):
+        assert bool(torch.isfinite(t_.float()).all())
+
+
 def case_attention_block_order(dev, B, H, Nq, Nk, D, seed=23):
     """whole heads per XCD (tile_order != "m") only permutes which workgroup handles which (head, block): the forward
     output, LSE and the three gradients are bit-identical; the grid (3 x 6 blocks at Nq = 300, B*H = 6) is not a multiple of 8"""

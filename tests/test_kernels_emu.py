@@ -111,6 +111,12 @@ def test_attention_block_order_does_not_change_results(B, H, Nq, Nk, D):
     KC.case_attention_block_order("cpu", B, H, Nq, Nk, D)
 
 
+@pytest.mark.parametrize("Nk,D", [(40, 40), (64, 64), (200, 40), (130, 64), (100, 80)])
+def test_attention_first_tile_far_below_zero(Nk, D):
+    """first KV tile with every logit below -88 (single-tile and multi-tile, ones-column and summed row sums)"""
+    KC.case_attention_negative_logits("cpu", 1, 2, 40, Nk, D)
+
+
 @pytest.mark.parametrize("D", [40, 80])
 def test_attention_rising_maxima(D):
     """forward: lazy exponent reference, rebased on later KV tiles for a subset of the queries (D = 40: rowsum from the ones column)"""

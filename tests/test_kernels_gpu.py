@@ -88,6 +88,12 @@ def test_attention(B, H, Nq, Nk, D, fused):
     KC.case_attention(DEV, B, H, Nq, Nk, D, fused_qkv=fused)
 
 
+@pytest.mark.parametrize("Nq,Nk,D", [(4096, 4096, 40), (300, 64, 40), (300, 77, 64), (1024, 1024, 80), (256, 256, 160)])
+def test_attention_first_tile_far_below_zero(Nq, Nk, D):
+    """first KV tile with every logit below -88: finite outputs, ordinary softmax over the later tiles"""
+    KC.case_attention_negative_logits(DEV, 2, 8, Nq, Nk, D)
+
+
 @pytest.mark.parametrize("Nq,Nk,D", [(1024, 4096, 40), (300, 1000, 80), (70, 300, 160)])
 def test_attention_rising_maxima(Nq, Nk, D):
     """forward: lazy exponent reference, rebased on later KV tiles for a subset of the queries (D = 40: rowsum from the ones column)"""

@@ -7,7 +7,7 @@
 # `git log --oneline -- controllora_amd/csrc/<file>`; the file must still match the current include/clora.h structs):
 #   tools/build_prev_lib.sh 62e4530:clora_norm.hip b00c262:clora_lora.hip
 set -e
-root=$(cd "$(dirname "$0")/.." && pwd)
+root=$(cd "$(dirname "$0")/../.." && pwd)
 out=$root/controllora_amd/_build_prev
 tmp=$(mktemp -d)
 mkdir -p "$out" "$tmp/controllora_amd/csrc" "$tmp/include"

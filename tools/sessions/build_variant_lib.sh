@@ -3,7 +3,7 @@
 # -DCLORA_EPI_SINGLE_PASS), for same-box A/B runs through CLORA_LIB_PATH.  Run in the dev container before gpurun.
 #   tools/build_variant_lib.sh -DCLORA_EPI_SINGLE_PASS
 set -e
-root=$(cd "$(dirname "$0")/.." && pwd)
+root=$(cd "$(dirname "$0")/../.." && pwd)
 out=$root/controllora_amd/_build_variant
 mkdir -p "$out"
 objs=""

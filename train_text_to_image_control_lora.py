@@ -151,7 +151,10 @@ def main(argv=None):
     # Adapter init: with --seed every rank draws the same init from a forked stream (and the per-rank noise / timestep
     # stream seeded above is left untouched); without --seed the run stays unseeded like the reference -- rank 0's init
     # reaches the other ranks through the trainer's broadcast of the flat parameter buffer.
-    with torch.random.fork_rng(devices=[]):
+    # torch.manual_seed() also reseeds every HIP generator, so the device stream is forked too: otherwise all ranks would
+    # draw identical noise / timesteps / VAE samples after this block.
+    fork_devs = [torch.device(dev).index or 0] if torch.device(dev).type == "cuda" else []
+    with torch.random.fork_rng(devices=fork_devs):
         if args.seed is not None:
             torch.manual_seed(args.seed)
         control_lora = M.ControlLoRA.from_config(args.control_lora_config).to(dev)
