@@ -90,9 +90,31 @@ def build_models(dev, seed=0, config="fill50k.json"):
     return unet, clora
 
 
-def cpu_baseline(steps=2):
+def _pick_cpu_threads(unet, b):
+    """The oracle is timed at the thread count that serves it best on this host: torch's default (all hardware threads)
+    loses to a smaller pool on many-core hosts (oversubscribed SMT / NUMA).  One UNet forward per candidate, ~2-3 s each."""
+    import os as _os
+    hw = _os.cpu_count() or 1
+    cands = sorted({c for c in (hw, hw // 2, hw // 4, 32) if 1 <= c <= hw}, reverse=True)
+    best, best_t = torch.get_num_threads(), None
+    with torch.no_grad():
+        for c in cands:
+            torch.set_num_threads(c)
+            unet(b["latents"].float(), b["timesteps"], b["ehs"].float())        # page in / thread pool spin-up
+            t0 = time.perf_counter()
+            unet(b["latents"].float(), b["timesteps"], b["ehs"].float())
+            dt = time.perf_counter() - t0
+            if best_t is None or dt < best_t:
+                best, best_t = c, dt
+    torch.set_num_threads(best)
+    return best
+
+
+def cpu_baseline(steps=3, full=False):
     """The CPU oracle (pure-torch fp32 restatement of the reference path, materialised attention) on BASELINE
-    configs[0]: fill50k.json, SD-1.5, 256x256, batch 1.  Bounded sample: 1 warm-up + `steps` timed steps."""
+    configs[0]: fill50k.json, SD-1.5, 256x256, batch 1.  Bounded sample: 1 warm-up + `steps` timed steps (SURVEY.md
+    section 8d asks for >= 3).  full=True (--cpu-baseline-full) adds one 512x512 bs1 step and the oracle's DDIM + CFG
+    UNet evaluation (batch 2) at 512x512: minutes of CPU work, reported in extra keys."""
     from oracle import cases, unet_ref
     from oracle.controllora_ref import ControlLoRARef, map_processors_to_unet
     torch.manual_seed(0)
@@ -101,22 +123,50 @@ def cpu_baseline(steps=2):
     clora = ControlLoRARef.from_config(os.path.join(ROOT, "configs", "fill50k.json"))
     unet.set_attn_processor(map_processors_to_unet(unet, clora))
     opt = torch.optim.AdamW(clora.parameters(), lr=1e-4, weight_decay=1e-2)
-    b = synthetic_batch(1, 256, "cpu", 42)
-    inp = dict(guide=b["guide"].float(), latents=b["latents"].float(), noise=b["noise"].float(),
-               timesteps=b["timesteps"], ehs=b["ehs"].float())
-    times = []
-    for i in range(steps + 1):
-        t0 = time.perf_counter()
-        cases.oracle_train_step(unet, clora, clora, inp)
-        torch.nn.utils.clip_grad_norm_(clora.parameters(), 1.0)
-        opt.step()
-        opt.zero_grad()
-        if i > 0:
-            times.append(time.perf_counter() - t0)
-    sec = sum(times) / len(times)
-    return {"value": round(1.0 / sec, 4), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle (pure-torch fp32, materialised attention) train step, fill50k.json SD-1.5 256x256 bs1, "
-                      f"{steps} steps after 1 warm-up, {sec:.2f} s/step"}
+
+    def batch_of(res):
+        b = synthetic_batch(1, res, "cpu", 42)
+        return dict(guide=b["guide"].float(), latents=b["latents"].float(), noise=b["noise"].float(),
+                    timesteps=b["timesteps"], ehs=b["ehs"].float())
+
+    inp = batch_of(256)
+    with torch.no_grad():
+        clora(inp["guide"])
+    threads = _pick_cpu_threads(unet, inp)
+
+    def timed_steps(inp, n):
+        times = []
+        for i in range(n + 1):
+            t0 = time.perf_counter()
+            cases.oracle_train_step(unet, clora, clora, inp)
+            torch.nn.utils.clip_grad_norm_(clora.parameters(), 1.0)
+            opt.step()
+            opt.zero_grad()
+            if i > 0:
+                times.append(time.perf_counter() - t0)
+        return sum(times) / len(times)
+
+    sec = timed_steps(inp, steps)
+    out = {"value": round(1.0 / sec, 4), "unit": "images/s", "cores": threads, "kind": "port",
+           "sample": f"oracle (pure-torch fp32, materialised attention) train step, fill50k.json SD-1.5 256x256 bs1, "
+                     f"{steps} steps after 1 warm-up, {sec:.2f} s/step, {threads} of {os.cpu_count()} hardware threads "
+                     f"(fastest of the candidates tried)"}
+    if full:
+        inp512 = batch_of(512)
+        sec512 = timed_steps(inp512, 1)
+        out["train_512_bs1"] = {"s_per_step": round(sec512, 2), "images_per_s": round(1.0 / sec512, 4), "steps": 1}
+        with torch.no_grad():
+            clora(inp512["guide"])
+            x = torch.cat([inp512["latents"]] * 2)
+            ehs = torch.cat([inp512["ehs"]] * 2)
+            unet(x, 981, ehs)
+            t0 = time.perf_counter()
+            for t in (961, 941):
+                unet(x, t, ehs)
+            dt = (time.perf_counter() - t0) / 2
+        out["ddim_512_1image"] = {"s_per_step": round(dt, 2), "extrapolated_50_steps_s": round(50 * dt, 1),
+                                  "what": "oracle UNet evaluation of one DDIM + CFG step (UNet batch 2), 512x512, 2 timed steps"}
+    return out
 
 
 def _free_port():
@@ -209,6 +259,65 @@ def rocprof_child_trace(args, steps=6, warmup=2):
     return res
 
 
+def rocprof_child_pmc(args, counter, steps=2, warmup=1):
+    """One `rocprofv3 --pmc <counter>` pass over THIS command issued eagerly (counter collection serialises the kernels; a
+    hipGraph replay is not instrumented per node), --kernel-trace / --stats only as gpurun requires: per-kernel
+    [(grid, bytes)] lists, or {"error": ...}.  FETCH_SIZE and WRITE_SIZE need separate passes (TCC slots, MI355X_MICROARCH.md)."""
+    import re
+    import sqlite3
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return {"error": "rocprofv3 not found"}
+    out = tempfile.mkdtemp(prefix="clora_pmc_", dir="/tmp")
+    cmd = [exe, "--pmc", counter, "-d", out, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__), "--trace-child", "--no-graph",
+           "--steps", str(steps), "--warmup", str(warmup), "--batch", str(args.batch), "--res", str(args.res), "--config", args.config]
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    try:
+        r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+        dbs = glob.glob(os.path.join(out, "**", "*.db"), recursive=True)
+        if r.returncode != 0 or not dbs:
+            return {"error": f"rocprofv3 --pmc {counter} rc={r.returncode}", "tail": r.stdout.decode(errors="replace")[-300:]}
+        res = {}
+        cur = sqlite3.connect(dbs[0]).cursor()
+        for name, grid, val in cur.execute("select kernel_name, grid_size, value from counters_collection"):
+            res.setdefault(re.sub(r"\(anonymous namespace\)::", "", name), []).append((grid, val * 1024.0))   # counters are in KiB
+        return res
+    except Exception as e:                                   # noqa: BLE001
+        return {"error": repr(e)}
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+
+
+def measured_traffic(args, family):
+    """HBM-side (L2 <-> fabric) bytes per launch of the kernel family, measured by THIS run: two PMC child passes.
+    gfx950 correction as the guide prescribes (FETCH_SIZE counts 128-byte requests at 64 B: x2), checked in place on a
+    kernel whose read volume is known exactly (the hint encoder's first GroupNorm statistics pass reads B*H*W*32 fp16
+    values once)."""
+    F = rocprof_child_pmc(args, "FETCH_SIZE")
+    if "error" in F:
+        return None, F
+    W = rocprof_child_pmc(args, "WRITE_SIZE")
+    if "error" in W:
+        return None, W
+    known = args.batch * args.res * args.res * 32 * 2
+    cal = max((v for k, vs in F.items() if "gn_fwd_partial" in k for _, v in vs), default=0.0)
+    factor = known / cal if cal > 0 else 2.0
+    if not 1.5 < factor < 2.5:
+        factor = 2.0                                         # calibration kernel changed shape: fall back to the guide's x2
+    fb = sum(v for k, vs in F.items() if any(t in k for t in family) for _, v in vs)
+    wb = sum(v for k, vs in W.items() if any(t in k for t in family) for _, v in vs)
+    n = sum(len(vs) for k, vs in F.items() if any(t in k for t in family))
+    if n == 0:
+        return None, {"error": "no kernel of the family in the PMC pass"}
+    return round((fb * factor + wb) / n), {
+        "static": False, "how": "two rocprofv3 --pmc child passes of this command (FETCH_SIZE, WRITE_SIZE; eager step, "
+                                "3 steps each), L2<->fabric bytes per launch = FETCH_SIZE x correction + WRITE_SIZE",
+        "fetch_correction": round(factor, 3), "calibration": "hint-encoder gn_fwd_partial reads B*H*W*32*2 bytes exactly once",
+        "launches_in_pass": n, "fetch_bytes_per_launch": round(fb * factor / n), "write_bytes_per_launch": round(wb / n)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -230,6 +339,9 @@ def main():
                     "rendezvous, flat all-reduce, rank-0 line) without touching a GPU")
     ap.add_argument("--trace-child", action="store_true", help=argparse.SUPPRESS)    # run by rocprof_child_trace()
     ap.add_argument("--no-rocprof", action="store_true", help="skip the rocprofv3 child run (roofline falls back to HIP events)")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 --pmc child passes (roofline.traffic = null)")
+    ap.add_argument("--cpu-baseline-full", action="store_true", help="also time the CPU oracle at 512x512 bs1 and its DDIM "
+                    "UNet evaluation (SURVEY.md section 8d; minutes of CPU work, not part of the default run)")
     ap.add_argument("--trace-out", default=None, help="write the child run's full per-kernel table (json) here, e.g. profiles/r02_kernel_stats.json")
     args = ap.parse_args()
 
@@ -356,17 +468,10 @@ def main():
         # HBM-side traffic per launch of the dominant family: PMC counters need their own rocprofv3 --pmc passes
         # (tools/pmc_traffic.sh -> tools/pmc_summary.py); the committed result of the latest passes is reported with
         # "static": true and the commit / round it was measured at -- it does not move with this run.
+        # measured by THIS run (two --pmc child passes) or null -- never read from a committed file
         traffic, traffic_src = None, None
-        pmc_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic*.json")))
-        if dom_name.startswith("clora_gemm") and pmc_files:
-            pmc = json.load(open(pmc_files[-1]))
-            ks = [v for k, v in pmc["kernels"].items() if any(t in k for t in GEMM_FAMILY)]
-            n = sum(v["launches"] for v in ks)
-            traffic = round(sum(v["launches"] * (v["fetch_bytes_per_launch_corrected"] + (v["write_bytes_per_launch_raw"] or 0.0))
-                                for v in ks) / n)
-            traffic_src = {"static": True, "file": os.path.relpath(pmc_files[-1], ROOT), "measured_at": pmc.get("measured_at"),
-                           "how": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command (L2<->fabric bytes, "
-                                  "FETCH_SIZE x2 gfx950 correction calibrated in place)"}
+        if dom_name.startswith("clora_gemm") and world == 1 and not args.no_rocprof and not args.no_pmc:
+            traffic, traffic_src = measured_traffic(args, GEMM_FAMILY)
         roofline = {"bound": "mfma", "kernel": dom_name, "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "duration_source": src,
                     "family_ms_per_step": round(fam_ms, 3), "launches": fam_launches,
@@ -445,7 +550,7 @@ def main():
 
     cpu = None
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
-        cpu = cpu_baseline()
+        cpu = cpu_baseline(full=args.cpu_baseline_full)
 
     if rank == 0:
         print(json.dumps({

@@ -122,6 +122,21 @@ class Lib:
         self.cdll.clora_build_info.restype = C.c_char_p
         self.cdll.clora_groupnorm_workspace_bytes.restype = C.c_size_t
         self.cdll.clora_lora_wgrad_workspace_bytes.restype = C.c_size_t
+        self._options_from_env()
+
+    # The library reads no environment variable; A/B runs set its knobs (clora_set_option, the ABI's single piece of
+    # process-global state) through these variables, forwarded here when the library is loaded.
+    _ENV_OPTIONS = {"CLORA_TILE_ORDER": ("tile_order", {"m": 0, "n": 1, "auto": 2, "a": 2}), "CLORA_LN_ROWS": ("ln_rows", None),
+                    "CLORA_ATTN_FWD_WAVES": ("attn_fwd_waves", None), "CLORA_ATTN_BWD_WAVES": ("attn_bwd_waves", None),
+                    "CLORA_GN_BLOCKS": ("gn_blocks", None)}
+
+    def _options_from_env(self):
+        for var, (name, names) in self._ENV_OPTIONS.items():
+            v = os.environ.get(var)
+            if v is None or v == "":
+                continue
+            val = names[v] if (names and v in names) else int(v)
+            self.call("clora_set_option", name.encode(), val)
 
     def call(self, name: str, *args) -> None:
         rc = getattr(self.cdll, name)(*args)

@@ -653,8 +653,8 @@ __global__ __launch_bounds__(256) void attn_dkv_convert_kernel(AttnArgs p) {
 
 template <int DP, int DT>
 int launch_fwd(const AttnArgs& a, hipStream_t s) {
-    // wider blocks when there are enough queries to keep the grid full (A/B: CLORA_ATTN_FWD_WAVES = 4 | 6 | 8)
-    static const int forced = [] { const char* e = getenv("CLORA_ATTN_FWD_WAVES"); return e ? atoi(e) : 0; }();
+    // wider blocks when there are enough queries to keep the grid full (A/B: clora_set_option("attn_fwd_waves", 4 | 6 | 8))
+    const int forced = clora_option(CLORA_OPT_ATTN_FWD_WAVES);
     int nw = forced ? forced : ((DP <= 64 && (long)clora_cdiv(a.Nq, 256) * a.B * a.H >= 512) ? 8 : 4);   // measured: 6 waves lose, 8 win 10-18 %
     if (DP > 64 && nw != 4) nw = 4;                         // larger head dims keep the 4-wave block (LDS / registers)
     const bool ones = a.D == DT * 16 - 8;
@@ -677,8 +677,8 @@ int launch_fwd(const AttnArgs& a, hipStream_t s) {
 template <int DP, int DT, int BT>
 int launch_bwd(const AttnArgs& a, hipStream_t s) {
     // 8-wave blocks (one per CU: the same 8 waves as two 4-wave blocks, half the K/V resp. Q/dO stream per flop) when the grids stay
-    // full; A/B: CLORA_ATTN_BWD_WAVES = 4 | 8
-    static const int forced = [] { const char* e = getenv("CLORA_ATTN_BWD_WAVES"); return e ? atoi(e) : 0; }();
+    // full; A/B: clora_set_option("attn_bwd_waves", 4 | 8)
+    const int forced = clora_option(CLORA_OPT_ATTN_BWD_WAVES);
     const bool wide_q = forced ? forced == 8 : (DP <= 64 && (long)clora_cdiv(a.Nq, 256) * a.B * a.H >= 256);
     const bool wide_k = forced ? forced == 8 : (DP <= 64 && a.nsplit == 1 && (long)clora_cdiv(a.Nk, 256) * a.B * a.H >= 256);
     if constexpr (DP <= 64) {

@@ -133,12 +133,16 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
-// XCD assignment policy of the launches that follow (clora_set_option("tile_order") / CLORA_TILE_ORDER, defined in clora_gemm.hip):
-// 0 = launch-order defaults, 1 = n-major GEMM tiles (tests), 2 = fewest distinct operand panels per XCD; non-zero also gives
-// every XCD whole attention heads (clora_attn.hip attn_block_ids)
-__attribute__((visibility("hidden"))) int clora_xcd_policy();
-// LayerNorm with several rows in flight per wave (default 1; clora_set_option("ln_rows") / CLORA_LN_ROWS=0: one row per wave)
-__attribute__((visibility("hidden"))) int clora_ln_rows();
+// The library's ONLY process-global state: the tuning knobs of clora_set_option (include/clora.h), one int each, defined in
+// clora_gemm.hip.  Results never depend on them.  The library itself reads no environment variable: the host layer
+// (controllora_amd/capi.py) forwards CLORA_* variables through clora_set_option when it loads the library.
+enum { CLORA_OPT_TILE_ORDER = 0, CLORA_OPT_LN_ROWS, CLORA_OPT_ATTN_FWD_WAVES, CLORA_OPT_ATTN_BWD_WAVES, CLORA_OPT_GN_BLOCKS, CLORA_OPT_COUNT };
+__attribute__((visibility("hidden"))) int clora_option(int id);
+// XCD assignment policy of the launches that follow ("tile_order"): 0 = launch-order defaults, 1 = n-major GEMM tiles (tests),
+// 2 = fewest distinct operand panels per XCD; non-zero also gives every XCD whole attention heads (clora_attn.hip attn_block_ids)
+static inline int clora_xcd_policy() { return clora_option(CLORA_OPT_TILE_ORDER); }
+// LayerNorm with several rows in flight per wave ("ln_rows", default 1; 0: one row per wave)
+static inline int clora_ln_rows() { return clora_option(CLORA_OPT_LN_ROWS); }
 
 static inline int clora_check_launch() { return hipGetLastError() == hipSuccess ? CLORA_OK : CLORA_ERR_LAUNCH; }
 static inline int clora_cdiv(long a, long b) { return (int)((a + b - 1) / b); }

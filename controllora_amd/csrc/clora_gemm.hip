@@ -414,11 +414,23 @@ __device__ __forceinline__ void dma_epilogue(const GemmArgs& p, floatx4 (&acc)[B
     // HOIST: only the kernels built for <= 2 blocks per CU have the 40 registers to spare (the others spilled accumulators: measured
     // +0.6 ms per train step), and a thread must own >= 4 output chunks for the hoist to amortise (2 on the 64x64 tile)
     constexpr bool HOIST_PAYS = HOIST && (BM * CPR / NT) >= 4 && (BM / WM / 16) * (BN / WN / 16) * 4 < 128;
+    // the two-phase chunk loop (below) only where the register file has the room: the 8-wave tiles up to 128 rows (64x320, 128x320,
+    // 128x256: one block per CU, 256 VGPRs per wave); the 256-row tiles and the 2-blocks-per-CU kernels would spill
+    constexpr bool TWO_PHASE = HOIST_PAYS && NT == 512 && BM <= 128;
     const bool hoist = HOIST_PAYS && p.epi.lora_t != nullptr && p.epi.lora_r == 4 && p.epi.geglu == 0 && n < p.N &&
                        ((p.epi.ldt | ((n / p.epi.lora_seg) * 4)) & 3) == 0 && (p.epi.lora_u_tr ? (p.epi.ldu & 3) == 0 : p.epi.ldu == 4);
+    // `two`: this thread takes the two-phase chunk loop -- adapter launches it can hoist, and launches without an adapter
+    // (proj_in / proj_out / FF2 and the dgrads: bias and / or residual only)
+    const bool two = TWO_PHASE && p.epi.geglu == 0 && !p.epi.rowadd && n < p.N && (hoist || p.epi.lora_t == nullptr);
     floatx4 ureg[8];
     float bias8[8];
     int utoff = 0;
+    if (two && !hoist) {
+        floatx4 b0 = zero4f(), b1 = zero4f();
+        if (p.epi.bias) { b0 = *reinterpret_cast<const floatx4*>(p.epi.bias + n); b1 = *reinterpret_cast<const floatx4*>(p.epi.bias + n + 4); }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { bias8[e] = b0[e]; bias8[4 + e] = b1[e]; }
+    }
     if (hoist) {
         utoff = (n / p.epi.lora_seg) * 4;
 #pragma unroll
@@ -540,7 +552,69 @@ __device__ __forceinline__ void dma_epilogue(const GemmArgs& p, floatx4 (&acc)[B
         };
         if constexpr (HOIST_PAYS) {
             // thread -> one fixed chunk column, rows ml = t / CPR + it * RPIT: what depends on the column only is already in registers
-            for (int ml = t / CPR; ml < PR && t < RPIT * CPR; ml += RPIT) chunk(ml, nc, n);
+            if (two) {
+                // Two-phase form: the accumulators are dead (staged in LDS), so the T row and the residual chunk of EVERY row this
+                // thread owns are requested before the first one is used.  In the loop below each iteration is load -> wait -> use ->
+                // store, and the compiler may not move a load above the previous iteration's store (C / residual / T may alias):
+                // five to six dependent L2 round trips per thread on the short-K projections, whose main loop is only 5 k-steps.
+                // Rows past the tile / matrix re-read the tile's first row (always valid) and are masked at the store.
+                constexpr int NIT = (PR + RPIT - 1) / RPIT;
+                floatx4 t4s[NIT];
+                half8 rrs[NIT];
+                const bool col_ok = t < RPIT * CPR;
+                const bool has_res = p.epi.residual != nullptr;
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    const int ml = t / CPR + it * RPIT, m = m0 + ph * PR + ml;
+                    const int mc = (col_ok && ml < PR && m < p.M) ? m : m0;
+                    t4s[it] = zero4f();
+                    if (hoist) t4s[it] = *reinterpret_cast<const floatx4*>(p.epi.lora_t + (size_t)mc * p.epi.ldt + utoff);
+                    rrs[it] = zero8();
+                    if (has_res) rrs[it] = ld8((const half_t*)p.epi.residual + (size_t)mc * p.epi.ldr + n);
+                }
+                // pin the loaded registers only AFTER every load has been issued (an asm that consumes a register waits for its
+                // load): stops the compiler from sinking each load into the conditional block that uses it
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    if (hoist) CLORA_KEEP(t4s[it]);
+                    if (has_res) CLORA_KEEP(rrs[it]);
+                }
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    const int ml = t / CPR + it * RPIT, m = m0 + ph * PR + ml;
+                    if (col_ok && ml < PR && m < p.M) {
+                        const floatx4 f0 = *reinterpret_cast<const floatx4*>(Cf + ml * F_LD + nc * 8);
+                        const floatx4 f1 = *reinterpret_cast<const floatx4*>(Cf + ml * F_LD + nc * 8 + 4);
+                        float v[8] = {f0[0], f0[1], f0[2], f0[3], f1[0], f1[1], f1[2], f1[3]};
+                        if (p.epi.bias) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[e] += bias8[e];
+                        }
+                        if (hoist) {
+                            const floatx4 t4 = t4s[it] * p.epi.lora_scale;
+                            if (p.epi.lora_u_tr) {
+#pragma unroll
+                                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                                    for (int e = 0; e < 8; ++e) v[e] += t4[j] * ureg[2 * j + (e >> 2)][e & 3];
+                            } else {
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) v[e] += t4[0] * ureg[e][0] + t4[1] * ureg[e][1] + t4[2] * ureg[e][2] + t4[3] * ureg[e][3];
+                            }
+                        }
+                        half8 o;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o[e] = (half_t)v[e];
+                        if (has_res) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) o[e] = (half_t)((float)o[e] + (float)rrs[it][e]);
+                        }
+                        st8(p.C + (size_t)m * p.ldc + n, o);
+                    }
+                }
+            } else {
+                for (int ml = t / CPR; ml < PR && t < RPIT * CPR; ml += RPIT) chunk(ml, nc, n);
+            }
         } else {
             for (int c = t; c < PR * CPR; c += NT) {
                 const int ml = c / CPR, ncc = c - ml * CPR;
@@ -1206,16 +1280,10 @@ int conv_mode(const GemmArgs& a, int bk) {
 // (profiles/r02_l2_share_probe.txt).  m-major ranges (n fastest) fetch A about once and B up to eight times -- right for the
 // 64x64 / 32x32 levels (activations 5-30 MB, weights 2-7 MB); at 16x16 / 8x8 the weights are 29-59 MB against 1-3 MB of
 // activations and n-major ranges (m fastest) are the cheaper assignment.  The model counts, per XCD and split, the distinct
-// panels of its range under either order.   g_tile_order: 0 m-major always (default until A/B-measured), 1 n-major always
+// panels of its range under either order.   "tile_order": 0 m-major always, 1 n-major always
 // (tests), 2 pick by the model.
-int g_tile_order = -1;
-int tile_order_mode() {
-    if (g_tile_order < 0) {
-        const char* e = getenv("CLORA_TILE_ORDER");
-        g_tile_order = !e ? 0 : (e[0] == 'n' ? 1 : (e[0] == 'a' ? 2 : 0));
-    }
-    return g_tile_order;
-}
+int g_opts[CLORA_OPT_COUNT] = {2, 1, 0, 0, 512};    // tile_order, ln_rows, attn_fwd_waves (0 = auto), attn_bwd_waves (0 = auto), gn_blocks
+int tile_order_mode() { return g_opts[CLORA_OPT_TILE_ORDER]; }
 
 double fabric_model_bytes(int tiles_m, int tiles_n, int splits, double a_panel, double b_panel, bool n_major) {
     const int tiles = tiles_m * tiles_n, nwg = tiles * splits;
@@ -1498,29 +1566,22 @@ extern "C" int clora_gemm_f16_ex(const clora_half* A, int lda, const clora_half*
     return rc;
 }
 
-int clora_xcd_policy() { return tile_order_mode(); }
-
-static int g_ln_rows = -1;
-int clora_ln_rows() {
-    if (g_ln_rows < 0) {
-        const char* e = getenv("CLORA_LN_ROWS");                 // default on; "0" = one row per wave (A/B)
-        g_ln_rows = (e && atoi(e) == 0) ? 0 : 1;
-    }
-    return g_ln_rows;
-}
+int clora_option(int id) { return (id >= 0 && id < CLORA_OPT_COUNT) ? g_opts[id] : 0; }
 
 extern "C" int clora_set_option(const char* name, int value) {
     if (!name) return CLORA_ERR_ARG;
-    if (!strcmp(name, "tile_order")) {
-        if (value < 0 || value > 2) return CLORA_ERR_ARG;
-        g_tile_order = value;
-        return CLORA_OK;
-    }
-    if (!strcmp(name, "ln_rows")) {
-        if (value < 0 || value > 1) return CLORA_ERR_ARG;
-        g_ln_rows = value;
-        return CLORA_OK;
-    }
+    struct Opt { const char* name; int id, lo, hi; };
+    static const Opt kOpts[] = {{"tile_order", CLORA_OPT_TILE_ORDER, 0, 2}, {"ln_rows", CLORA_OPT_LN_ROWS, 0, 1},
+                                {"attn_fwd_waves", CLORA_OPT_ATTN_FWD_WAVES, 0, 8}, {"attn_bwd_waves", CLORA_OPT_ATTN_BWD_WAVES, 0, 8},
+                                {"gn_blocks", CLORA_OPT_GN_BLOCKS, 64, 1 << 16}};
+    for (const Opt& o : kOpts)
+        if (!strcmp(name, o.name)) {
+            if (value < o.lo || value > o.hi) return CLORA_ERR_ARG;
+            if ((o.id == CLORA_OPT_ATTN_FWD_WAVES && value != 0 && value != 4 && value != 6 && value != 8) ||
+                (o.id == CLORA_OPT_ATTN_BWD_WAVES && value != 0 && value != 4 && value != 8)) return CLORA_ERR_ARG;
+            g_opts[o.id] = value;
+            return CLORA_OK;
+        }
     return CLORA_ERR_ARG;
 }
 

@@ -683,8 +683,8 @@ int gn_plan(GnArgs& a, void* ws, size_t ws_bytes, bool bwd, bool params) {
         return CLORA_ERR_ARG;
     const int CH = a.C / 8;
     const int nrl = CH >= 256 ? 1 : 256 / CH;
-    static const long kBlocks = [] { const char* e = getenv("CLORA_GN_BLOCKS"); const long v = e ? atol(e) : 0; return v >= 64 ? v : 512; }();
-    long rpc = ((long)a.HW * a.B + kBlocks - 1) / kBlocks;   // ~512 blocks in flight (A/B: CLORA_GN_BLOCKS)
+    const long kBlocks = clora_option(CLORA_OPT_GN_BLOCKS);
+    long rpc = ((long)a.HW * a.B + kBlocks - 1) / kBlocks;   // ~512 blocks in flight (A/B: clora_set_option("gn_blocks"))
     if (rpc < 32) rpc = 32;
     if (rpc < 2 * nrl) rpc = 2 * nrl;
     if (rpc > a.HW) rpc = a.HW;

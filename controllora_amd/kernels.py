@@ -194,6 +194,7 @@ def conv_patch_eligible(M: int, conv: ConvDesc, tile_cfg: int) -> bool:
 
 
 TILE_ORDERS = {"m": 0, "n": 1, "auto": 2}
+DEFAULT_TILE_ORDER = "auto"      # the library's default (clora_set_option "tile_order" = 2): -0.16 ms/step over "m", same-box A/B r03
 
 
 def set_option(name: str, value: int) -> None:
@@ -202,7 +203,7 @@ def set_option(name: str, value: int) -> None:
 
 
 def set_tile_order(mode: str) -> None:
-    """tile / attention-block -> XCD assignment of the launches that follow: 'm' (default), 'n' or 'auto'"""
+    """tile / attention-block -> XCD assignment of the launches that follow: 'm', 'n' or 'auto' (default)"""
     set_option("tile_order", TILE_ORDERS[mode])
 
 

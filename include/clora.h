@@ -110,12 +110,17 @@ int clora_gemm_f16_ex(const clora_half* A, int lda, const clora_half* B, clora_h
 int clora_conv_patch_eligible(int M, const clora_conv_t* conv, int tile_cfg);
 
 /* Tuning knobs, no reference counterpart: results never depend on them (bit-identical outputs, tests/test_kernels_*.py).
- * Process-wide; they take effect for the launches that follow (a captured hipGraph keeps what it was captured with).
- *   "tile_order"  how clora_gemm_f16[_ex] assigns output tiles -- and the attention kernels their (batch, head) blocks -- to the
- *                 eight XCDs.  0 = every XCD a contiguous range of tiles in m-major order, attention blocks in launch order
- *                 (default; CLORA_TILE_ORDER unset / "m"); 1 = n-major tile ranges ("n"); 2 = per launch the order that
- *                 fetches fewer distinct A / B panels per XCD ("auto").  1 and 2 also give every XCD whole attention heads.
- *   "ln_rows"     1 = LayerNorm keeps several rows in flight per wave (default), 0 = one row per wave (CLORA_LN_ROWS=0).
+ * This table is the ABI's ONLY process-global state (every other entry point is a pure function of its arguments and the
+ * stream); the library reads no environment variable.  A knob takes effect for the launches that follow (a captured hipGraph
+ * keeps what it was captured with).
+ *   "tile_order"      how clora_gemm_f16[_ex] assigns output tiles -- and the attention kernels their (batch, head) blocks -- to
+ *                     the eight XCDs.  0 = every XCD a contiguous range of tiles in m-major order, attention blocks in launch
+ *                     order; 1 = n-major tile ranges; 2 = per launch the order that fetches fewer distinct A / B panels per XCD
+ *                     (default: same-box A/B on MI355X 24.51 -> 24.35 ms/step).  1 and 2 also give every XCD whole attention heads.
+ *   "ln_rows"         1 = LayerNorm keeps several rows in flight per wave (default), 0 = one row per wave.
+ *   "attn_fwd_waves"  0 = pick by grid size (default), 4 | 6 | 8 = waves per forward attention block (head dims <= 64).
+ *   "attn_bwd_waves"  0 = pick by grid size (default), 4 | 8 = waves per backward attention block (head dims <= 64).
+ *   "gn_blocks"       target number of GroupNorm row-chunk blocks in flight (default 512, >= 64).
  * Unknown names / values: CLORA_ERR_ARG. */
 int clora_set_option(const char* name, int value);
 

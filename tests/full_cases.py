@@ -308,3 +308,23 @@ def ddim_vs_fixture(dev, graph=True):
         if k.startswith("latents_step"):
             errs[k] = rel(traj[int(k[-2:])][0], fx[k])
     return errs
+
+
+def fp16_reference_regime_vs_fixture(dev):
+    """The oracle in the reference's own fp16 arithmetic (oracle/precision_regimes.py "fp16": stock torch ops on the GPU, fp16
+    weights / activations, scheduler state fp32) against the same fp32 fixture: the noise floor of "fp16" at this configuration."""
+    from oracle import precision_regimes as PR
+    from oracle.make_fullsize_golden import ddim_inputs
+    fx, meta = load_fixture("full_ddim_512_50.safetensors")
+    o_unet = oracle_unet_sd15()
+    torch.manual_seed(1)
+    o_clora = ControlLoRARef.from_config(os.path.join(ROOT, "configs", meta["config"]))
+    randomize_adapters_(o_clora, seed=1, std=0.02)
+    o_unet.set_attn_processor(map_processors_to_unet(o_unet, o_clora))
+    guide, cond, uncond, lat0 = ddim_inputs(int(meta["res"]), int(meta["images"]), int(meta["input_seed"]))
+    u, c = PR.build_regime(o_unet, o_clora, "fp16", dev)
+    x, _, eps1 = PR.ddim_loop(u, c, guide, cond, uncond, lat0, int(meta["steps"]), float(meta["guidance_scale"]))
+    out = {"latents": rel(x, fx["latents"]), "eps_step01": rel(eps1, fx["eps_step01"])}
+    del u, c
+    torch.cuda.empty_cache()
+    return out

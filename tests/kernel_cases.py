@@ -41,6 +41,34 @@ def case_gemm_epilogue(dev, M=200, N=96, K_=64, split_k=1, tile_cfg=0):
     assert rel(out, ref) < 6e-4
 
 
+def case_gemm_epilogue_no_rowadd(dev, M=300, N=320, K_=128, tile_cfg=0, split_k=1):
+    """The epilogue shapes of the attention / transformer projections (no time-embedding row add): the 8-wave tiles take
+    their two-phase chunk loop here (all T rows / residual chunks requested before the first is used) -- (a) bias + rank-4
+    adapter + residual, N split in two adapter segments; (b) the transposed-U form of the dgrad launches; (c) bias +
+    residual without an adapter; (d) no operands at all.  Ragged M (rows past the matrix re-read the tile's first row)."""
+    g = torch.Generator().manual_seed(41)
+    A, B = rnd((M, K_), dev, g), rnd((N, K_), dev, g, 1 / math.sqrt(K_))
+    bias, res = rnd((N,), dev, g, dtype=f32), rnd((M, N), dev, g)
+    base = A.float() @ B.float().T
+    nseg = 2 if N % 32 == 0 else 1                     # lora_seg must be a multiple of 16
+    seg_w = N // nseg
+    T, U = rnd((M, 4 * nseg), dev, g, dtype=f32), rnd((N, 4), dev, g, dtype=f32)
+    seg = (torch.arange(N) // seg_w).tolist()
+    lora = torch.stack([T[:, s_ * 4:(s_ + 1) * 4] @ U[n] for n, s_ in enumerate(seg)], 1)
+    kw = dict(split_k=split_k, tile_cfg=tile_cfg)
+    out = K.gemm(A, B, M, N, K_, bias=bias, residual=res, lora_t=T, lora_u=U, lora_seg=seg_w, lora_scale=0.7, **kw)
+    assert rel(out, (base + bias + 0.7 * lora).half().float() + res.float()) < 6e-4
+    out = K.gemm(A, B, M, N, K_, lora_t=T, lora_u=U, lora_seg=seg_w, lora_scale=1.0, **kw)            # no bias, no residual
+    assert rel(out, (base + lora).half().float()) < 6e-4
+    Ut = rnd((4, N), dev, g, dtype=f32)                                                                  # dgrad form: u(n, j) = Ut[j, n]
+    out = K.gemm(A, B, M, N, K_, residual=res, lora_t=T[:, :4].contiguous(), lora_u=Ut, lora_seg=N, lora_u_tr=True, lora_r=4, **kw)
+    assert rel(out, (base + T[:, :4] @ Ut).half().float() + res.float()) < 6e-4
+    out = K.gemm(A, B, M, N, K_, bias=bias, residual=res, **kw)
+    assert rel(out, (base + bias).half().float() + res.float()) < 6e-4
+    out = K.gemm(A, B, M, N, K_, residual=res, **kw)
+    assert rel(out, base.half().float() + res.float()) < 6e-4
+
+
 def case_conv(dev, Bn, H, W, Ci, Co, stride=1, pad=1, ups=False, asym=False, seed=2, tile_cfg=0, kchunk=0):
     """forward, dgrad and wgrad of one 3x3 conv configuration against F.conv2d autograd.
     kchunk > 0: forward and dgrad additionally run with the channel-chunk-major K order (clora_conv_t.kchunk)."""
@@ -189,7 +217,7 @@ def case_tile_order(dev, tile_cfg, order, seed=21):
         K.set_tile_order(order)
         other = run()
     finally:
-        K.set_tile_order("m")
+        K.set_tile_order(K.DEFAULT_TILE_ORDER)
     assert rel(base[0], A.float() @ B.float().T) < 6e-4 if not patch else True
     for a, b in zip(base, other):
         assert torch.equal(a, b)
@@ -307,7 +335,7 @@ def case_attention_block_order(dev, B, H, Nq, Nk, D, seed=23):
         K.set_tile_order("auto")
         other = run()
     finally:
-        K.set_tile_order("m")
+        K.set_tile_order(K.DEFAULT_TILE_ORDER)
     for a, b_ in zip(base, other):
         assert torch.equal(a, b_)
 

@@ -53,3 +53,23 @@ def test_workspace_is_never_freed_or_moved_under_a_graph():
     b = K.workspace(a.numel() + 4096, "cpu")
     assert b.numel() >= a.numel() + 4096 and any(t.data_ptr() == pa for t in K._ws_retired)
     assert K.workspace(10, "cpu") is b                       # never shrinks
+
+
+def test_options_are_the_only_global_state_and_no_getenv_in_the_library(monkeypatch):
+    """clora_set_option validates names / ranges (host-only call: no kernel runs); the kernel sources read no environment
+    variable -- CLORA_* variables are forwarded by the host binding when the library is loaded."""
+    import glob
+    from controllora_amd import build, capi
+    for src in glob.glob(os.path.join(ROOT, "controllora_amd", "csrc", "*")):
+        assert "getenv" not in open(src).read(), src
+    monkeypatch.setenv("CLORA_TILE_ORDER", "auto")
+    monkeypatch.setenv("CLORA_GN_BLOCKS", "256")
+    L = capi.Lib(build.build(verbose=False), require_device=False)            # forwards the two variables
+    so = L.cdll.clora_set_option
+    assert so(b"tile_order", 0) == 0 and so(b"tile_order", 3) == capi.ERR_ARG
+    assert so(b"attn_fwd_waves", 6) == 0 and so(b"attn_fwd_waves", 5) == capi.ERR_ARG and so(b"attn_fwd_waves", 0) == 0
+    assert so(b"attn_bwd_waves", 6) == capi.ERR_ARG and so(b"gn_blocks", 8) == capi.ERR_ARG and so(b"gn_blocks", 512) == 0
+    assert so(b"no_such_knob", 1) == capi.ERR_ARG and so(None, 1) == capi.ERR_ARG
+    monkeypatch.setenv("CLORA_TILE_ORDER", "sideways")
+    with pytest.raises((ValueError, capi.CloraError)):
+        capi.Lib(build.build(verbose=False), require_device=False)

@@ -20,8 +20,12 @@ pytestmark = pytest.mark.gpu
 
 # measured on MI355X (r02, fill50k): pred 1.7e-3, control maps 1.9-2.9e-3, loss 2.5e-5, flat gradient 1.2e-3 (adapters
 # 1.1e-3, hint encoder 4.5e-3); limits are <= 2x the measured values
-# full-size fixtures (512x512): PROVISIONAL limits until the first measurement on MI355X
-FIX_TOL = dict(pred=3.5e-3, loss=2e-4, grads=3e-3, grads_norm=2e-3, control=5e-3, control_norm=2e-3, param_norm=2e-2,
+# full-size fixtures (512x512 = BASELINE's own sizes), measured on MI355X (profiles/r03_gputest_1.log): train step -- pred 1.59e-3, loss
+# 1.5e-5, flat gradient 3.7e-4 (norm 3.8e-5, worst per-parameter norm 2.5e-3), control maps 1.9-2.9e-3 (norms <= 3.6e-6); 50-step
+# DDIM -- first UNet evaluation 1.61e-3, latents 1.12e-3 after step 1, 1.97e-3 from step 20 to step 50.  Limits are <= 2x measured.
+FIX_TOL = dict(pred=3.2e-3, loss=1e-4, grads=8e-4, grads_norm=2e-4, control=5e-3, control_norm=5e-5, param_norm=5e-3,
+               eps=3.2e-3, latents=3.5e-3)
+TOL = dict(pred=3.5e-3, loss=2e-4, grads=3e-3, grads_norm=2e-3, control=5e-3, control_norm=2e-3, param_norm=2e-2,
                eps=3.5e-3, latents=1.5e-2)
 TOL = dict(pred=3.5e-3, control=5e-3, loss=2e-4, grads=3e-3, grads_adapters=3e-3, grads_hint=9e-3)
 
@@ -110,7 +114,14 @@ def test_baseline_config1_train_step_vs_committed_oracle_fixture():
 
 def test_baseline_inference_ddim50_512_vs_committed_oracle_fixture():
     """BASELINE inference geometry (apps/gradio_canny2image.py:83-89): 50 DDIM steps + CFG 9.0 at 512x512, UNet batch 4, product
-    (hipGraph replay, as shipped) vs the fp32 CPU oracle's committed trajectory and final latents."""
+    (hipGraph replay, as shipped) vs the fp32 CPU oracle's committed trajectory and final latents.
+
+    north_star states "denoised latents within 1e-3 rel fp16".  The error budget at this exact configuration
+    (tools/error_budget.py, profiles/r03_error_budget.json): the ORACLE ITSELF in the reference's fp16 arithmetic (stock torch
+    ops, fp16 weights / activations) sits 2.85e-3 from its fp32 run, with an fp32 residual trunk 2.62e-3; the product sits
+    1.96e-3 away.  1e-3 is below what fp16 storage of the branch activations allows any implementation at 50 steps, so the test
+    pins (a) <= 2x the measured product error and (b) product error < the error of the reference's own fp16 arithmetic,
+    re-measured here on the same inputs."""
     errs = F.ddim_vs_fixture("cuda", graph=True)
     print("FULL_SIZE_DDIM50_VS_FIXTURE", {k: (f"{v:.3e}" if isinstance(v, float) else v) for k, v in errs.items()})
     assert errs["eps_step01"] < FIX_TOL["eps"], errs
@@ -118,3 +129,6 @@ def test_baseline_inference_ddim50_512_vs_committed_oracle_fixture():
     for k, v in errs.items():
         if k.startswith("latents_step"):
             assert v < FIX_TOL["latents"], (k, errs)
+    floor = F.fp16_reference_regime_vs_fixture("cuda")
+    print("FULL_SIZE_DDIM50_FP16_REFERENCE_REGIME", {k: f"{v:.3e}" for k, v in floor.items()})
+    assert errs["latents"] < floor["latents"] and errs["eps_step01"] < floor["eps_step01"], (errs, floor)

@@ -45,6 +45,13 @@ def test_gemm_tile_configs(tile):
     KC.case_conv("cpu", 1, 8, 8, 16, 24, tile_cfg=tile)
 
 
+@pytest.mark.parametrize("tile", [3, 21, 23, 51, 52, 53, 54, 55, 56, 57, 58])
+def test_gemm_epilogue_without_rowadd(tile):
+    """projection epilogues (adapter / bias / residual, no row add): the two-phase chunk loop of the 8-wave tiles, ragged M and N"""
+    KC.case_gemm_epilogue_no_rowadd("cpu", M=300, N=320, K_=128, tile_cfg=tile)
+    KC.case_gemm_epilogue_no_rowadd("cpu", M=70, N=144, K_=64, tile_cfg=tile)
+
+
 @pytest.mark.parametrize("order", ["n", "auto"])
 @pytest.mark.parametrize("tile", [21, 43, 53, 72, 76])
 def test_tile_order_does_not_change_results(tile, order):

@@ -68,6 +68,14 @@ def test_conv_patch_kernel_upsampled(tile, Bn, H, Ci):
     KC.case_conv_patch_upsampled(DEV, Bn, H, H, Ci, Ci, tile)
 
 
+@pytest.mark.parametrize("tile", [0, 3, 21, 23, 43, 51, 52, 53, 54, 55, 56, 57, 58])
+def test_gemm_epilogue_without_rowadd(tile):
+    """projection epilogues at real shapes (M = 16384 x N = 320 / 960, ragged variants): two-phase chunk loop of the 8-wave tiles"""
+    KC.case_gemm_epilogue_no_rowadd(DEV, M=16384, N=320, K_=320, tile_cfg=tile)
+    KC.case_gemm_epilogue_no_rowadd(DEV, M=4100, N=960, K_=320, tile_cfg=tile)
+    KC.case_gemm_epilogue_no_rowadd(DEV, M=1000, N=1296, K_=1280, tile_cfg=tile, split_k=2 if tile else 0)
+
+
 @pytest.mark.parametrize("order", ["n", "auto"])
 @pytest.mark.parametrize("tile", [21, 43, 53, 58, 72, 76])
 def test_tile_order_does_not_change_results(tile, order):

@@ -42,7 +42,7 @@ def ab(name, fn, flops):
         K.set_tile_order(order)
         us = timeit(fn)
         r[order] = min(us, r.get(order, 1e9))
-    K.set_tile_order("m")
+    K.set_tile_order(K.DEFAULT_TILE_ORDER)
     r["tflops_m"], r["tflops_auto"] = flops / r["m"] / 1e6, flops / r["auto"] / 1e6
     rows.append(r)
     print(f"{name:34s} m {r['m']:7.1f} us   n {r['n']:7.1f} us   auto {r['auto']:7.1f} us   ({r['m'] / r['auto']:.2f}x, {r['tflops_auto']:.0f} TF)", flush=True)
