@@ -28,6 +28,7 @@ struct GemmArgs {
     int lda, ldc, M, N, K;
     int k_per_split;
     int tiles_n;
+    int two_phase;             // option "epi_two_phase" at launch time (A/B switch of the two-phase chunk loop)
     int tiles_m, n_major;      // n_major: logical tile t = n * tiles_m + m (else m * tiles_n + n); see pick_tile_order
     clora_conv_t conv;
     clora_epilogue_t epi;
@@ -421,7 +422,7 @@ __device__ __forceinline__ void dma_epilogue(const GemmArgs& p, floatx4 (&acc)[B
                        ((p.epi.ldt | ((n / p.epi.lora_seg) * 4)) & 3) == 0 && (p.epi.lora_u_tr ? (p.epi.ldu & 3) == 0 : p.epi.ldu == 4);
     // `two`: this thread takes the two-phase chunk loop -- adapter launches it can hoist, and launches without an adapter
     // (proj_in / proj_out / FF2 and the dgrads: bias and / or residual only)
-    const bool two = TWO_PHASE && p.epi.geglu == 0 && !p.epi.rowadd && n < p.N && (hoist || p.epi.lora_t == nullptr);
+    const bool two = TWO_PHASE && p.two_phase && p.epi.geglu == 0 && !p.epi.rowadd && n < p.N && (hoist || p.epi.lora_t == nullptr);
     floatx4 ureg[8];
     float bias8[8];
     int utoff = 0;
@@ -1282,7 +1283,7 @@ int conv_mode(const GemmArgs& a, int bk) {
 // activations and n-major ranges (m fastest) are the cheaper assignment.  The model counts, per XCD and split, the distinct
 // panels of its range under either order.   "tile_order": 0 m-major always, 1 n-major always
 // (tests), 2 pick by the model.
-int g_opts[CLORA_OPT_COUNT] = {2, 1, 0, 0, 512};    // tile_order, ln_rows, attn_fwd_waves (0 = auto), attn_bwd_waves (0 = auto), gn_blocks
+int g_opts[CLORA_OPT_COUNT] = {2, 1, 0, 0, 512, 1};    // tile_order, ln_rows, attn_fwd_waves (0 = auto), attn_bwd_waves (0 = auto), gn_blocks, epi_two_phase
 int tile_order_mode() { return g_opts[CLORA_OPT_TILE_ORDER]; }
 
 double fabric_model_bytes(int tiles_m, int tiles_n, int splits, double a_panel, double b_panel, bool n_major) {
@@ -1410,6 +1411,7 @@ extern "C" int clora_gemm_f16_ex(const clora_half* A, int lda, const clora_half*
     a.A = (const half_t*)A; a.B = (const half_t*)B; a.C = (half_t*)C; a.partial = nullptr;
     a.lda = lda; a.ldc = ldc; a.M = M; a.N = N; a.K = K;
     a.tiles_m = 0; a.n_major = 0;
+    a.two_phase = g_opts[CLORA_OPT_EPI_TWO_PHASE];
     if (conv && conv->enabled) {
         a.conv = *conv;
         if ((conv->Cin & 7) || K != conv->ksize * conv->ksize * conv->Cin) return CLORA_ERR_ARG;
@@ -1573,7 +1575,7 @@ extern "C" int clora_set_option(const char* name, int value) {
     struct Opt { const char* name; int id, lo, hi; };
     static const Opt kOpts[] = {{"tile_order", CLORA_OPT_TILE_ORDER, 0, 2}, {"ln_rows", CLORA_OPT_LN_ROWS, 0, 1},
                                 {"attn_fwd_waves", CLORA_OPT_ATTN_FWD_WAVES, 0, 8}, {"attn_bwd_waves", CLORA_OPT_ATTN_BWD_WAVES, 0, 8},
-                                {"gn_blocks", CLORA_OPT_GN_BLOCKS, 64, 1 << 16}};
+                                {"gn_blocks", CLORA_OPT_GN_BLOCKS, 64, 1 << 16}, {"epi_two_phase", CLORA_OPT_EPI_TWO_PHASE, 0, 1}};
     for (const Opt& o : kOpts)
         if (!strcmp(name, o.name)) {
             if (value < o.lo || value > o.hi) return CLORA_ERR_ARG;

@@ -121,6 +121,8 @@ int clora_conv_patch_eligible(int M, const clora_conv_t* conv, int tile_cfg);
  *   "attn_fwd_waves"  0 = pick by grid size (default), 4 | 6 | 8 = waves per forward attention block (head dims <= 64).
  *   "attn_bwd_waves"  0 = pick by grid size (default), 4 | 8 = waves per backward attention block (head dims <= 64).
  *   "gn_blocks"       target number of GroupNorm row-chunk blocks in flight (default 512, >= 64).
+ *   "epi_two_phase"   1 = the 8-wave GEMM tiles request every T row / residual chunk of a thread before using the first (default),
+ *                     0 = one chunk at a time.
  * Unknown names / values: CLORA_ERR_ARG. */
 int clora_set_option(const char* name, int value);
 

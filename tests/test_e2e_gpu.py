@@ -102,6 +102,17 @@ def test_vae_encode_decode_matches_oracle():
     print(vae_cases.check_vae("cuda", res=64, batch=2))
 
 
+def test_vae_sd15_topology_real_widths_matches_oracle():
+    """SURVEY section 8 (f)1 / U8 at the bar of the hot path: the SD-1.5 VAE topology at its real widths (128 / 256 / 512 / 512
+    channels, two resnets per level, the single-head d = 512 attention over 1024 tokens) at 256x256, product on the GPU vs
+    oracle/vae_ref.py on the host: encoder moments, the sampled latents, the decoded image (reference train...:753-754,
+    apps/gradio_canny2image.py:88-92)."""
+    from controllora_amd import vae as V
+    from tests import vae_cases
+    errs = vae_cases.check_vae("cuda", res=256, batch=1, cfg=V.SD15_VAE, tol=6e-3)
+    print("VAE_SD15_TOPOLOGY_256", {k: f"{v:.2e}" for k, v in errs.items()})
+
+
 @pytest.mark.parametrize("case", ["v1", "v2", "sketch"])
 def test_inference_with_control_batch_broadcast(case):
     print(case, E.check_inference_broadcast(case, "cuda"))
