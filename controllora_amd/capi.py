@@ -72,6 +72,7 @@ _PROTOS = {
     "clora_conv_weight_pack_f32": [_P, _I, _I, _I, _I, _I, _P, _P, _P],
     "clora_conv_wgrad_unpack_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "clora_attn_fwd_f16": [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _F, _P],
+    "clora_attn_fwd_causal_f16": [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _F, _P],
     "clora_attn_bwd_f16": [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _F, _P, _Z, _P],
     "clora_groupnorm_fwd_f16": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P, _Z, _P],
     "clora_groupnorm_bwd_f16": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _Z, _P],
@@ -89,6 +90,7 @@ _PROTOS = {
     "clora_add_f16": [_P, _P, _P, _Z, _P],
     "clora_silu_f16": [_P, _P, _Z, _P],
     "clora_silu_bwd_f16": [_P, _P, _P, _Z, _P],
+    "clora_quick_gelu_f16": [_P, _P, _Z, _P],
     "clora_copy2d_f16": [_P, _I, _P, _I, _Z, _I, _P],
     "clora_pool2x2_sum_f16": [_P, _P, _I, _I, _I, _I, _P],
     "clora_colsum_f16": [_P, _I, _P, _I, _I, _P],

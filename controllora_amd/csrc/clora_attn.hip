@@ -151,7 +151,9 @@ constexpr float kRebase = 8.0f;
 // NWV waves per block (32 queries each).  The loop is bound by the L2 -> LDS stream of K/V tiles (every block of NWV*32 queries
 // re-streams all keys: 7.5 TB/s at B = 32, the same DMA ceiling the GEMMs hit), so more queries per block = less traffic per flop:
 // 8 waves (256 queries, 126 registers: two blocks per CU = 16 waves) at head dims <= 64 when the grid stays full (-18 % at B = 4, N = 4096).
-template <int DP, int DT, bool ONES, int NWV>
+// CAUSAL (clora_attn_fwd_causal_f16: the CLIP text encoder's masked self-attention, 77 tokens): key j is visible to query i
+// iff j <= i.  A separate instantiation, so the unmasked kernels of the UNet keep their exact code.
+template <int DP, int DT, bool ONES, int NWV, bool CAUSAL = false>
 __global__ __launch_bounds__(NWV * 64, (DP <= 64 ? (NWV == 4 ? 3 : 2) : 1)) void attn_fwd_kernel(AttnArgs p) {
     constexpr int BKV = 64, LDK = DP + 16, DV = DT * 16, LDV = DV + ((DV % 32) == 16 ? 0 : 16), KS = DP / 32;
     constexpr int TILE = BKV * LDK + BKV * LDV;           // one K tile + one V tile; two of them: double buffer
@@ -218,7 +220,16 @@ __global__ __launch_bounds__(NWV * 64, (DP <= 64 ? (NWV == 4 ? 3 : 2) : 1)) void
                 s[kt][0] = mfma16(a, qf[0][ks], s[kt][0]);
                 s[kt][1] = mfma16(a, qf[1][ks], s[kt][1]);
             }
-        if (rows < BKV) {                                  // ragged last tile only: mask the missing keys
+        if (CAUSAL) {                                      // keys past the query (and past the end of a ragged tile)
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int kl = kt * 16 + 4 * g + r, key = kv0 + kl;
+                    if (kl >= rows || key > q0 + li) s[kt][0][r] = kNegBig;
+                    if (kl >= rows || key > q0 + 16 + li) s[kt][1][r] = kNegBig;
+                }
+        } else if (rows < BKV) {                           // ragged last tile only: mask the missing keys
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
@@ -674,6 +685,13 @@ int launch_fwd(const AttnArgs& a, hipStream_t s) {
 #undef CLORA_FWD_LAUNCH
     return clora_check_launch();
 }
+template <int DP, int DT>
+int launch_fwd_causal(const AttnArgs& a, hipStream_t s) {
+    const dim3 grid(clora_cdiv(a.Nq, 128), a.B * a.H);
+    if (a.D == DT * 16 - 8) hipLaunchKernelGGL((attn_fwd_kernel<DP, DT, true, 4, true>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((attn_fwd_kernel<DP, DT, false, 4, true>), grid, dim3(256), 0, s, a);
+    return clora_check_launch();
+}
 template <int DP, int DT, int BT>
 int launch_bwd(const AttnArgs& a, hipStream_t s) {
     // 8-wave blocks (one per CU: the same 8 waves as two 4-wave blocks, half the K/V resp. Q/dO stream per flop) when the grids stay
@@ -733,6 +751,19 @@ extern "C" int clora_attn_fwd_f16(const clora_half* q, int ldq, const clora_half
     CLORA_ATTN_DISPATCH(launch_fwd);
     if (D <= 128) return launch_fwd<128, 8>(a, s);
     return launch_fwd<160, 10>(a, s);
+}
+
+extern "C" int clora_attn_fwd_causal_f16(const clora_half* q, int ldq, const clora_half* k, int ldk, const clora_half* v,
+                                         int ldv, clora_half* o, int ldo, int B, int H, int N, int D, float scale, void* stream) {
+    if (!q || !k || !v || !o || bad_dims(B, H, N, N, D) || D > 64 || ((ldq | ldk | ldv | ldo) & 7)) return CLORA_ERR_ARG;
+    AttnArgs a = AttnArgs();
+    a.q = (const half_t*)q; a.k = (const half_t*)k; a.v = (const half_t*)v; a.out = (half_t*)o; a.lse = nullptr;
+    a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
+    a.B = B; a.H = H; a.Nq = N; a.Nk = N; a.D = D; a.scale = scale;
+    hipStream_t s = (hipStream_t)stream;
+    if (D <= 32) return launch_fwd_causal<32, 2>(a, s);
+    if ((D + 15) / 16 <= 3) return launch_fwd_causal<64, 3>(a, s);
+    return launch_fwd_causal<64, 4>(a, s);
 }
 
 extern "C" int clora_attn_bwd_f16(const clora_half* q, int ldq, const clora_half* k, int ldk, const clora_half* v,

@@ -35,6 +35,17 @@ __global__ __launch_bounds__(256) void silu_kernel(const half_t* x, half_t* y, s
     }
 }
 
+// CLIP's activation (transformers `quick_gelu`): x * sigmoid(1.702 x)
+__global__ __launch_bounds__(256) void quick_gelu_kernel(const half_t* x, half_t* y, size_t n8) {
+    EW_LOOP(i, n8) {
+        const half8 v = ld8(x + i * 8);
+        half8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (half_t)((float)v[e] * sigmoid_f(1.702f * (float)v[e]));
+        st8(y + i * 8, o);
+    }
+}
+
 __global__ __launch_bounds__(256) void silu_bwd_kernel(const half_t* x, const half_t* dy, half_t* dx, size_t n8) {
     EW_LOOP(i, n8) {
         const half8 v = ld8(x + i * 8), g = ld8(dy + i * 8);
@@ -244,6 +255,11 @@ extern "C" int clora_add_f16(const clora_half* a, const clora_half* b, clora_hal
 extern "C" int clora_silu_f16(const clora_half* x, clora_half* y, size_t n, void* stream) {
     if (!x || !y || (n & 7)) return CLORA_ERR_ARG;
     hipLaunchKernelGGL(silu_kernel, dim3(ew_grid(n / 8)), dim3(256), 0, (hipStream_t)stream, H(x), HM(y), n / 8);
+    return clora_check_launch();
+}
+extern "C" int clora_quick_gelu_f16(const clora_half* x, clora_half* y, size_t n, void* stream) {
+    if (!x || !y || (n & 7)) return CLORA_ERR_ARG;
+    hipLaunchKernelGGL(quick_gelu_kernel, dim3(ew_grid(n / 8)), dim3(256), 0, (hipStream_t)stream, H(x), HM(y), n / 8);
     return clora_check_launch();
 }
 extern "C" int clora_silu_bwd_f16(const clora_half* x, const clora_half* dy, clora_half* dx, size_t n, void* stream) {

@@ -269,6 +269,14 @@ def attn_fwd(q, k, v, B, H, Nq, Nk, D, scale, out=None):
     return o, lse
 
 
+def attn_fwd_causal(q, k, v, B, H, N, D, scale, out=None):
+    """causal self-attention, forward only (CLIP text encoder); q/k/v: 2-D row-strided views [B*N, >= H*D]"""
+    o = out if out is not None else torch.empty((B * N, H * D), dtype=f16, device=q.device)
+    _call("clora_attn_fwd_causal_f16", ptr(q, f16), q.stride(0), ptr(k, f16), k.stride(0), ptr(v, f16), v.stride(0),
+          ptr(o), o.stride(0), B, H, N, D, float(scale), flops=2.0 * B * H * N * N * D)
+    return o
+
+
 def attn_bwd(q, k, v, o, dO, lse, B, H, Nq, Nk, D, scale, dq, dk, dv):
     delta = torch.empty((B, H, Nq), dtype=f32, device=q.device)
     ws = workspace(16 * 2 * B * Nk * H * D * 4, q.device) if Nk <= 1024 else None     # up to 16 query splits, one fp32 slab pair each
@@ -501,6 +509,12 @@ def add(a, b):
 def silu(x):
     y = torch.empty_like(x)
     _call("clora_silu_f16", ptr(x, f16), ptr(y), x.numel())
+    return y
+
+
+def quick_gelu(x):
+    y = torch.empty_like(x)
+    _call("clora_quick_gelu_f16", ptr(x, f16), ptr(y), x.numel())
     return y
 
 

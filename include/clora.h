@@ -156,6 +156,11 @@ int clora_conv_weight_pack_f32(const float* w, int Co, int Ci, int ksize, int Ci
 int clora_attn_fwd_f16(const clora_half* q, int ldq, const clora_half* k, int ldk, const clora_half* v, int ldv,
                        clora_half* o, int ldo, float* lse, int B, int H, int Nq, int Nk, int D, float scale,
                        void* stream);
+/* Forward only, causal: key j is visible to query i iff j <= i (self-attention, Nq = Nk = N, head dims <= 64).  The masked
+ * self-attention of the frozen CLIP text encoder (reference train_text_to_image_control_lora.py:768
+ * `text_encoder(batch["input_ids"])[0]`; transformers CLIPTextTransformer builds the same mask additively). */
+int clora_attn_fwd_causal_f16(const clora_half* q, int ldq, const clora_half* k, int ldk, const clora_half* v, int ldv,
+                              clora_half* o, int ldo, int B, int H, int N, int D, float scale, void* stream);
 /* dq/dk/dv given do (autograd of the same lines). delta: [B,H,Nq] fp32 scratch.  workspace (optional, one
  * 2*B*Nk*H*D*4-byte slab pair per query split, up to 16) lets the dK/dV kernel split its query loop when there are few keys
  * (cross-attention); the splits are folded in a fixed order (no atomics). */
@@ -248,6 +253,9 @@ int clora_lora_wgrad_f16(const clora_half* A, int lda, const float* T, int ldt, 
 int clora_add_f16(const clora_half* a, const clora_half* b, clora_half* y, size_t n, void* stream);
 int clora_silu_f16(const clora_half* x, clora_half* y, size_t n, void* stream);
 int clora_silu_bwd_f16(const clora_half* x, const clora_half* dy, clora_half* dx, size_t n, void* stream);
+/* y = x * sigmoid(1.702 x): the activation of the CLIP text encoder's MLP (transformers `quick_gelu`; the frozen text
+ * encoder the reference calls at train_text_to_image_control_lora.py:768). */
+int clora_quick_gelu_f16(const clora_half* x, clora_half* y, size_t n, void* stream);
 /* dst[m, 0:N] = src[m, 0:N] with independent row strides (skip-connection concat = two copies,
  * its backward = two slice copies; upstream torch.cat in the up blocks) */
 int clora_copy2d_f16(const clora_half* src, int lds, clora_half* dst, int ldd, size_t M, int N, void* stream);

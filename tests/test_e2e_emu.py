@@ -38,6 +38,13 @@ def test_vae_encode_decode_matches_oracle():
     print(vae_cases.check_vae("cpu", res=32, batch=1))
 
 
+def test_clip_text_encoder_matches_transformers():
+    """controllora_amd/clip.py on the emulated kernels vs the stock transformers CLIPTextModel (fp32 CPU): small config, causal mask"""
+    from tests import clip_cases
+    print(clip_cases.check_clip("cpu", batch=2, seq=77))
+    print(clip_cases.check_clip("cpu", batch=1, seq=20, seed=3))
+
+
 @pytest.mark.parametrize("case", ["v1", "v2"])
 def test_inference_with_control_batch_broadcast(case):
     print(case, E.check_inference_broadcast(case, "cpu"))

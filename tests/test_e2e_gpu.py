@@ -102,6 +102,16 @@ def test_vae_encode_decode_matches_oracle():
     print(vae_cases.check_vae("cuda", res=64, batch=2))
 
 
+def test_clip_text_encoder_matches_transformers_sd15_shape():
+    """the frozen CLIP ViT-L/14 text encoder (12 layers, 768 wide, 12 heads of 64, 77 tokens) on the clora
+    kernels -- fused q|k|v GEMM, causal flash attention, quick_gelu MLP -- vs the stock transformers model in fp32 on the host
+    (reference train...:768 `text_encoder(batch["input_ids"])[0]`)"""
+    from controllora_amd import clip as C
+    from tests import clip_cases
+    print("CLIP_SMALL", clip_cases.check_clip("cuda", batch=2, seq=77))
+    print("CLIP_SD15_SHAPE", clip_cases.check_clip("cuda", cfg=C.SD15_CLIP, batch=4, seq=77, tol=3e-3))
+
+
 def test_vae_sd15_topology_real_widths_matches_oracle():
     """SURVEY section 8 (f)1 / U8 at the bar of the hot path: the SD-1.5 VAE topology at its real widths (128 / 256 / 512 / 512
     channels, two resnets per level, the single-head d = 512 attention over 1024 tokens) at 256x256, product on the GPU vs

@@ -5,8 +5,8 @@
 set -x
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-( time timeout 900 python -m pytest tests/test_kernels_gpu.py tests/test_e2e_gpu.py -m gpu -x -q -s -k "without_rowadd or vae or tile_configs or gemm" ) > gpurun_out/r03_gputest_2.log 2>&1
-tail -3 gpurun_out/r03_gputest_2.log; grep -h "VAE_SD15" gpurun_out/r03_gputest_2.log
+( time timeout 900 python -m pytest tests/test_kernels_gpu.py tests/test_e2e_gpu.py -m gpu -x -q -s -k "without_rowadd or vae or clip or tile_configs or gemm" ) > gpurun_out/r03_gputest_2.log 2>&1
+tail -3 gpurun_out/r03_gputest_2.log; grep -h "VAE_SD15\|CLIP_" gpurun_out/r03_gputest_2.log
 for tp in 1 0; do
   CLORA_EPI_TWO_PHASE=$tp timeout 300 python tools/gemm_decomp.py gpurun_out/r03_gemm_decomp_tp$tp.json > gpurun_out/r03_gemm_decomp_tp$tp.txt 2>&1
 done
