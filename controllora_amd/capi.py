@@ -87,6 +87,11 @@ _PROTOS = {
     "clora_lora_up_f16": [_P, _I, _P, _I, _I, _P, _I, _I, _P, _I, _I, _I, _I, _F, _P],
     "clora_lora_up_multi_f16": [C.POINTER(LoraUpJob), _I, _P],
     "clora_lora_wgrad_f16": [_P, _I, _P, _I, _I, _P, _I, _I, _I, _I, _I, _F, _I, _P, _Z, _P],
+    "clora_comm_unique_id": [_P],
+    "clora_comm_init": [_P, _I, _I],
+    "clora_comm_world": [],
+    "clora_allreduce_flat_f32": [_P, _Z, _P],
+    "clora_comm_destroy": [],
     "clora_add_f16": [_P, _P, _P, _Z, _P],
     "clora_silu_f16": [_P, _P, _Z, _P],
     "clora_silu_bwd_f16": [_P, _P, _P, _Z, _P],

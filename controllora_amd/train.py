@@ -71,7 +71,7 @@ class FlatParams:
 class ControlLoRATrainer:
     def __init__(self, unet, control_lora, lr=1e-4, betas=(0.9, 0.999), weight_decay=1e-2, eps=1e-8, max_grad_norm=1.0,
                  init_scale=65536.0, dynamic_scale=True, growth_interval=2000, process_group=None, world_size=1,
-                 gradient_accumulation_steps=1, lr_lambda=None):
+                 gradient_accumulation_steps=1, lr_lambda=None, comm=None):
         self.unet, self.control_lora = unet, control_lora
         trainable = {id(p) for p in control_lora.parameters()}
         for p in unet.parameters():          # the installed processors are sub-modules of the UNet too: keep them trainable
@@ -91,8 +91,45 @@ class ControlLoRATrainer:
         self.accum, self._micro = max(1, int(gradient_accumulation_steps)), 0
         # LR schedule (train...:660-665 get_scheduler): multiplier(step) written to state[10] before each optimizer step
         self.lr_lambda, self.global_step = lr_lambda, 0
+        # Exchange step: "torch" = torch.distributed.all_reduce on the process group (backend "nccl" IS RCCL on ROCm; gloo in
+        # the CPU tests); "clora" = the C ABI's own RCCL communicator (clora_comm_init / clora_allreduce_flat_f32), created
+        # from a unique id that rank 0 draws and the process group broadcasts.  Both enqueue the same ncclAllReduce on the
+        # current stream; "clora" is what a non-torch host would call.  Default "torch" (CLORA_COMM=clora switches).
+        import os as _os
+        self.comm = comm or _os.environ.get("CLORA_COMM", "torch")
+        if self.comm not in ("torch", "clora"):
+            raise ValueError(f"comm={self.comm!r}: expected 'torch' or 'clora'")
         if world_size > 1:
             torch.distributed.broadcast(self.flat.data, src=0, group=process_group)   # identical adapter init
+        if self.comm == "clora":
+            self._init_clora_comm(process_group, world_size)
+
+    def _init_clora_comm(self, pg, world):
+        """one RCCL communicator per process behind the C ABI: rank 0 draws the 128-byte unique id, the torch process group
+        (or nothing, world 1) carries it to the other ranks, every rank joins"""
+        import ctypes
+        from . import capi
+        L = capi.lib()
+        if L.cdll.clora_comm_world() == world:
+            return                                                   # already joined (a second trainer in this process)
+        rank = torch.distributed.get_rank(pg) if world > 1 else 0
+        uid = (ctypes.c_char * 128)()
+        if rank == 0:
+            L.call("clora_comm_unique_id", uid)
+        if world > 1:
+            box = [bytes(uid)] if rank == 0 else [None]
+            torch.distributed.broadcast_object_list(box, src=0, group=pg)
+            uid = (ctypes.c_char * 128).from_buffer_copy(box[0])
+        L.call("clora_comm_init", uid, rank, world)
+
+    def _all_reduce_grads(self):
+        g = self.flat.grad
+        if self.comm == "clora":
+            from . import capi
+            capi.lib().call("clora_allreduce_flat_f32", capi.ptr(g, f32), g.numel(), capi.stream())
+        else:
+            torch.distributed.all_reduce(g, group=self.pg)           # RCCL over xGMI: one flat 24 MB buffer (SUM; the 1/N of
+            #                                                          the mean is folded into optim_prep)
 
     # -- pieces (kept separate so tests can check each against the oracle)
     def forward_backward(self, noisy_latents, timesteps, encoder_hidden_states, guide, target):
@@ -120,10 +157,8 @@ class ControlLoRATrainer:
         if self.lr_lambda is not None:
             self.state[10:11].fill_(max(float(self.lr_lambda(self.global_step)), 1e-30))
         self.global_step += 1
-        g = self.flat.grad
         if self.world > 1:
-            torch.distributed.all_reduce(g, group=self.pg)           # RCCL over xGMI: one flat 24 MB buffer (SUM;
-            #                                                          the 1/N of the mean is folded into optim_prep)
+            self._all_reduce_grads()
             self._reduced = True
         self._optimizer_kernels()
         return True
@@ -172,7 +207,7 @@ class ControlLoRATrainer:
         self._reduced = False
         self._g_fb.replay()
         if self.world > 1:
-            torch.distributed.all_reduce(self.flat.grad, group=self.pg)
+            self._all_reduce_grads()
             self._reduced = True
         if self.lr_lambda is not None:
             self.state[10:11].fill_(max(float(self.lr_lambda(self.global_step)), 1e-30))

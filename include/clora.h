@@ -249,6 +249,22 @@ int clora_lora_wgrad_f16(const clora_half* A, int lda, const float* T, int ldt, 
                          int M, int N, int R, float scale, int a_rows, void* workspace, size_t workspace_bytes,
                          void* stream);
 
+/* ---- data-parallel exchange: ONE in-place all-reduce (sum) of the flat fp32 adapter-gradient buffer per optimizer step, RCCL over
+ * xGMI, one process per GPU.  Replaces the gradient all-reduce of accelerate's DDP wrapper around the prepared `control_lora`
+ * (reference train_text_to_image_control_lora.py:683-685 `accelerator.prepare`, :790 `accelerator.backward`); the 1/N of the
+ * mean is folded into clora_optim_prep_f32.  The communicator is a per-process handle kept by the library (librccl is opened
+ * lazily with dlopen: no link-time dependency).
+ *   clora_comm_unique_id   rank 0 only: 128 opaque bytes; the host hands them to every rank (any transport)
+ *   clora_comm_init        every rank, collectively, after hipSetDevice: creates the communicator (once per process)
+ *   clora_comm_world       number of ranks of the live communicator, 0 when there is none
+ *   clora_allreduce_flat_f32  buf[0..n) := sum over ranks, enqueued on `stream` (asynchronous like every other entry point)
+ *   clora_comm_destroy     releases the communicator */
+int clora_comm_unique_id(void* id128);
+int clora_comm_init(const void* id128, int rank, int world);
+int clora_comm_world(void);
+int clora_allreduce_flat_f32(float* buf, size_t n, void* stream);
+int clora_comm_destroy(void);
+
 /* ---- small elementwise / data-movement kernels on the path */
 int clora_add_f16(const clora_half* a, const clora_half* b, clora_half* y, size_t n, void* stream);
 int clora_silu_f16(const clora_half* x, clora_half* y, size_t n, void* stream);

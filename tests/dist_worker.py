@@ -20,14 +20,14 @@ def main():
     from oracle import cases, unet_ref
     with use_emulator():
         unet, clora, _ = E.build_product_case("v1", "cpu")
-        if rank == 1:                      # perturb rank 1: the trainer must broadcast rank 0's adapters
+        if rank >= 1:                      # perturb the other ranks: the trainer must broadcast rank 0's adapters
             with torch.no_grad():
                 for p in clora.parameters():
-                    p.add_(0.01)
+                    p.add_(0.01 * rank)
         trainer = ControlLoRATrainer(unet, clora, init_scale=128.0, dynamic_scale=False, process_group=dist.group.WORLD,
                                      world_size=world)
-        full = cases.seeded_inputs(batch=2)
-        sl = slice(rank, rank + 1)           # rank r gets sample r of the global batch of 2
+        full = cases.seeded_inputs(batch=world)
+        sl = slice(rank, rank + 1)           # rank r gets sample r of the global batch of `world`
         noisy = unet_ref.DDPMSchedule().add_noise(full["latents"], full["noise"], full["timesteps"])
         trainer.forward_backward(noisy[sl].half(), full["timesteps"][sl], full["ehs"][sl].half(), full["guide"][sl].half(),
                                  full["noise"][sl])

@@ -165,3 +165,22 @@ def test_canny2image_app_process():
     assert len(out) == 3 and all(o.dtype == np.uint8 for o in out)
     assert out[0].shape == (64, 64, 3) or out[0].shape == (64, 128, 3)       # resized to multiples of 64
     assert out[1].shape == out[0].shape and (out[0] < 255).any()             # inverted edge map shows the square
+
+
+def test_c_abi_rccl_exchange_single_rank():
+    """SURVEY section 8b `allreduce_flat`: the C ABI's own RCCL communicator (clora_comm_unique_id / clora_comm_init /
+    clora_allreduce_flat_f32; reference train...:683-685, 790).  One GPU here: a world of 1 -- the sum over one rank leaves the
+    flat gradient buffer bit-identical, on the launch stream, and the trainer path with comm="clora" runs a step."""
+    from controllora_amd import capi
+    from controllora_amd.train import ControlLoRATrainer
+    unet, _, clora = E.build_product_case("v1", "cuda")
+    tr = ControlLoRATrainer(unet, clora, init_scale=128.0, dynamic_scale=False, comm="clora")
+    assert capi.lib().cdll.clora_comm_world() == 1
+    g = tr.flat.grad
+    g.copy_(torch.randn(g.shape, generator=torch.Generator().manual_seed(0)).to(g.device))
+    before = g.clone()
+    tr._all_reduce_grads()
+    torch.cuda.synchronize()
+    assert torch.equal(g, before)
+    tr._init_clora_comm(None, 1)                                   # idempotent: a second trainer joins the existing communicator
+    assert capi.lib().cdll.clora_comm_destroy() == 0 and capi.lib().cdll.clora_comm_world() == 0
