@@ -1,8 +1,9 @@
 """Frozen CLIP text encoder + tokenizer glue (reference train_text_to_image_control_lora.py:395-402, 768;
-SURVEY.md section 8f rank 4: 13.3 GFLOP, forward-only, outside the hot path).  `transformers` ships in the
-image, so a checkpoint directory in the SD-1.5 layout (`text_encoder/`, `tokenizer/`) loads as is; offline there
-are no weights / vocab files, so the fallbacks are a seeded random-init CLIPTextModel of the SD-1.5 shape and a
-deterministic hashing tokenizer (start token, hashed word ids, end-token padding to 77)."""
+SURVEY.md section 8f rank 4: 13.3 GFLOP, forward-only, outside the hot path).  The encoder itself runs on the gfx950
+kernels (controllora_amd/clip.py); a checkpoint directory in the SD-1.5 layout (`text_encoder/`, `tokenizer/`) loads as
+is (the tokenizer through `transformers.CLIPTokenizer`); offline there are no weights / vocab files, so the stand-ins
+are a seeded random-init model of the SD-1.5 shape and a deterministic hashing tokenizer (start token, hashed word
+ids, end-token padding to 77)."""
 from __future__ import annotations
 
 import os
@@ -34,15 +35,33 @@ def load_tokenizer(root: str):
     return HashTokenizer()
 
 
+def _read_text_encoder_weights(folder: str):
+    """transformers file names of a `text_encoder/` folder (model.safetensors / pytorch_model.bin)"""
+    safe, pt = os.path.join(folder, "model.safetensors"), os.path.join(folder, "pytorch_model.bin")
+    if os.path.exists(safe):
+        from safetensors.torch import load_file
+        return load_file(safe)
+    if os.path.exists(pt):
+        return torch.load(pt, map_location="cpu", weights_only=True)
+    raise FileNotFoundError(f"no model.safetensors / pytorch_model.bin under {folder}")
+
+
 def load_text_encoder(root: str, device, seed: int = 0, small: bool = False):
-    from transformers import CLIPTextConfig, CLIPTextModel
+    """The frozen CLIP text encoder on the gfx950 kernels (controllora_amd/clip.py: same parameters / key names as
+    `transformers.CLIPTextModel`).  A checkpoint directory in the SD-1.5 layout (`text_encoder/config.json` + weights) loads as is;
+    offline the stand-in is a seeded random-init model of the SD-1.5 shape (`small`: a 2-layer test shape)."""
+    import json
+    from . import clip
     path = os.path.join(root, "text_encoder")
     if os.path.isdir(path):
-        model = CLIPTextModel.from_pretrained(path)
+        cfg = json.load(open(os.path.join(path, "config.json")))
+        keep = ("vocab_size", "hidden_size", "intermediate_size", "num_hidden_layers", "num_attention_heads",
+                "max_position_embeddings", "hidden_act", "layer_norm_eps")
+        model = clip.CLIPTextModel(**{k: v for k, v in cfg.items() if k in keep})
+        model.load_state_dict(_read_text_encoder_weights(path), strict=True)
     else:
-        cfg = CLIPTextConfig(vocab_size=VOCAB, hidden_size=64 if small else 768, intermediate_size=128 if small else 3072,
-                             num_hidden_layers=2 if small else 12, num_attention_heads=4 if small else 12,
-                             max_position_embeddings=CTX_LEN, hidden_act="quick_gelu", projection_dim=64 if small else 768)
-        torch.manual_seed(seed)
-        model = CLIPTextModel(cfg)
-    return model.to(device=device, dtype=torch.float16).eval().requires_grad_(False)
+        model = clip.CLIPTextModel(vocab_size=VOCAB, hidden_size=64 if small else 768, intermediate_size=128 if small else 3072,
+                                   num_hidden_layers=2 if small else 12, num_attention_heads=4 if small else 12,
+                                   max_position_embeddings=CTX_LEN)
+        clip.init_random_(model, seed)
+    return model.to(device).eval().requires_grad_(False)

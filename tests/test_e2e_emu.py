@@ -45,6 +45,26 @@ def test_clip_text_encoder_matches_transformers():
     print(clip_cases.check_clip("cpu", batch=1, seq=20, seed=3))
 
 
+def test_text_encoder_loads_a_transformers_checkpoint_folder(tmp_path):
+    """`text_encoder/` in the SD-1.5 layout (config.json + model.safetensors written by transformers' save_pretrained) loads
+    into the clora CLIP and reproduces the transformers model's last hidden state"""
+    from transformers import CLIPTextConfig, CLIPTextModel
+    from controllora_amd import text
+    from tests import clip_cases
+    torch.manual_seed(5)
+    ref = CLIPTextModel(CLIPTextConfig(hidden_act="quick_gelu", bos_token_id=0, eos_token_id=999, pad_token_id=999,
+                                       **clip_cases.SMALL_CLIP)).eval()
+    with torch.no_grad():
+        for p_ in ref.parameters():
+            p_.copy_(p_.half().float())
+    ref.save_pretrained(tmp_path / "text_encoder")
+    enc = text.load_text_encoder(str(tmp_path), "cpu")
+    ids = torch.randint(0, 1000, (2, 77), generator=torch.Generator().manual_seed(1))
+    with torch.no_grad():
+        want = ref(input_ids=ids).last_hidden_state
+    assert clip_cases.rel(enc(ids)[0], want) < 3e-3
+
+
 @pytest.mark.parametrize("case", ["v1", "v2"])
 def test_inference_with_control_batch_broadcast(case):
     print(case, E.check_inference_broadcast(case, "cpu"))
