@@ -875,12 +875,16 @@ __global__ __launch_bounds__(WM * WN * 64, (DmaOcc<BM, BN, NST, BK, WM * WN>::v)
 template <int BM, int BN> struct PatchCfg {
     static constexpr int MAXPP = (BM == 256) ? 400 : 288;    // patch pixels (multiple of 8): 4x66 / 6x34 / 10x18 / nx10x10 ... see eligibility
 };
+// WIDE (tile_cfg 77, 78): a 392-pixel patch = 3 x (128 + 2): ONE image row of 128 pixels, or a 128-pixel SEGMENT of a wider row
+// (W = 256, 512: the VAE's 128..256-channel levels; the tile's pixels are still consecutive rows of the NHWC operand).  The
+// halo patch is then 3.05x the output pixels instead of the 9x the implicit GEMM gathers.
+constexpr int kPatchWide = 392;
 
-template <int BM, int BN, int WM, int WN, int NST>
+template <int BM, int BN, int WM, int WN, int NST, int MAXPP_ = 0>
 __global__ __launch_bounds__(WM * WN * 64, 1) void conv3x3_patch_kernel(GemmArgs p) {
     constexpr int NT = WM * WN * 64, NW = WM * WN, BK = 64;
     constexpr int FM = BM / WM / 16, FN = BN / WN / 16;
-    constexpr int MAXPP = PatchCfg<BM, BN>::MAXPP;
+    constexpr int MAXPP = MAXPP_ > 0 ? MAXPP_ : PatchCfg<BM, BN>::MAXPP;
     constexpr int PA_IN = (MAXPP / 8 + NW - 1) / NW;           // patch DMA wave-instructions per wave per slab
     constexpr int B_NI = BN / 8;                               // ring DMA wave-instructions per stage (8 rows x 128 B each)
     constexpr int B_IN = (B_NI + NW - 1) / NW;                 // ... per wave (instruction ib = w + NW*i; surplus ones fetch the zero page into a dump slot)
@@ -907,10 +911,11 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void conv3x3_patch_kernel(GemmArgs
     // ---- geometry of this tile
     // (nearest-2x upsampled convs: the tile / patch live at the OUTPUT resolution and the loader reads source pixel (y>>1, x>>1))
     const int H = p.conv.Hout, W = p.conv.Wout, C = p.conv.Cin, HW = H * W, sh = p.conv.shift;
-    const int nimg = HW >= BM ? 1 : BM / HW, rpi = HW >= BM ? BM / W : H;   // images per tile, image rows per image
-    const int PW = W + 2, PRI = rpi + 2;
+    // images per tile, image rows per image, tile width: whole rows (TW = W), or for W > BM a BM-pixel segment of ONE row
+    const int nimg = HW >= BM ? 1 : BM / HW, rpi = HW >= BM ? (W >= BM ? 1 : BM / W) : H, TW = W > BM ? BM : W;
+    const int PW = TW + 2, PRI = rpi + 2;
     const int npp = nimg * PRI * PW;
-    const int b0 = m0 / HW, y0 = (m0 - b0 * HW) / W;
+    const int b0 = m0 / HW, y0 = (m0 - b0 * HW) / W, x0 = W > BM ? (m0 - b0 * HW - y0 * W) : 0;
     const int nb = p.M / HW;
     const int slabs = C / 64;
     const int cs_beg = split * p.k_per_split, cs_end_ = cs_beg + p.k_per_split;   // k_per_split counts SLABS here
@@ -925,7 +930,7 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void conv3x3_patch_kernel(GemmArgs
         if (pp < npp) {
             const int img = pp / (PRI * PW), rem = pp - img * (PRI * PW);
             const int pr = rem / PW, pc = rem - pr * PW;
-            const int y = y0 - 1 + pr, x = pc - 1, b = b0 + img;
+            const int y = y0 - 1 + pr, x = x0 + pc - 1, b = b0 + img;
             if (b < nb && y >= 0 && y < H && x >= 0 && x < W)
                 poff[j] = ((b * p.conv.Hin + (y >> sh)) * p.conv.Win + (x >> sh)) * C + ((pos ^ (pp & 7)) * 8);
         }
@@ -969,8 +974,8 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void conv3x3_patch_kernel(GemmArgs
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
         const int ml = wm * FM * 16 + i * 16 + li;
-        const int img = ml / (rpi * W), rem = ml - img * (rpi * W);
-        const int yl = rem / W, x = rem - yl * W;
+        const int img = ml / (rpi * TW), rem = ml - img * (rpi * TW);
+        const int yl = rem / TW, x = rem - yl * TW;
         pp0[i] = (img * PRI + yl) * PW + x;
     }
     int bsw[2];
@@ -1342,7 +1347,7 @@ int launch_gemm(GemmArgs& a, int splits, hipStream_t s, bool dma) {
 }
 
 // conv3x3_patch_kernel: what it can take (everything else stays on gemm_dma_kernel)
-bool patch_eligible(const GemmArgs& a, int bm) {
+bool patch_eligible(const GemmArgs& a, int bm, int maxpp = 0) {
     const clora_conv_t& c = a.conv;
     if (!c.enabled || c.ksize != 3 || c.mul != 1 || c.need_even != 0 || c.kchunk != 64 || (c.Cin % 64)) return false;
     if (c.shift == 0) {
@@ -1353,18 +1358,19 @@ bool patch_eligible(const GemmArgs& a, int bm) {
             return false;
     }
     const int W = c.Wout, HW = c.Hout * c.Wout;
-    if (W <= 0 || bm % W || (a.M % HW) || (long)a.M * c.Cin >= (1L << 31)) return false;
-    if (!((HW % bm) == 0 || (bm % HW) == 0)) return false;                                     // whole rows of one image, or whole images
-    const int nimg = HW >= bm ? 1 : bm / HW, rpi = HW >= bm ? bm / W : c.Hout;
-    return nimg * (rpi + 2) * (W + 2) <= (bm == 256 ? 400 : 288);
+    if (W <= 0 || (a.M % HW) || (long)a.M * c.Cin >= (1L << 31)) return false;
+    if ((bm % W) && !(maxpp > 0 && (W % bm) == 0)) return false;                               // whole rows, or (wide patch) row segments
+    if (!((HW % bm) == 0 || (bm % HW) == 0)) return false;                                     // ... of one image, or whole images
+    const int nimg = HW >= bm ? 1 : bm / HW, rpi = HW >= bm ? (W >= bm ? 1 : bm / W) : c.Hout, tw = W > bm ? bm : W;
+    return nimg * (rpi + 2) * (tw + 2) <= (maxpp > 0 ? maxpp : (bm == 256 ? 400 : 288));
 }
 
-template <int BM, int BN, int WM, int WN, int NST>
+template <int BM, int BN, int WM, int WN, int NST, int MAXPP_ = 0>
 int launch_patch(GemmArgs& a, int splits, hipStream_t s) {
     a.tiles_n = clora_cdiv(a.N, BN);
     pick_tile_order(a, BM, BN, splits, true);
     const dim3 grid(clora_cdiv(a.M, BM) * a.tiles_n, splits);
-    hipLaunchKernelGGL((conv3x3_patch_kernel<BM, BN, WM, WN, NST>), grid, dim3(WM * WN * 64), 0, s, a);
+    hipLaunchKernelGGL((conv3x3_patch_kernel<BM, BN, WM, WN, NST, MAXPP_>), grid, dim3(WM * WN * 64), 0, s, a);
     return clora_check_launch();
 }
 
@@ -1459,6 +1465,8 @@ extern "C" int clora_gemm_f16_ex(const clora_half* A, int lda, const clora_half*
     // untuned shape (no table entry: tile_cfg == 0) that the patch-staged conv kernel can take: it beat every implicit-GEMM
     // variant on all 46 tuned signatures (profiles/r02_tune_patch.log), so it is the default there too -- 128-pixel tiles, 160
     // columns when the width allows, split over slabs until the grid covers the chip (split_k == 0) or as forced
+    const bool untuned_wide = tile_cfg == 0 && dma && !a.epi.geglu && !patch_eligible(a, 128) && patch_eligible(a, 128, kPatchWide);
+    if (untuned_wide) { cfg = 77; if (split_k == 0) splits = 1; }   // W >= 128 (VAE levels): one row / a 128-pixel row segment per tile
     if (tile_cfg == 0 && dma && !a.epi.geglu && patch_eligible(a, 128)) {
         cfg = (N % 160 == 0) ? 76 : 72;
         if (split_k == 0) {
@@ -1478,8 +1486,9 @@ extern "C" int clora_gemm_f16_ex(const clora_half* A, int lda, const clora_half*
     //   71..76 = conv3x3_patch_kernel (3x3 stride-1 pad-1 convs and their dgrads, input patch staged once per 64-channel slab):
     //            256x128 (8 waves of 64x64), 128x128 (64x32), 128x128 (32x64), 256x64 (32x64), 128x64 (32x32), 128x160 (32x80: the
     //            UNet widths 320 / 640 / 960 / 1280 are multiples of 160, not of 128); shapes it cannot take fall back to 21
-    if (cfg >= 71 && cfg <= 76) {
-        if (!dma || !patch_eligible(a, (cfg == 71 || cfg == 74) ? 256 : 128)) cfg = 21;
+    //            77, 78 = 128x128 / 128x64 with the 392-pixel patch (one 128-pixel row or row segment per tile: W = 128, 256, 512)
+    if (cfg >= 71 && cfg <= 78) {
+        if (!dma || !patch_eligible(a, (cfg == 71 || cfg == 74) ? 256 : 128, cfg >= 77 ? kPatchWide : 0)) cfg = 21;
         else {
             const int slabs = a.conv.Cin / 64;
             if (splits > slabs) splits = slabs;
@@ -1496,6 +1505,8 @@ extern "C" int clora_gemm_f16_ex(const clora_half* A, int lda, const clora_half*
                 case 73: rc = launch_patch<128, 128, 4, 2, 3>(a, splits, s); break;
                 case 74: rc = launch_patch<256, 64, 8, 1, 4>(a, splits, s); break;
                 case 75: rc = launch_patch<128, 64, 4, 2, 4>(a, splits, s); break;
+                case 77: rc = launch_patch<128, 128, 2, 4, 3, kPatchWide>(a, splits, s); break;
+                case 78: rc = launch_patch<128, 64, 4, 2, 4, kPatchWide>(a, splits, s); break;
                 default: rc = launch_patch<128, 160, 4, 2, 3>(a, splits, s); break;
             }
             if (rc != CLORA_OK) return rc;
@@ -1588,10 +1599,10 @@ extern "C" int clora_set_option(const char* name, int value) {
 }
 
 extern "C" int clora_conv_patch_eligible(int M, const clora_conv_t* conv, int tile_cfg) {
-    if (!conv || tile_cfg < 71 || tile_cfg > 76) return 0;
+    if (!conv || tile_cfg < 71 || tile_cfg > 78) return 0;
     GemmArgs a;
     a.M = M; a.conv = *conv;
-    return patch_eligible(a, (tile_cfg == 71 || tile_cfg == 74) ? 256 : 128) ? 1 : 0;
+    return patch_eligible(a, (tile_cfg == 71 || tile_cfg == 74) ? 256 : 128, tile_cfg >= 77 ? kPatchWide : 0) ? 1 : 0;
 }
 
 extern "C" int clora_gemm_f16(const clora_half* A, int lda, const clora_half* B, clora_half* C, int ldc, int M, int N,

@@ -151,7 +151,7 @@ def case_conv_patch_upsampled(dev, Bn, H, W, Ci, Co, tile_cfg, seed=13):
         assert rel(out, yref) < 6e-4, (sk, rel(out, yref))
 
 
-def case_conv_patch(dev, Bn, H, W, Ci, Co, tile_cfg, seed=12):
+def case_conv_patch(dev, Bn, H, W, Ci, Co, tile_cfg, seed=12, fwd_only=False):
     """conv3x3_patch_kernel (tile_cfg 71..75): forward and dgrad of a stride-1 pad-1 conv with the slab-major K order,
     split-K 1..3, bias + residual epilogue, against F.conv2d autograd -- and the shape must really take the patch path."""
     from controllora_amd.ops import conv_k_order
@@ -176,7 +176,9 @@ def case_conv_patch(dev, Bn, H, W, Ci, Co, tile_cfg, seed=12):
         assert rel(out, yref) < 6e-4, (sk, rel(out, yref))
     out = K.gemm(xn, wp, M, Co, 9 * Ci, conv=cd, tile_cfg=tile_cfg, split_k=1, bias=bias, residual=res)
     assert rel(out, yref.float().cpu() + bias.float().cpu() + res.float().cpu()) < 6e-4
-    if Co % 64 == 0:
+    out = K.gemm(xn, wp, M, Co, 9 * Ci, conv=cd, _tuned=False)                 # the library's own choice for an untuned shape
+    assert rel(out, yref) < 6e-4
+    if Co % 64 == 0 and not fwd_only:
         wd = conv_k_order(w.permute(1, 2, 3, 0).contiguous().reshape(Ci, 9, Co), 64)
         dyn = dy.permute(0, 2, 3, 1).contiguous().reshape(M, Co)
         cdd = K.conv_dgrad_desc(H, W, Co, H, W, 3, 1, 1, kchunk=64)

@@ -68,6 +68,13 @@ def test_conv_patch_kernel_upsampled(tile, Bn, H, Ci):
     KC.case_conv_patch_upsampled(DEV, Bn, H, H, Ci, Ci, tile)
 
 
+@pytest.mark.parametrize("tile", [77, 78])
+@pytest.mark.parametrize("Bn,H,W,Ci,Co", [(1, 512, 512, 128, 128), (2, 256, 256, 256, 256), (2, 128, 128, 512, 512), (1, 256, 256, 128, 256)])
+def test_conv_patch_kernel_row_segments_vae_shapes(tile, Bn, H, W, Ci, Co):
+    """tile_cfg 77 / 78 (392-pixel patch, one 128-pixel row or row segment per tile) at the SD-1.5 VAE's level shapes"""
+    KC.case_conv_patch(DEV, Bn, H, W, Ci, Co, tile, fwd_only=True)
+
+
 @pytest.mark.parametrize("tile", [0, 3, 21, 23, 43, 51, 52, 53, 54, 55, 56, 57, 58])
 def test_gemm_epilogue_without_rowadd(tile):
     """projection epilogues at real shapes (M = 16384 x N = 320 / 960, ragged variants): two-phase chunk loop of the 8-wave tiles"""
