@@ -425,6 +425,64 @@ def main():
     if args.trace_child:
         return
 
+    # secondary line of BASELINE.json's metric: 50-step DDIM latency, 512^2, 16 images, CFG 9.0 (UNet batch 32),
+    # control batch 1 (the inference call pattern of apps/gradio_canny2image.py:66-92); replicas only, rank 0, N=1
+    ddim = None
+    if world == 1 and rank == 0 and not args.no_ddim:
+        from controllora_amd.pipeline import ddim_sample
+        nb = args.ddim_batch
+        g = torch.Generator(device=dev).manual_seed(1)
+        cond = torch.randn(nb, 77, 768, device=dev, generator=g).half()
+        uncond = torch.randn(nb, 77, 768, device=dev, generator=g).half()
+        lat0 = torch.randn(nb, 4, args.res // 8, args.res // 8, device=dev, generator=g).half()
+        ddim_sample(unet, clora, batch["guide"][:1], cond, uncond, steps=2, latents=lat0)      # warm-up
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        out = ddim_sample(unet, clora, batch["guide"][:1], cond, uncond, steps=50, guidance_scale=9.0, latents=lat0)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t1
+        ddim = {"metric": f"50-step DDIM latency {args.res}^2 bs{nb} (CFG 9.0, UNet batch {2 * nb}, control batch 1)",
+                "latency_s": round(dt, 3), "images_per_s": round(nb / dt, 3), "finite": bool(torch.isfinite(out.float()).all())}
+        del out, cond, uncond, lat0
+        torch.cuda.empty_cache()
+
+    # informational third line: the WHOLE reference step (train...:751-796) -- VAE encode x0.18215, noise / timesteps /
+    # add_noise, CLIP text encode (stock transformers model: frozen glue outside the hot path), then the captured hot
+    # path -- so the cost of what SURVEY section 8f ranks "next" is visible beside the headline number.  N=1, rank 0.
+    full = None
+    if world == 1 and rank == 0 and graphed and not args.no_full_step:
+        from controllora_amd import loading, text
+        vae = loading.load_vae("random:sd15", dev)
+        enc = text.load_text_encoder("random:sd15", dev)
+        gpix = torch.Generator(device=dev).manual_seed(3)
+        pixel = (torch.rand(args.batch, 3, args.res, args.res, device=dev, generator=gpix) * 2 - 1).half()
+        ids = torch.randint(0, 49408, (args.batch, 77), device=dev, generator=gpix)
+
+        def full_step():
+            with torch.no_grad():
+                lat = vae.encode(pixel).latent_dist.sample() * vae.scaling_factor
+                nz = torch.randn_like(lat)
+                ts = torch.randint(0, 1000, (args.batch,), device=dev)
+                ny = DDPMScheduler().add_noise(lat, nz, ts).half()
+                ehs_ = enc(ids)[0].half()
+            trainer.step_graphed(ny, ts, ehs_, batch["guide"], nz)
+
+        for _ in range(2):
+            full_step()
+        torch.cuda.synchronize()
+        tf0 = time.perf_counter()
+        nfull = max(5, args.steps // 2)
+        for _ in range(nfull):
+            full_step()
+        torch.cuda.synchronize()
+        fms = (time.perf_counter() - tf0) / nfull * 1e3
+        full = {"what": "VAE encode + CLIP text encode + noise/add_noise + hot path (random-init SD-1.5-shaped VAE / CLIP)",
+                "ms_per_step": round(fms, 3), "images_per_s": round(args.batch / fms * 1e3, 3), "steps": nfull}
+        del vae, enc
+        torch.cuda.empty_cache()
+
+    # (the roofline leg runs AFTER the secondary timings: its rocprofv3 --pmc child passes were followed by a 10 % slower DDIM line
+    # on the same box -- counter collection leaves the device in a profiling power state for a while)
     roofline = None
     if not args.no_roofline and rank != 0:
         eager_step()                           # the profiled step contains the all-reduce: every rank takes part
@@ -491,62 +549,6 @@ def main():
                     "whole_step_frac_of_mfma_peak": round(
                         images_per_s / world * hot_path_tflop_per_image(args.res) / MFMA_PEAK_TFLOPS, 4),
                     "whole_step_algorithmic_TFLOPs": round(images_per_s / world * hot_path_tflop_per_image(args.res), 1)}
-
-    # secondary line of BASELINE.json's metric: 50-step DDIM latency, 512^2, 16 images, CFG 9.0 (UNet batch 32),
-    # control batch 1 (the inference call pattern of apps/gradio_canny2image.py:66-92); replicas only, rank 0, N=1
-    ddim = None
-    if world == 1 and rank == 0 and not args.no_ddim:
-        from controllora_amd.pipeline import ddim_sample
-        nb = args.ddim_batch
-        g = torch.Generator(device=dev).manual_seed(1)
-        cond = torch.randn(nb, 77, 768, device=dev, generator=g).half()
-        uncond = torch.randn(nb, 77, 768, device=dev, generator=g).half()
-        lat0 = torch.randn(nb, 4, args.res // 8, args.res // 8, device=dev, generator=g).half()
-        ddim_sample(unet, clora, batch["guide"][:1], cond, uncond, steps=2, latents=lat0)      # warm-up
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        out = ddim_sample(unet, clora, batch["guide"][:1], cond, uncond, steps=50, guidance_scale=9.0, latents=lat0)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t1
-        ddim = {"metric": f"50-step DDIM latency {args.res}^2 bs{nb} (CFG 9.0, UNet batch {2 * nb}, control batch 1)",
-                "latency_s": round(dt, 3), "images_per_s": round(nb / dt, 3), "finite": bool(torch.isfinite(out.float()).all())}
-        del out, cond, uncond, lat0
-        torch.cuda.empty_cache()
-
-    # informational third line: the WHOLE reference step (train...:751-796) -- VAE encode x0.18215, noise / timesteps /
-    # add_noise, CLIP text encode (stock transformers model: frozen glue outside the hot path), then the captured hot
-    # path -- so the cost of what SURVEY section 8f ranks "next" is visible beside the headline number.  N=1, rank 0.
-    full = None
-    if world == 1 and rank == 0 and graphed and not args.no_full_step:
-        from controllora_amd import loading, text
-        vae = loading.load_vae("random:sd15", dev)
-        enc = text.load_text_encoder("random:sd15", dev)
-        gpix = torch.Generator(device=dev).manual_seed(3)
-        pixel = (torch.rand(args.batch, 3, args.res, args.res, device=dev, generator=gpix) * 2 - 1).half()
-        ids = torch.randint(0, 49408, (args.batch, 77), device=dev, generator=gpix)
-
-        def full_step():
-            with torch.no_grad():
-                lat = vae.encode(pixel).latent_dist.sample() * vae.scaling_factor
-                nz = torch.randn_like(lat)
-                ts = torch.randint(0, 1000, (args.batch,), device=dev)
-                ny = DDPMScheduler().add_noise(lat, nz, ts).half()
-                ehs_ = enc(ids)[0].half()
-            trainer.step_graphed(ny, ts, ehs_, batch["guide"], nz)
-
-        for _ in range(2):
-            full_step()
-        torch.cuda.synchronize()
-        tf0 = time.perf_counter()
-        nfull = max(5, args.steps // 2)
-        for _ in range(nfull):
-            full_step()
-        torch.cuda.synchronize()
-        fms = (time.perf_counter() - tf0) / nfull * 1e3
-        full = {"what": "VAE encode + CLIP text encode + noise/add_noise + hot path (random-init SD-1.5-shaped VAE / CLIP)",
-                "ms_per_step": round(fms, 3), "images_per_s": round(args.batch / fms * 1e3, 3), "steps": nfull}
-        del vae, enc
-        torch.cuda.empty_cache()
 
     cpu = None
     if world == 1 and rank == 0 and not args.no_cpu_baseline:

@@ -417,8 +417,16 @@ __device__ __forceinline__ void dma_epilogue(const GemmArgs& p, floatx4 (&acc)[B
     constexpr bool HOIST_PAYS = HOIST && (BM * CPR / NT) >= 4 && (BM / WM / 16) * (BN / WN / 16) * 4 < 128;
     // the two-phase chunk loop (below) only where the register file has the room: the 8-wave tiles up to 128 rows (64x320, 128x320,
     // 128x256: one block per CU, 256 VGPRs per wave); the 256-row tiles and the 2-blocks-per-CU kernels would spill
-    constexpr bool TWO_PHASE = HOIST_PAYS && NT == 512 && BM <= 128;
-    const bool hoist = HOIST_PAYS && p.epi.lora_t != nullptr && p.epi.lora_r == 4 && p.epi.geglu == 0 && n < p.N &&
+    // SMALL2: the 64x64 tile (4 waves; 167 launches per step: out / proj / FF2 projections at the 32x32 .. 8x8 levels).  A thread owns
+    // TWO chunks of one column there; with its accumulators dead after the single staging pass, U, bias and both rows' T / residual
+    // chunks are one batch of loads instead of ~12 dependent ones per chunk (tools/gemm_decomp.py: +4.8 .. +6.3 us per launch for
+    // bias + adapter + residual on a 10 us launch).
+    // Only the variants whose LDS ring (>= 48 KB) already limits them to <= 3 blocks per CU have the registers (164 of 170 VGPRs,
+    // no spills); the BK = 32 three-stage variant is built for 5 blocks per CU (96 VGPRs) and would spill 61.
+    constexpr bool SMALL2 = BM == 64 && BN == 64 && NT == 256 && NPASS == 1 && SMEM >= 24576;
+    constexpr bool FIXED_COL = HOIST_PAYS || SMALL2;           // thread -> one fixed chunk column, rows t / CPR + it * RPIT
+    constexpr bool TWO_PHASE = (HOIST_PAYS && NT == 512 && BM <= 128) || SMALL2;
+    const bool hoist = FIXED_COL && p.epi.lora_t != nullptr && p.epi.lora_r == 4 && p.epi.geglu == 0 && n < p.N &&
                        ((p.epi.ldt | ((n / p.epi.lora_seg) * 4)) & 3) == 0 && (p.epi.lora_u_tr ? (p.epi.ldu & 3) == 0 : p.epi.ldu == 4);
     // `two`: this thread takes the two-phase chunk loop -- adapter launches it can hoist, and launches without an adapter
     // (proj_in / proj_out / FF2 and the dgrads: bias and / or residual only)
@@ -551,7 +559,7 @@ __device__ __forceinline__ void dma_epilogue(const GemmArgs& p, floatx4 (&acc)[B
                 st8(p.C + (size_t)m * p.ldc + n, o);
             }
         };
-        if constexpr (HOIST_PAYS) {
+        if constexpr (FIXED_COL) {
             // thread -> one fixed chunk column, rows ml = t / CPR + it * RPIT: what depends on the column only is already in registers
             if (two) {
                 // Two-phase form: the accumulators are dead (staged in LDS), so the T row and the residual chunk of EVERY row this
@@ -568,17 +576,19 @@ __device__ __forceinline__ void dma_epilogue(const GemmArgs& p, floatx4 (&acc)[B
                 for (int it = 0; it < NIT; ++it) {
                     const int ml = t / CPR + it * RPIT, m = m0 + ph * PR + ml;
                     const int mc = (col_ok && ml < PR && m < p.M) ? m : m0;
-                    t4s[it] = zero4f();
-                    if (hoist) t4s[it] = *reinterpret_cast<const floatx4*>(p.epi.lora_t + (size_t)mc * p.epi.ldt + utoff);
-                    rrs[it] = zero8();
-                    if (has_res) rrs[it] = ld8((const half_t*)p.epi.residual + (size_t)mc * p.epi.ldr + n);
+                    // unconditional loads (an absent operand reads the 16-byte zero page): no branch between them, one batch
+                    const float* tp = hoist ? p.epi.lora_t + (size_t)mc * p.epi.ldt + utoff : reinterpret_cast<const float*>(g_clora_zero16);
+                    const half_t* rp = has_res ? (const half_t*)p.epi.residual + (size_t)mc * p.epi.ldr + n
+                                               : reinterpret_cast<const half_t*>(g_clora_zero16);
+                    t4s[it] = *reinterpret_cast<const floatx4*>(tp);
+                    rrs[it] = ld8(rp);
                 }
                 // pin the loaded registers only AFTER every load has been issued (an asm that consumes a register waits for its
                 // load): stops the compiler from sinking each load into the conditional block that uses it
 #pragma unroll
                 for (int it = 0; it < NIT; ++it) {
-                    if (hoist) CLORA_KEEP(t4s[it]);
-                    if (has_res) CLORA_KEEP(rrs[it]);
+                    CLORA_KEEP(t4s[it]);
+                    CLORA_KEEP(rrs[it]);
                 }
 #pragma unroll
                 for (int it = 0; it < NIT; ++it) {
