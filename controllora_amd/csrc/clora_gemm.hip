@@ -417,13 +417,11 @@ __device__ __forceinline__ void dma_epilogue(const GemmArgs& p, floatx4 (&acc)[B
     constexpr bool HOIST_PAYS = HOIST && (BM * CPR / NT) >= 4 && (BM / WM / 16) * (BN / WN / 16) * 4 < 128;
     // the two-phase chunk loop (below) only where the register file has the room: the 8-wave tiles up to 128 rows (64x320, 128x320,
     // 128x256: one block per CU, 256 VGPRs per wave); the 256-row tiles and the 2-blocks-per-CU kernels would spill
-    // SMALL2: the 64x64 tile (4 waves; 167 launches per step: out / proj / FF2 projections at the 32x32 .. 8x8 levels).  A thread owns
-    // TWO chunks of one column there; with its accumulators dead after the single staging pass, U, bias and both rows' T / residual
-    // chunks are one batch of loads instead of ~12 dependent ones per chunk (tools/gemm_decomp.py: +4.8 .. +6.3 us per launch for
-    // bias + adapter + residual on a 10 us launch).
-    // Only the variants whose LDS ring (>= 48 KB) already limits them to <= 3 blocks per CU have the registers (164 of 170 VGPRs,
-    // no spills); the BK = 32 three-stage variant is built for 5 blocks per CU (96 VGPRs) and would spill 61.
-    constexpr bool SMALL2 = BM == 64 && BN == 64 && NT == 256 && NPASS == 1 && SMEM >= 24576;
+    // SMALL2 (the 64x64 BK = 64 tile: a thread owns two chunks of one column) is NOT enabled: with the hoisted U registers that kernel
+    // produced a handful of wrong elements per launch on MI355X at M = 16384, N = K = 320 -- sporadic, different on every run, rows
+    // 6 / 7 (mod 8) of a fragment, with the two-phase loop on AND off (profiles/r03_epi_diag.txt); the emulator and the 8-wave tiles
+    // are clean.  Not understood (164 VGPRs at 3 blocks per CU; no spills), so the 64x64 tile keeps the one-chunk-at-a-time epilogue.
+    constexpr bool SMALL2 = false;
     constexpr bool FIXED_COL = HOIST_PAYS || SMALL2;           // thread -> one fixed chunk column, rows t / CPR + it * RPIT
     constexpr bool TWO_PHASE = (HOIST_PAYS && NT == 512 && BM <= 128) || SMALL2;
     const bool hoist = FIXED_COL && p.epi.lora_t != nullptr && p.epi.lora_r == 4 && p.epi.geglu == 0 && n < p.N &&
@@ -1475,8 +1473,9 @@ extern "C" int clora_gemm_f16_ex(const clora_half* A, int lda, const clora_half*
     // untuned shape (no table entry: tile_cfg == 0) that the patch-staged conv kernel can take: it beat every implicit-GEMM
     // variant on all 46 tuned signatures (profiles/r02_tune_patch.log), so it is the default there too -- 128-pixel tiles, 160
     // columns when the width allows, split over slabs until the grid covers the chip (split_k == 0) or as forced
-    const bool untuned_wide = tile_cfg == 0 && dma && !a.epi.geglu && !patch_eligible(a, 128) && patch_eligible(a, 128, kPatchWide);
-    if (untuned_wide) { cfg = 77; if (split_k == 0) splits = 1; }   // W >= 128 (VAE levels): one row / a 128-pixel row segment per tile
+    // (shapes only the WIDE patch can take -- rows of 128 pixels and more: the VAE's levels -- stay on the implicit GEMM: on MI355X
+    // tile_cfg 77 ties it at 128 x 128 maps and loses 10-25 % at 256^2 / 512^2, profiles/r03_vae_conv_ab.txt: with 128 output columns
+    // per tile the weight stream, which the patch does not reduce, dominates the operand traffic)
     if (tile_cfg == 0 && dma && !a.epi.geglu && patch_eligible(a, 128)) {
         cfg = (N % 160 == 0) ? 76 : 72;
         if (split_k == 0) {

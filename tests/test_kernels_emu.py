@@ -78,7 +78,7 @@ def test_conv_patch_kernel_upsampled(tile):
 @pytest.mark.parametrize("Bn,H,W,Ci,Co", [(1, 3, 128, 64, 64), (1, 2, 256, 64, 128), (2, 1, 128, 128, 64)])
 def test_conv_patch_kernel_row_segments(tile, Bn, H, W, Ci, Co):
     """tile_cfg 77 / 78 (392-pixel patch): one 128-pixel image row per tile (W = 128) or 128-pixel SEGMENTS of a wider row (W = 256):
-    the VAE's levels; forward, dgrad, split-K, epilogue -- and an untuned launch (tile_cfg 0) picks the wide patch by itself"""
+    the VAE's levels; forward, dgrad, split-K, epilogue"""
     KC.case_conv_patch("cpu", Bn, H, W, Ci, Co, tile)
     if tile == 77:
         KC.case_conv_patch_upsampled("cpu", 1, 2, 64, 64, 64, tile)        # output rows of 128 pixels from a 64-wide source

@@ -9,7 +9,8 @@ def rel(a, b):
     a, b = a.float().cpu(), b.float().cpu()
     return float((a - b).norm() / (b.norm() + 1e-20))
 def where(out, ref, BM=64, BN=64):
-    d = (out.float().cpu() - ref.float().cpu()).abs()
+    ref = ref.float().cpu()
+    d = (out.float().cpu() - ref).abs()
     bad = d > 0.02 * ref.abs().max()
     if not bool(bad.any()):
         return "none"
