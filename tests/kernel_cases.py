@@ -17,6 +17,16 @@ def rel(a, b):
     return float((a - b).norm() / (b.norm() + 1e-20))
 
 
+def no_outliers(out, ref, what=""):
+    """elementwise guard beside the rel-L2 checks: a handful of wrong elements in a large tensor (a race that corrupts a few
+    rows of a few tiles -- seen on hardware with an epilogue variant in round 3) moves rel-L2 by 1e-4..1e-3 only and would
+    pass a norm-wise limit; no element may be further from the reference than a few fp16 ulps of the largest value."""
+    out, ref = out.detach().float().cpu(), ref.detach().float().cpu()
+    lim = 6e-3 * max(1.0, float(ref.abs().max()))
+    worst = float((out - ref).abs().max())
+    assert worst < lim, f"{what}: {int(((out - ref).abs() >= lim).sum())} elements off by up to {worst:.3f} (limit {lim:.3f})"
+
+
 def rnd(shape, dev, gen, scale=1.0, dtype=f16):
     return (torch.randn(shape, generator=gen) * scale).to(dtype).to(dev)
 
@@ -58,13 +68,21 @@ def case_gemm_epilogue_no_rowadd(dev, M=300, N=320, K_=128, tile_cfg=0, split_k=
     kw = dict(split_k=split_k, tile_cfg=tile_cfg)
     out = K.gemm(A, B, M, N, K_, bias=bias, residual=res, lora_t=T, lora_u=U, lora_seg=seg_w, lora_scale=0.7, **kw)
     assert rel(out, (base + bias + 0.7 * lora).half().float() + res.float()) < 6e-4
+    no_outliers(out, (base + bias + 0.7 * lora).half().float() + res.float(), "bias + adapter + residual")
+    again = K.gemm(A, B, M, N, K_, bias=bias, residual=res, lora_t=T, lora_u=U, lora_seg=seg_w, lora_scale=0.7, **kw)
+    assert torch.equal(out, again), "the same launch twice must give the same bits"
     out = K.gemm(A, B, M, N, K_, lora_t=T, lora_u=U, lora_seg=seg_w, lora_scale=1.0, **kw)            # no bias, no residual
     assert rel(out, (base + lora).half().float()) < 6e-4
+    no_outliers(out, (base + lora).half().float(), "adapter only")
     Ut = rnd((4, N), dev, g, dtype=f32)                                                                  # dgrad form: u(n, j) = Ut[j, n]
     out = K.gemm(A, B, M, N, K_, residual=res, lora_t=T[:, :4].contiguous(), lora_u=Ut, lora_seg=N, lora_u_tr=True, lora_r=4, **kw)
     assert rel(out, (base + T[:, :4] @ Ut).half().float() + res.float()) < 6e-4
+    no_outliers(out, (base + T[:, :4] @ Ut).half().float() + res.float(), "transposed-U adapter + residual")
+    again = K.gemm(A, B, M, N, K_, residual=res, lora_t=T[:, :4].contiguous(), lora_u=Ut, lora_seg=N, lora_u_tr=True, lora_r=4, **kw)
+    assert torch.equal(out, again), "the same launch twice must give the same bits"
     out = K.gemm(A, B, M, N, K_, bias=bias, residual=res, **kw)
     assert rel(out, (base + bias).half().float() + res.float()) < 6e-4
+    no_outliers(out, (base + bias).half().float() + res.float(), "bias + residual")
     out = K.gemm(A, B, M, N, K_, residual=res, **kw)
     assert rel(out, base.half().float() + res.float()) < 6e-4
 
