@@ -121,7 +121,7 @@ def _tuned(M, N, K, conv):
     if _TUNING is None:
         import json
         import os
-        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gemm_tuning_gfx950.json")
+        path = os.environ.get("CLORA_GEMM_TUNING_FILE") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "gemm_tuning_gfx950.json")
         use = os.path.exists(path) and os.environ.get("CLORA_GEMM_TUNING", "1") != "0"   # "0": latency model only (A/B runs)
         _TUNING = json.load(open(path))["table"] if use else {}
     return _TUNING.get(tuning_key(M, N, K, conv))
