@@ -28,7 +28,9 @@ struct DownJobs {
 // KSPLIT (few rows: the 32x32 / 16x16 / 8x8 levels and the 77-token text context): one block = ONE 16-row group,
 // its four waves each take a quarter of K and the partial tiles are folded through LDS -- 4x more blocks and a 4x
 // shorter dependent load chain for what is a pure latency problem at those sizes.
-template <bool KSPLIT>
+// G = k-steps whose loads are in flight together (4 KB of X per wave at G = 4).  Bytes in flight are what bounds this kernel: at
+// M = 16384 the non-split form has ONE block per CU = 16 KB in flight per CU = 2.6 TB/s by Little's law, exactly what it measured.
+template <bool KSPLIT, int G = 4>
 __global__ __launch_bounds__(256) void lora_down_kernel(DownJobs jobs) {
     const clora_lora_down_job_t& p = jobs.j[blockIdx.y];
     const half_t* X = (const half_t*)p.X;
@@ -52,7 +54,6 @@ __global__ __launch_bounds__(256) void lora_down_kernel(DownJobs jobs) {
     const int d_kmajor = p.d_kmajor;
     const float dscale = p.d_scale;
     floatx4 acc = zero4f();
-    constexpr int G = 4;                                   // k-steps in flight
     const int npass = p.X2 ? 2 : 1;                        // second input: (X + X2) . D^T by linearity, same accumulator
     for (int pass = 0; pass < npass; ++pass) {
     if (pass == 1) {
@@ -345,10 +346,16 @@ extern "C" int clora_lora_down_multi_f16(const clora_lora_down_job_t* jobs, int 
         dj.j[i] = j;
         if (j.M > maxM) maxM = j.M;
     }
-    if (maxM <= 4096)
-        hipLaunchKernelGGL(lora_down_kernel<true>, dim3(clora_cdiv(maxM, 16), njobs), dim3(256), 0, (hipStream_t)stream, dj);
+    // option "lora_down_mode": 0 = K-split up to 4096 rows, one wave per 16 rows x all of K above (round-1/2 behaviour);
+    // 1 = K-split at every size (4x the waves, each a quarter of K: more bytes in flight per CU at M = 16384);
+    // 2 = as 0 with eight k-steps in flight per wave above 4096 rows
+    const int mode = clora_option(CLORA_OPT_LORA_DOWN_MODE);
+    if (maxM <= 4096 || mode == 1)
+        hipLaunchKernelGGL((lora_down_kernel<true, 4>), dim3(clora_cdiv(maxM, 16), njobs), dim3(256), 0, (hipStream_t)stream, dj);
+    else if (mode == 2)
+        hipLaunchKernelGGL((lora_down_kernel<false, 8>), dim3(clora_cdiv(maxM, 64), njobs), dim3(256), 0, (hipStream_t)stream, dj);
     else
-        hipLaunchKernelGGL(lora_down_kernel<false>, dim3(clora_cdiv(maxM, 64), njobs), dim3(256), 0, (hipStream_t)stream, dj);
+        hipLaunchKernelGGL((lora_down_kernel<false, 4>), dim3(clora_cdiv(maxM, 64), njobs), dim3(256), 0, (hipStream_t)stream, dj);
     return clora_check_launch();
 }
 

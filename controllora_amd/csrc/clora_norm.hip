@@ -92,8 +92,9 @@ __device__ __forceinline__ void gn_block_reduce(float* red, const float (&a)[NJ]
 constexpr int kRedFloats = 2 * 4096;   // LDS: max(nrl*C, C) * 2 floats with nrl*C <= 2048 for CH < 256
 
 // ---- forward, pass 1
-template <int NJ>
+template <int NJ, int UF = 1>
 __global__ __launch_bounds__(256) void gn_fwd_partial_kernel(GnArgs p) {
+    constexpr int kGnU = ::kGnU * UF;                        // rows loaded before the first is used (option "gn_unroll": UF = 2)
     __shared__ float red[kRedFloats];
     const int t = threadIdx.x, b = blockIdx.z, chunk = blockIdx.x, cb = blockIdx.y * p.CS;
     const int CH = p.CS / 8, gps = p.G / p.nslab;
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(256) void gn_fwd_partial_kernel(GnArgs p) {
 }
 
 // ---- backward, pass 1: per channel a1 = sum dyp, a2 = sum dyp*xhat over this block's rows
-template <int NJ>
+template <int NJ, int UF = 1>
 __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(GnArgs p) {
     __shared__ float red[kRedFloats];
     const int t = threadIdx.x, b = blockIdx.z, chunk = blockIdx.x, cb = blockIdx.y * p.CS;
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(GnArgs p) {
         }
     if (active) {
         const size_t boff = (size_t)b * p.HW * p.C + cb;
-        constexpr int U = 2;                                     // two tensors per row: 4 * NJ loads in flight
+        constexpr int U = 2 * UF;                                // two tensors per row: 4 * NJ * UF loads in flight
         for (int it0 = 0; it0 < nit; it0 += U) {
             half8 xv[U][NJ], gv[U][NJ];
 #pragma unroll
@@ -233,8 +234,9 @@ __device__ __forceinline__ void gn_fold_groups(const GnArgs& p, int b, int t, fl
     if (g < p.G && part == 0) { out2[g * 2] = s * inv_n; out2[g * 2 + 1] = q * inv_n; }
 }
 
-template <int NJ>
+template <int NJ, int UF = 1>
 __global__ __launch_bounds__(256) void gn_fwd_apply2_kernel(GnArgs p) {
+    constexpr int kGnU = ::kGnU * UF;
     __shared__ float mr[64 * 2];
     const int t = threadIdx.x, b = blockIdx.z, chunk = blockIdx.x, cb = blockIdx.y * p.CS;
     const int CH = p.CS / 8, cpg = p.C / p.G;
@@ -300,7 +302,7 @@ __global__ __launch_bounds__(256) void gn_fwd_apply2_kernel(GnArgs p) {
 }
 
 // ---- fused finalize + apply (backward): dx = k1*dyp + k2*x + k3 with per-channel coefficients in registers
-template <int NJ>
+template <int NJ, int UF = 1>
 __global__ __launch_bounds__(256) void gn_bwd_apply2_kernel(GnArgs p) {
     __shared__ float gs[64 * 2];
     const int t = threadIdx.x, b = blockIdx.z, chunk = blockIdx.x, cb = blockIdx.y * p.CS;
@@ -331,7 +333,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply2_kernel(GnArgs p) {
     const size_t boff = (size_t)b * p.HW * p.C + cb;
     const bool has_res = p.dres != nullptr;                      // kernel-uniform
     const half_t* res = has_res ? p.dres : p.dy;                 // a valid address either way: the loads stay unconditional
-    constexpr int U = 2;                                         // three tensors per row: 6 * NJ loads in flight
+    constexpr int U = 2 * UF;                                    // three tensors per row: 6 * NJ * UF loads in flight
     for (int it0 = 0; it0 < nit; it0 += U) {
         half8 xv[U][NJ], gv[U][NJ], rv[U][NJ];
 #pragma unroll
@@ -749,8 +751,13 @@ extern "C" int clora_groupnorm_fwd_f16(const clora_half* x, clora_half* y, const
         hipLaunchKernelGGL(gn_fwd_partial_kernel<2>, grid, dim3(256), 0, s, a);
         hipLaunchKernelGGL(gn_fwd_apply2_kernel<2>, grid, dim3(256), 0, s, a);
     } else {
-        hipLaunchKernelGGL(gn_fwd_partial_kernel<1>, grid, dim3(256), 0, s, a);
-        hipLaunchKernelGGL(gn_fwd_apply2_kernel<1>, grid, dim3(256), 0, s, a);
+        if (clora_option(CLORA_OPT_GN_UNROLL)) {                 // twice the rows in flight per thread (same accumulation order: same bits)
+            hipLaunchKernelGGL((gn_fwd_partial_kernel<1, 2>), grid, dim3(256), 0, s, a);
+            hipLaunchKernelGGL((gn_fwd_apply2_kernel<1, 2>), grid, dim3(256), 0, s, a);
+        } else {
+            hipLaunchKernelGGL(gn_fwd_partial_kernel<1>, grid, dim3(256), 0, s, a);
+            hipLaunchKernelGGL(gn_fwd_apply2_kernel<1>, grid, dim3(256), 0, s, a);
+        }
     }
     return clora_check_launch();
 }
@@ -770,9 +777,11 @@ extern "C" int clora_groupnorm_bwd_f16(const clora_half* x, const clora_half* dy
     const dim3 grid(a.nchunk, a.nslab, B);
     const bool two = a.CS / 8 > 256;                             // slabs wider than 2048 channels
     if (two) hipLaunchKernelGGL(gn_bwd_partial_kernel<2>, grid, dim3(256), 0, s, a);
+    else if (clora_option(CLORA_OPT_GN_UNROLL)) hipLaunchKernelGGL((gn_bwd_partial_kernel<1, 2>), grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL(gn_bwd_partial_kernel<1>, grid, dim3(256), 0, s, a);
     if (dgamma) hipLaunchKernelGGL(gn_bwd_params_kernel, dim3(clora_cdiv(C, 32)), dim3(256), 0, s, a);
     if (two) hipLaunchKernelGGL(gn_bwd_apply2_kernel<2>, grid, dim3(256), 0, s, a);
+    else if (clora_option(CLORA_OPT_GN_UNROLL)) hipLaunchKernelGGL((gn_bwd_apply2_kernel<1, 2>), grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL(gn_bwd_apply2_kernel<1>, grid, dim3(256), 0, s, a);
     return clora_check_launch();
 }

@@ -3,6 +3,7 @@ attention-site / resnet shapes of SD-1.5 plus ragged edge
 import pytest
 import torch
 
+from controllora_amd import kernels as K
 from tests import kernel_cases as KC
 
 pytestmark = pytest.mark.gpu
@@ -141,6 +142,28 @@ def test_geglu():
 @pytest.mark.parametrize("M,K,N,R,xr", [(8192, 320, 320, 4, 0), (8192, 320, 320, 8, 4096), (308, 768, 640, 8, 0), (512, 576, 320, 32, 0)])
 def test_lora(M, K, N, R, xr):
     KC.case_lora(DEV, M, K, N, R, x_rows=xr)
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_lora_down_launch_modes(mode):
+    """option "lora_down_mode": how an adapter down-projection is spread over waves (K-split everywhere / eight k-steps in flight):
+    same T within fp32 summation-order noise at the level-0 size, stacked q|k|v rows with a second input on the first adapter"""
+    g = torch.Generator().manual_seed(61)
+    M, Kd = 16384, 320
+    X, X2 = KC.rnd((M, Kd), DEV, g), KC.rnd((M, Kd), DEV, g)
+    D = KC.rnd((12, Kd), DEV, g, 0.25, dtype=torch.float32)
+    ref = X.float() @ D.T
+    ref[:, :4] += X2.float() @ D[:4].T
+    try:
+        K.set_option("lora_down_mode", mode)
+        T = torch.empty((M, 12), dtype=torch.float32, device=DEV)
+        K.lora_down_multi([K.down_job(X, D, T, 0, M, Kd, X2=X2, r2=4)])
+        again = torch.empty_like(T)
+        K.lora_down_multi([K.down_job(X, D, again, 0, M, Kd, X2=X2, r2=4)])
+    finally:
+        K.set_option("lora_down_mode", 0)
+    assert KC.rel(T, ref) < 1e-5 and torch.equal(T, again)
+    KC.no_outliers(T, ref, f"lora_down mode {mode}")
 
 
 def test_elementwise():
