@@ -44,6 +44,7 @@ def hot_path_tflop_per_image(res):
     cfg = json.load(open(os.path.join(ROOT, "configs", "fill50k.json")))
     return R.train_step_flops_per_image(res, cfg, 1.51 * (res / 512) ** 2)["total"] / 1e12
 MFMA_PEAK_TFLOPS = 2500.0                # dense fp16, MI355X_MICROARCH.md
+LEG_SECONDS = {}                         # wall time of each leg of the run (printed on stderr)
 # measured ceilings of this chip (stand-alone probes, profiles/r02_{mfma_rate,stream_rate}_probe.txt): reported beside `frac`,
 # never instead of it
 # (the stand-alone MFMA probe of round 2 -- 18.3 ns per 32x32x16 instruction = the guide's 32 cycles at ~1.75 GHz -- measured the clock the
@@ -96,7 +97,7 @@ def _pick_cpu_threads(unet, b):
     loses to a smaller pool on many-core hosts (oversubscribed SMT / NUMA).  One UNet forward per candidate, ~2-3 s each."""
     import os as _os
     hw = _os.cpu_count() or 1
-    cands = sorted({c for c in (hw, hw // 2, hw // 4, 32) if 1 <= c <= hw}, reverse=True)
+    cands = sorted({c for c in (hw // 2, hw // 4, hw // 8, 32, min(hw, 8)) if 1 <= c <= hw}, reverse=True)   # all `hw` threads lost 5x on the GPU hosts
     best, best_t = torch.get_num_threads(), None
     with torch.no_grad():
         for c in cands:
@@ -260,7 +261,7 @@ def rocprof_child_trace(args, steps=6, warmup=2):
     return res
 
 
-def rocprof_child_pmc(args, counter, steps=2, warmup=1):
+def rocprof_child_pmc(args, counter, steps=1, warmup=1):
     """One `rocprofv3 --pmc <counter>` pass over THIS command issued eagerly (counter collection serialises the kernels; a
     hipGraph replay is not instrumented per node), --kernel-trace / --stats only as gpurun requires: per-kernel
     [(grid, bytes)] lists, or {"error": ...}.  FETCH_SIZE and WRITE_SIZE need separate passes (TCC slots, MI355X_MICROARCH.md)."""
@@ -314,7 +315,7 @@ def measured_traffic(args, family):
         return None, {"error": "no kernel of the family in the PMC pass"}
     return round((fb * factor + wb) / n), {
         "static": False, "how": "two rocprofv3 --pmc child passes of this command (FETCH_SIZE, WRITE_SIZE; eager step, "
-                                "3 steps each), L2<->fabric bytes per launch = FETCH_SIZE x correction + WRITE_SIZE",
+                                "2 steps each), L2<->fabric bytes per launch = FETCH_SIZE x correction + WRITE_SIZE",
         "fetch_correction": round(factor, 3), "calibration": "hint-encoder gn_fwd_partial reads B*H*W*32*2 bytes exactly once",
         "launches_in_pass": n, "fetch_bytes_per_launch": round(fb * factor / n), "write_bytes_per_launch": round(wb / n)}
 
@@ -428,6 +429,7 @@ def main():
 
     # secondary line of BASELINE.json's metric: 50-step DDIM latency, 512^2, 16 images, CFG 9.0 (UNet batch 32),
     # control batch 1 (the inference call pattern of apps/gradio_canny2image.py:66-92); replicas only, rank 0, N=1
+    _t_leg = time.perf_counter()
     ddim = None
     if world == 1 and rank == 0 and not args.no_ddim:
         from controllora_amd.pipeline import ddim_sample
@@ -450,6 +452,7 @@ def main():
     # informational third line: the WHOLE reference step (train...:751-796) -- VAE encode x0.18215, noise / timesteps /
     # add_noise, CLIP text encode (stock transformers model: frozen glue outside the hot path), then the captured hot
     # path -- so the cost of what SURVEY section 8f ranks "next" is visible beside the headline number.  N=1, rank 0.
+    LEG_SECONDS['ddim50'] = time.perf_counter() - _t_leg; _t_leg = time.perf_counter()
     full = None
     if world == 1 and rank == 0 and graphed and not args.no_full_step:
         from controllora_amd import loading, text
@@ -484,17 +487,24 @@ def main():
 
     # (the roofline leg runs AFTER the secondary timings: its rocprofv3 --pmc child passes were followed by a 10 % slower DDIM line
     # on the same box -- counter collection leaves the device in a profiling power state for a while)
+    LEG_SECONDS['full_step'] = time.perf_counter() - _t_leg; _t_leg = time.perf_counter()
     roofline = None
     if not args.no_roofline and rank != 0:
-        eager_step()                           # the profiled step contains the all-reduce: every rank takes part
+        eager_step()                           # the warm-up and the profiled step contain the all-reduce: every rank takes part in both
+        eager_step()
     if not args.no_roofline and rank == 0:
         # (1) algorithmic flops / bytes per launch family + HIP-event durations of ONE eager step (events on the launch stream)
+        eager_step()                           # untimed: the secondary legs above emptied the allocator cache, and the first eager step
+        torch.cuda.synchronize()               # after that pays hipMalloc stalls inside whatever launch follows them
         K.PROFILER = K.KernelProfiler()
         eager_step()
         agg = K.PROFILER.summary()
         K.PROFILER = None
         ev_total_ms = sum(a["ms"] for a in agg.values())
-        dom_name, dom = max(agg.items(), key=lambda kv: kv[1]["ms"])
+        # the roofline object is about the GEMM / conv family (clora_gemm_f16_ex: 5.67 of the step's 7.24 algorithmic TFLOP): named, not
+        # picked by event time -- a one-off stall in a small family must not redirect it
+        dom_name = "clora_gemm_f16_ex" if "clora_gemm_f16_ex" in agg else max(agg.items(), key=lambda kv: kv[1]["ms"])[0]
+        dom = agg[dom_name]
         fam = {k: {"calls": v["calls"], "event_ms": round(v["ms"], 3),
                    "event_TFLOPs": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["flops"] else None}
                for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])[:8]}
@@ -550,11 +560,14 @@ def main():
                         images_per_s / world * hot_path_tflop_per_image(args.res) / MFMA_PEAK_TFLOPS, 4),
                     "whole_step_algorithmic_TFLOPs": round(images_per_s / world * hot_path_tflop_per_image(args.res), 1)}
 
+    LEG_SECONDS['roofline(trace+pmc children)'] = time.perf_counter() - _t_leg; _t_leg = time.perf_counter()
     cpu = None
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
         cpu = cpu_baseline(full=args.cpu_baseline_full)
 
+    LEG_SECONDS['cpu_baseline'] = time.perf_counter() - _t_leg
     if rank == 0:
+        print("bench legs (s):", {k: round(v, 1) for k, v in LEG_SECONDS.items()}, file=sys.stderr)
         print(json.dumps({
             "metric": "train images/sec SD-1.5+ControlLoRA 512^2 bs4/GPU", "value": round(images_per_s, 3),
             "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
