@@ -30,19 +30,21 @@ struct DownJobs {
 // shorter dependent load chain for what is a pure latency problem at those sizes.
 // G = k-steps whose loads are in flight together (4 KB of X per wave at G = 4).  Bytes in flight are what bounds this kernel: at
 // M = 16384 the non-split form has ONE block per CU = 16 KB in flight per CU = 2.6 TB/s by Little's law, exactly what it measured.
-template <bool KSPLIT, int G = 4>
-__global__ __launch_bounds__(256) void lora_down_kernel(DownJobs jobs) {
+// NW = waves per block (KSPLIT: the waves of a block share one 16-row group and split K NW ways -- 16 at the 16x16 / 8x8 levels,
+// where 64 / 16 row groups are all the parallelism M offers and a wave's K chain is the whole launch).
+template <bool KSPLIT, int G = 4, int NW = 4>
+__global__ __launch_bounds__(NW * 64) void lora_down_kernel(DownJobs jobs) {
     const clora_lora_down_job_t& p = jobs.j[blockIdx.y];
     const half_t* X = (const half_t*)p.X;
     const float* __restrict__ D = p.D;
     float* __restrict__ T = p.T;
     const int ldx = p.ldx, ldd = p.ldd, ldt = p.ldt, toff = p.toff, M = p.M, K = p.K, R = p.R;
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63, g = l >> 4, li = l & 15;
-    const int m0 = KSPLIT ? blockIdx.x * 16 : (blockIdx.x * 4 + w) * 16;
+    const int m0 = KSPLIT ? blockIdx.x * 16 : (blockIdx.x * NW + w) * 16;
     if (m0 >= M) return;                                    // jobs of one launch may differ in M (block/wave-uniform exit)
     int kbeg = 0, kend = K;
     if (KSPLIT) {
-        const int per = ((K + 31) / 32 + 3) / 4 * 32;
+        const int per = ((K + 31) / 32 + NW - 1) / NW * 32;
         kbeg = w * per;
         kend = (kbeg + per < K) ? kbeg + per : K;
     }
@@ -98,13 +100,13 @@ __global__ __launch_bounds__(256) void lora_down_kernel(DownJobs jobs) {
         }
     }
     }
-    if (KSPLIT) {                                           // fold the four K-quarters (fixed order) into wave 0
-        __shared__ floatx4 part[3][64];
+    if (KSPLIT) {                                           // fold the NW K-slices (fixed order) into wave 0
+        __shared__ floatx4 part[NW - 1][64];
         if (w > 0) part[w - 1][l] = acc;
         __syncthreads();
         if (w > 0) return;
 #pragma unroll
-        for (int q = 0; q < 3; ++q) {
+        for (int q = 0; q < NW - 1; ++q) {
             const floatx4 o = part[q][l];
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[r] += o[r];
@@ -347,10 +349,15 @@ extern "C" int clora_lora_down_multi_f16(const clora_lora_down_job_t* jobs, int 
         if (j.M > maxM) maxM = j.M;
     }
     // option "lora_down_mode": 0 = K-split up to 4096 rows, one wave per 16 rows x all of K above (round-1/2 behaviour);
-    // 1 = K-split at every size (4x the waves, each a quarter of K: more bytes in flight per CU at M = 16384);
+    // 1 (default) = K-split at every size (4x the waves, each a quarter of K: more bytes in flight per CU at M = 16384: 11.8 -> 9.5 us
+    //     for the stacked q|k|v job, bench line -0.13 ms, profiles/r03_lora_down_ab.txt) and sixteen waves per row group up to 1024 rows;
     // 2 = as 0 with eight k-steps in flight per wave above 4096 rows
     const int mode = clora_option(CLORA_OPT_LORA_DOWN_MODE);
-    if (maxM <= 4096 || mode == 1)
+    int maxK = 0;
+    for (int i = 0; i < njobs; ++i) if (jobs[i].K > maxK) maxK = jobs[i].K;
+    if (mode == 1 && maxM <= 1024 && maxK >= 1024)          // 64 / 16 row groups: sixteen waves split K (each >= 64 of it)
+        hipLaunchKernelGGL((lora_down_kernel<true, 4, 16>), dim3(clora_cdiv(maxM, 16), njobs), dim3(1024), 0, (hipStream_t)stream, dj);
+    else if (maxM <= 4096 || mode == 1)
         hipLaunchKernelGGL((lora_down_kernel<true, 4>), dim3(clora_cdiv(maxM, 16), njobs), dim3(256), 0, (hipStream_t)stream, dj);
     else if (mode == 2)
         hipLaunchKernelGGL((lora_down_kernel<false, 8>), dim3(clora_cdiv(maxM, 64), njobs), dim3(256), 0, (hipStream_t)stream, dj);

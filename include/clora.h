@@ -124,8 +124,9 @@ int clora_conv_patch_eligible(int M, const clora_conv_t* conv, int tile_cfg);
  *   "epi_two_phase"   1 = the 8-wave GEMM tiles request every T row / residual chunk of a thread before using the first (default),
  *                     0 = one chunk at a time.
  *   "gn_unroll"       1 = the GroupNorm passes keep twice as many rows in flight per thread (8 forward, 4 backward); same bits.
- *   "lora_down_mode"  how clora_lora_down[_multi]_f16 spreads a job: 0 = four waves split K up to 4096 rows, one wave per 16 rows above
- *                     (default); 1 = K-split at every size; 2 = as 0 with eight k-steps of loads in flight above 4096 rows.
+ *   "lora_down_mode"  how clora_lora_down[_multi]_f16 spreads a job: 0 = four waves split K up to 4096 rows, one wave per 16 rows above;
+ *                     1 = K-split at every size, sixteen waves per row group up to 1024 rows (default); 2 = as 0 with eight k-steps of
+ *                     loads in flight above 4096 rows.
  * Unknown names / values: CLORA_ERR_ARG. */
 int clora_set_option(const char* name, int value);
 

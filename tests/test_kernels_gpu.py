@@ -148,8 +148,12 @@ def test_lora(M, K, N, R, xr):
 def test_lora_down_launch_modes(mode):
     """option "lora_down_mode": how an adapter down-projection is spread over waves (K-split everywhere / eight k-steps in flight):
     same T within fp32 summation-order noise at the level-0 size, stacked q|k|v rows with a second input on the first adapter"""
+    for M, Kd in ((16384, 320), (1024, 1280), (200, 1288), (256, 2560)):
+        _lora_down_mode_case(mode, M, Kd)
+
+
+def _lora_down_mode_case(mode, M, Kd):
     g = torch.Generator().manual_seed(61)
-    M, Kd = 16384, 320
     X, X2 = KC.rnd((M, Kd), DEV, g), KC.rnd((M, Kd), DEV, g)
     D = KC.rnd((12, Kd), DEV, g, 0.25, dtype=torch.float32)
     ref = X.float() @ D.T
@@ -162,8 +166,8 @@ def test_lora_down_launch_modes(mode):
         K.lora_down_multi([K.down_job(X, D, again, 0, M, Kd, X2=X2, r2=4)])
     finally:
         K.set_option("lora_down_mode", 0)
-    assert KC.rel(T, ref) < 1e-5 and torch.equal(T, again)
-    KC.no_outliers(T, ref, f"lora_down mode {mode}")
+    assert KC.rel(T, ref) < 1e-5 and torch.equal(T, again), (mode, M, Kd, KC.rel(T, ref))
+    KC.no_outliers(T, ref, f"lora_down mode {mode} M={M} K={Kd}")
 
 
 def test_elementwise():
