@@ -45,7 +45,7 @@ def test_gemm_tile_configs(tile):
     KC.case_conv("cpu", 1, 8, 8, 16, 24, tile_cfg=tile)
 
 
-@pytest.mark.parametrize("tile", [3, 21, 23, 51, 52, 53, 54, 55, 56, 57, 58])
+@pytest.mark.parametrize("tile", [1, 3, 4, 5, 6, 7, 21, 23, 43, 51, 52, 53, 54, 55, 56, 57, 58])
 def test_gemm_epilogue_without_rowadd(tile):
     """projection epilogues (adapter / bias / residual, no row add): the two-phase chunk loop of the 8-wave tiles, ragged M and N"""
     KC.case_gemm_epilogue_no_rowadd("cpu", M=300, N=320, K_=128, tile_cfg=tile)

@@ -76,7 +76,7 @@ def test_conv_patch_kernel_row_segments_vae_shapes(tile, Bn, H, W, Ci, Co):
     KC.case_conv_patch(DEV, Bn, H, W, Ci, Co, tile, fwd_only=True)
 
 
-@pytest.mark.parametrize("tile", [0, 3, 21, 23, 43, 51, 52, 53, 54, 55, 56, 57, 58])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7, 8, 21, 22, 23, 26, 31, 32, 33, 41, 42, 43, 51, 52, 53, 54, 55, 56, 57, 58])
 def test_gemm_epilogue_without_rowadd(tile):
     """projection epilogues at real shapes (M = 16384 x N = 320 / 960, ragged variants): two-phase chunk loop of the 8-wave tiles"""
     KC.case_gemm_epilogue_no_rowadd(DEV, M=16384, N=320, K_=320, tile_cfg=tile)
