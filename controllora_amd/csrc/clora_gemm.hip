@@ -859,7 +859,12 @@ __global__ __launch_bounds__(WM * WN * 64, (DmaOcc<BM, BN, NST, BK, WM * WN>::v)
                 for (int j = 0; j < FN; ++j) acc[i][j] = mfma16(af[ks][i], bf[ks][j], acc[i][j]);
     }
     CLORA_WAIT_VMCNT(0);                                       // trailing zero-page stages: LDS is reused below
-    dma_epilogue<BM, BN, WM, WN, NT, SMEM, (DmaOcc<BM, BN, NST, BK, NW>::v <= 2)>(p, acc, m0, n0, split, smem, t);
+    // HOIST (U / bias of a thread's column in registers for the whole tile) only on the 8-wave tiles = ONE block per CU.  Round 2 had it
+    // on every kernel built for <= 2 blocks per CU; the strict epilogue test of round 3 (no element off by more than a few ulps, two
+    // launches bit-identical) caught those variants -- 128x64 BK64 at 2 blocks per CU, and the 64x64 experiment at 3 -- producing a handful
+    // of wrong elements per launch at M = 16384, N = K = 320 on hardware, sporadically; the one-block-per-CU kernels and the
+    // non-hoisted epilogue are clean and bit-stable (profiles/r03_epi_diag*.txt, r03_gputest_11.log).  Cause not established.
+    dma_epilogue<BM, BN, WM, WN, NT, SMEM, (NW > 4)>(p, acc, m0, n0, split, smem, t);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -201,6 +201,10 @@ def full_size_properties(dev, config_name="fill50k.json", res=512, batch=4):
         p_unet.set_attn_processor(M.map_processors_to_unet(p_unet, p_clora))
         p_clora(g16("guide"))
         pred4 = p_unet(noisy, ts, g16("ehs")).sample.clone()
+        # run-to-run: the same forward twice must give the same bits (every forward kernel is atomics-free; a sporadic
+        # wrong element in one launch -- seen in round 3 with an epilogue variant -- shows up here at the real shapes)
+        out["forward_bit_stable"] = bool(torch.equal(pred4, p_unet(noisy, ts, g16("ehs")).sample)) and \
+            bool(torch.equal(pred4, p_unet(noisy, ts, g16("ehs")).sample))
         errs = []
         for i in range(batch):
             p_clora(g16("guide")[i:i + 1])
