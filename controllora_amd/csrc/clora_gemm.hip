@@ -412,8 +412,8 @@ __device__ __forceinline__ void dma_epilogue(const GemmArgs& p, floatx4 (&acc)[B
     // live in registers for the whole tile -- per output chunk only the 16-byte T row is fetched.  (Fetching U per chunk made the
     // epilogue's L1 traffic as long as a 5-step main loop: 8 x 16-byte loads per chunk.)
     // (Staging U in LDS for the other kernels instead was measured too: 24.24 -> 24.30 ms/step, not kept.)
-    // HOIST: only the kernels built for <= 2 blocks per CU have the 40 registers to spare (the others spilled accumulators: measured
-    // +0.6 ms per train step), and a thread must own >= 4 output chunks for the hoist to amortise (2 on the 64x64 tile)
+    // HOIST: only the 8-wave tiles (one block per CU: registers to spare, and see the note at the call site about the variants with
+    // more than one block per CU), and a thread must own >= 4 output chunks for the hoist to amortise (2 on the 64x64 tile)
     constexpr bool HOIST_PAYS = HOIST && (BM * CPR / NT) >= 4 && (BM / WM / 16) * (BN / WN / 16) * 4 < 128;
     // the two-phase chunk loop (below) only where the register file has the room: the 8-wave tiles up to 128 rows (64x320, 128x320,
     // 128x256: one block per CU, 256 VGPRs per wave); the 256-row tiles and the 2-blocks-per-CU kernels would spill
