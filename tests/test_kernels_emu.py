@@ -210,3 +210,15 @@ def test_conv_channel_chunk_major_k_order(tile):
     KC.case_conv("cpu", 1, 5, 5, 32, 32, tile_cfg=tile, kchunk=16)
     for kw in (dict(stride=2, pad=1), dict(asym=True, stride=2, pad=0), dict(ups=True)):
         KC.case_conv("cpu", 1, 6, 6, 64, 64, tile_cfg=tile, kchunk=64, **kw)
+
+
+@pytest.mark.parametrize("family", ["attention", "groupnorm", "layernorm", "lora_up", "lora_wgrad", "conv_patch", "conv_patch_splitk"])
+def test_kernels_are_bit_stable_run_to_run(family):
+    """the body of the GPU test of the same name at small sizes (host logic of the check; the emulator is deterministic by construction)"""
+    import tests.test_kernels_gpu as TG
+    old = TG.DEV
+    TG.DEV = "cpu"
+    try:
+        TG.test_kernels_are_bit_stable_run_to_run(family)
+    finally:
+        TG.DEV = old

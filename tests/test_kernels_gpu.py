@@ -209,3 +209,68 @@ def test_conv_channel_chunk_major_k_order(tile):
     KC.case_conv(DEV, 1, 16, 16, 1280, 1280, tile_cfg=tile, kchunk=64)
     for kw in (dict(stride=2, pad=1), dict(asym=True, stride=2, pad=0), dict(ups=True)):
         KC.case_conv(DEV, 1, 16, 16, 128, 64, tile_cfg=tile, kchunk=64, **kw)
+
+
+@pytest.mark.parametrize("family", ["attention", "groupnorm", "layernorm", "lora_up", "lora_wgrad", "conv_patch", "conv_patch_splitk"])
+def test_kernels_are_bit_stable_run_to_run(family):
+    """Two identical launches must give identical bits at the level-0 shapes of the step (every kernel here is atomics-free by
+    design): the guard that caught a sporadically wrong GEMM epilogue variant in round 3, extended to the other kernel families."""
+    import math
+    g = torch.Generator().manual_seed(71)
+    f32 = torch.float32
+    big = DEV == "cuda"                       # (the CPU harness in tests/test_kernels_emu.py drives the same body at small sizes)
+    if family == "attention":
+        B, H, N, D = (2, 8, 4096, 40) if big else (1, 2, 200, 40)
+        qkv, dO = KC.rnd((B * N, 3 * H * D), DEV, g), KC.rnd((B * N, H * D), DEV, g)
+        q, k, v = qkv[:, :H * D], qkv[:, H * D:2 * H * D], qkv[:, 2 * H * D:]
+
+        def run():
+            o, lse = K.attn_fwd(q, k, v, B, H, N, N, D, D ** -0.5)
+            d = torch.empty_like(qkv)
+            K.attn_bwd(q, k, v, o, dO, lse, B, H, N, N, D, D ** -0.5, d[:, :H * D], d[:, H * D:2 * H * D], d[:, 2 * H * D:])
+            return o, lse, d
+    elif family == "groupnorm":
+        x, dy, dres = (KC.rnd((4, 4096, 320) if big else (2, 60, 320), DEV, g) for _ in range(3))
+        gamma, beta = KC.rnd((320,), DEV, g, dtype=f32), KC.rnd((320,), DEV, g, dtype=f32)
+
+        def run():
+            y, st = K.groupnorm_fwd(x, gamma, beta, 32, 1e-5, True)
+            dx, _, _ = K.groupnorm_bwd(x, dy, gamma, beta, st, 32, True, dres=dres)
+            return y, st, dx
+    elif family == "layernorm":
+        x, dy, dres = (KC.rnd((16384 if big else 70, 320), DEV, g) for _ in range(3))
+        gamma, beta = KC.rnd((320,), DEV, g, dtype=f32), KC.rnd((320,), DEV, g, dtype=f32)
+
+        def run():
+            return K.layernorm_fwd(x, gamma, beta, 1e-5), K.layernorm_bwd(x, dy, gamma, 1e-5, dres=dres)
+    elif family == "lora_up":
+        M, N = (16384 if big else 200), 320
+        base, T, U = KC.rnd((M, N), DEV, g), KC.rnd((M, 4), DEV, g, dtype=f32), KC.rnd((N, 4), DEV, g, dtype=f32)
+
+        def run():
+            return (K.lora_up(base, T, 0, U, M, N, 0.7),)
+    elif family == "lora_wgrad":
+        M, N = (16384 if big else 300), 320
+        A, T = KC.rnd((M, N), DEV, g), KC.rnd((M, 4), DEV, g, dtype=f32)
+
+        def run():
+            G = torch.zeros((N, 4), dtype=f32, device=DEV)
+            K.lora_wgrad(A, T, 0, G, 4, 1, M, N, 4, scale=0.5)
+            return (G,)
+    else:
+        from controllora_amd.ops import conv_k_order
+        Bn, Hh, Ci, Co = (4, 64, 320, 320) if big else (1, 16, 128, 160)
+        M = Bn * Hh * Hh
+        x = KC.rnd((M, Ci), DEV, g)
+        w = conv_k_order(KC.rnd((Co, 9, Ci), DEV, g, 1 / math.sqrt(9 * Ci)), 64)
+        res = KC.rnd((M, Co), DEV, g)
+        cd, _, _ = K.conv_fwd_desc(Hh, Hh, Ci, 3, 1, 1, kchunk=64)
+        sk = 2 if family == "conv_patch_splitk" else 1
+
+        def run():
+            return (K.gemm(x, w, M, Co, 9 * Ci, conv=cd, residual=res, tile_cfg=76, split_k=sk, _tuned=False),)
+    a, b = run(), run()
+    torch.cuda.synchronize() if DEV == "cuda" else None
+    for u, v_ in zip(a, b):
+        assert torch.equal(u, v_), f"{family}: two identical launches differ in {int((u != v_).sum())} elements"
+        assert bool(torch.isfinite(u.float()).all())
