@@ -89,3 +89,26 @@ def test_ddim_text_kv_cache_is_exact():
     assert torch.equal(a, b)
     kv_rows = 2 * cases.CTX_LEN                         # CFG batch 2 x text length: the K/V projections' row count
     assert sum(1 for m in calls if m == kv_rows) == 16  # 16 cross-attention sites, projected once for all 3 steps
+
+
+def test_pipeline_prompt_to_image_on_the_emulator():
+    """reference apps/gradio_canny2image.py:66-92 end to end on the small random model with the kernels emulated: CLIP text encode
+    (controllora_amd/clip.py), hint encode, CFG DDIM loop, VAE decode; one guide broadcast over the samples, one guide per image
+    (tiled like the CFG batch), and a guide batch with no defined pairing is rejected."""
+    from controllora_amd import models as M
+    from controllora_amd.pipeline import ControlLoRAPipeline
+    from oracle import cases
+    torch.manual_seed(0)
+    clora = M.ControlLoRA(**cases.SMALL_CLORA_V1)
+    with torch.no_grad():                                  # fresh adapters have zero `up` matrices: the guide would have no effect
+        for n, p_ in clora.named_parameters():
+            if n.endswith(".up.weight"):
+                p_.normal_(0.0, 0.2)
+    pipe = ControlLoRAPipeline.from_pretrained("random:small", clora, "cpu")
+    guide = torch.rand(2, 3, 64, 64) * 2 - 1
+    a = pipe("red circle", guide[:1], num_samples=2, ddim_steps=2, scale=5.0, seed=5)
+    assert a.shape == (2, 64, 64, 3) and a.dtype == torch.uint8
+    b = pipe("red circle", guide, num_samples=2, ddim_steps=2, scale=5.0, seed=5)          # one guide per image
+    assert b.shape == a.shape and torch.equal(a[0], b[0]) and not torch.equal(a[1], b[1])   # image 0 sees the same guide both times
+    with pytest.raises(ValueError):
+        pipe("red circle", torch.rand(3, 3, 64, 64), num_samples=2, ddim_steps=2, seed=5)
