@@ -274,3 +274,37 @@ def test_kernels_are_bit_stable_run_to_run(family):
     for u, v_ in zip(a, b):
         assert torch.equal(u, v_), f"{family}: two identical launches differ in {int((u != v_).sum())} elements"
         assert bool(torch.isfinite(u.float()).all())
+
+
+def test_every_plain_entry_of_the_tuned_table_is_exact_and_bit_stable():
+    """The autotuned launch table (controllora_amd/gemm_tuning_gfx950.json) entry by entry, for the plain (non-conv) signatures of the
+    train step and the batch-32 inference forward: each (shape, tile_cfg, split_k) with a bias + rank-4 adapter + residual epilogue
+    against an fp32 matmul -- rel-L2, no outlier element, and two identical launches bit-identical (the guard that caught tile_cfg 42)."""
+    import json
+    import math
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(K.__file__)), "gemm_tuning_gfx950.json")
+    table = json.load(open(path))["table"]
+    g = torch.Generator().manual_seed(81)
+    done = 0
+    for key, (tile, sk) in sorted(table.items()):
+        if ":" in key:
+            continue
+        M, N, Kd = (int(v) for v in key.split("x"))
+        if M * N * Kd > 6e10 or M * N > 3.4e7 or N % 16 or M < 16:        # keep the whole sweep to seconds; the big ones share their kernels
+            continue
+        A, B = KC.rnd((M, Kd), DEV, g), KC.rnd((N, Kd), DEV, g, 1 / math.sqrt(Kd))
+        bias, res = KC.rnd((N,), DEV, g, dtype=torch.float32), KC.rnd((M, N), DEV, g)
+        T, U = KC.rnd((M, 4), DEV, g, dtype=torch.float32), KC.rnd((N, 4), DEV, g, 0.3, dtype=torch.float32)
+        ref = ((A.float() @ B.float().T) + bias + T @ U.T).half().float() + res.float()
+        kw = dict(bias=bias, residual=res, lora_t=T, lora_u=U, lora_seg=N, tile_cfg=tile, split_k=sk, _tuned=False)
+        out = K.gemm(A, B, M, N, Kd, **kw)
+        again = K.gemm(A, B, M, N, Kd, **kw)
+        e = float((out.float() - ref).norm() / ref.norm())
+        assert e < 8e-4, (key, tile, sk, e)
+        assert torch.equal(out, again), (key, tile, sk, "two identical launches differ")
+        lim = 6e-3 * max(1.0, float(ref.abs().max()))
+        worst = float((out.float() - ref).abs().max())
+        assert worst < lim, (key, tile, sk, worst, lim)
+        done += 1
+    assert done >= 60, done
