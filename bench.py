@@ -337,6 +337,10 @@ def main():
     ap.add_argument("--no-full-step", action="store_true", help="skip the secondary 'whole reference step' line (VAE + CLIP inside)")
     ap.add_argument("--backend", default="nccl", help='torch.distributed backend ("nccl" is RCCL on ROCm; "gloo" only for '
                     "exercising the N>1 control flow on a box with fewer GPUs than ranks)")
+    ap.add_argument("--comm", default=os.environ.get("CLORA_COMM", "torch"), choices=["torch", "clora"],
+                    help='exchange path of the data-parallel step: "torch" = torch.distributed.all_reduce on the process group, '
+                         '"clora" = the C ABI\'s own RCCL communicator (clora_comm_init / clora_allreduce_flat_f32); same '
+                         'ncclAllReduce either way (also: CLORA_COMM)')
     ap.add_argument("--dry-run", action="store_true", help="with --backend gloo: exercise the multi-rank control flow (spawn, "
                     "rendezvous, flat all-reduce, rank-0 line) without touching a GPU")
     ap.add_argument("--trace-child", action="store_true", help=argparse.SUPPRESS)    # run by rocprof_child_trace()
@@ -375,7 +379,8 @@ def main():
     from controllora_amd.train import ControlLoRATrainer
 
     unet, clora = build_models(dev, config=args.config)
-    trainer = ControlLoRATrainer(unet, clora, process_group=pg, world_size=world)
+    comm = args.comm if not (args.backend != "nccl" and world > 1) else "torch"      # gloo ranks (CPU dry runs) have no RCCL
+    trainer = ControlLoRATrainer(unet, clora, process_group=pg, world_size=world, comm=comm)
     batch = synthetic_batch(args.batch, args.res, dev, 42 + rank)         # data-parallel: different samples per rank
     noisy = DDPMScheduler().add_noise(batch["latents"], batch["noise"], batch["timesteps"]).half()
 
@@ -413,16 +418,17 @@ def main():
     allreduce_ms = None
     if world > 1:                                  # the exchange step on its own: 10 flat-buffer all-reduces, HIP events
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        scratch = torch.zeros_like(trainer.flat.grad)
-        torch.distributed.all_reduce(scratch, group=pg)
+        keep = trainer.flat.grad.clone()           # through the trainer's own exchange path (torch process group or the C ABI)
+        trainer._all_reduce_grads()
         torch.cuda.synchronize()
         e0.record()
         for _ in range(10):
-            torch.distributed.all_reduce(scratch, group=pg)
+            trainer._all_reduce_grads()
         e1.record()
         torch.cuda.synchronize()
         allreduce_ms = round(e0.elapsed_time(e1) / 10, 4)
-        del scratch
+        trainer.flat.grad.copy_(keep)
+        del keep
 
     if args.trace_child:
         return
@@ -578,10 +584,12 @@ def main():
                                    f"latents/text embeddings synthetic (VAE/CLIP outside the hot path)",
                        "global_batch": args.batch * world, "parallelism": f"dp{world}", "hipgraph": graphed,
                        "allreduce_bytes": trainer.flat.numel * 4,
-                       "rccl_ranks": torch.distributed.get_world_size() if world > 1 else 1,
-                       "allreduce_ms": allreduce_ms},
+                       "rccl_ranks": trainer.comm_ranks(), "comm": trainer.comm,
+                       "allreduce_ms": allreduce_ms,
+                       "multi_gpu_note": "N > 1 is measured by the driver's scaling run only (gpurun exposes one GPU)"},
             "loss": round(loss, 5), "steps_skipped_by_scaler": skipped,
             "roofline": roofline, "ddim50": ddim, "full_step_with_vae_clip": full, "cpu_baseline": cpu}))
+    trainer.close()
     if world > 1:
         torch.distributed.destroy_process_group()
 

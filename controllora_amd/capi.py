@@ -36,7 +36,15 @@ class Epilogue(C.Structure):
     _fields_ = [("bias", C.c_void_p), ("rowadd", C.c_void_p), ("rows_per_batch", C.c_int), ("ld_rowadd", C.c_int),
                 ("residual", C.c_void_p), ("ldr", C.c_int), ("lora_t", C.c_void_p), ("ldt", C.c_int),
                 ("lora_u", C.c_void_p), ("ldu", C.c_int), ("lora_u_tr", C.c_int), ("lora_r", C.c_int), ("lora_seg", C.c_int), ("lora_scale", C.c_float),
-                ("geglu", C.c_int), ("geglu_f", C.c_int), ("geglu_h", C.c_void_p), ("geglu_y", C.c_void_p)]
+                ("geglu", C.c_int), ("geglu_f", C.c_int), ("geglu_h", C.c_void_p), ("geglu_y", C.c_void_p),
+                ("lora_dpack", C.c_void_p), ("lora_t_in", C.c_void_p), ("ldt_in", C.c_int), ("lora_t_in_rows", C.c_int),
+                ("lora_t_in_mask", C.c_uint)]
+
+
+class LoraPackJob(C.Structure):
+    """mirror of clora_lora_pack_job_t"""
+    _fields_ = [("D", C.c_void_p), ("out", C.c_void_p), ("ldd", C.c_int), ("R", C.c_int), ("K", C.c_int), ("kmajor", C.c_int),
+                ("scale", C.c_float), ("pad_", C.c_int)]
 
 
 class LoraDownJob(C.Structure):
@@ -84,12 +92,14 @@ _PROTOS = {
     "clora_lora_down_f16": [_P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P],
     "clora_lora_down_multi_f16": [C.POINTER(LoraDownJob), _I, _P],
     "clora_lora_wgrad_multi_f16": [C.POINTER(LoraWgradJob), _I, _P, _Z, _P],
+    "clora_lora_pack_f16": [_P, _I, _I, _P],
     "clora_lora_up_f16": [_P, _I, _P, _I, _I, _P, _I, _I, _P, _I, _I, _I, _I, _F, _P],
     "clora_lora_up_multi_f16": [C.POINTER(LoraUpJob), _I, _P],
     "clora_lora_wgrad_f16": [_P, _I, _P, _I, _I, _P, _I, _I, _I, _I, _I, _F, _I, _P, _Z, _P],
     "clora_comm_unique_id": [_P],
     "clora_comm_init": [_P, _I, _I],
     "clora_comm_world": [],
+    "clora_comm_rank": [],
     "clora_allreduce_flat_f32": [_P, _Z, _P],
     "clora_comm_destroy": [],
     "clora_add_f16": [_P, _P, _P, _Z, _P],
@@ -136,15 +146,21 @@ class Lib:
     _ENV_OPTIONS = {"CLORA_TILE_ORDER": ("tile_order", {"m": 0, "n": 1, "auto": 2, "a": 2}), "CLORA_LN_ROWS": ("ln_rows", None),
                     "CLORA_ATTN_FWD_WAVES": ("attn_fwd_waves", None), "CLORA_ATTN_BWD_WAVES": ("attn_bwd_waves", None),
                     "CLORA_GN_BLOCKS": ("gn_blocks", None), "CLORA_EPI_TWO_PHASE": ("epi_two_phase", None),
-                    "CLORA_LORA_DOWN_MODE": ("lora_down_mode", None), "CLORA_GN_UNROLL": ("gn_unroll", None)}
+                    "CLORA_LORA_DOWN_MODE": ("lora_down_mode", None), "CLORA_GN_UNROLL": ("gn_unroll", None),
+                    "CLORA_EPI_HOIST": ("epi_hoist", None)}
 
     def _options_from_env(self):
         for var, (name, names) in self._ENV_OPTIONS.items():
             v = os.environ.get(var)
             if v is None or v == "":
                 continue
-            val = names[v] if (names and v in names) else int(v)
-            self.call("clora_set_option", name.encode(), val)
+            try:
+                val = names[v] if (names and v in names) else int(v)
+                self.call("clora_set_option", name.encode(), val)
+            except (ValueError, CloraError) as e:
+                allowed = f"one of {sorted(names)} or an integer" if names else "an integer in the range include/clora.h documents"
+                raise CloraError(f"environment variable {var}={v!r} is not a valid value for the library option "
+                                 f"{name!r} (expected {allowed})") from e
 
     def call(self, name: str, *args) -> None:
         rc = getattr(self.cdll, name)(*args)

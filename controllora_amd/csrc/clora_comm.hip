@@ -76,6 +76,7 @@ extern "C" int clora_comm_init(const void* id128, int rank, int world) {
 }
 
 extern "C" int clora_comm_world(void) { return g_rccl.comm ? g_rccl.world : 0; }
+extern "C" int clora_comm_rank(void) { return g_rccl.comm ? g_rccl.rank : -1; }
 
 extern "C" int clora_allreduce_flat_f32(float* buf, size_t n, void* stream) {
     if (!buf || n == 0) return CLORA_ERR_ARG;

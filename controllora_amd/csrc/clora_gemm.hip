@@ -29,6 +29,7 @@ struct GemmArgs {
     int k_per_split;
     int tiles_n;
     int two_phase;             // option "epi_two_phase" at launch time (A/B switch of the two-phase chunk loop)
+    int hoist_on;              // option "epi_hoist" at launch time (0: the one-chunk-at-a-time epilogue on the 8-wave tiles too)
     int tiles_m, n_major;      // n_major: logical tile t = n * tiles_m + m (else m * tiles_n + n); see pick_tile_order
     clora_conv_t conv;
     clora_epilogue_t epi;
@@ -369,9 +370,40 @@ __device__ __attribute__((aligned(16))) const unsigned g_clora_zero16[4] = {0u, 
 // Epilogue shared by the LDS-DMA main loops (gemm_dma_kernel, conv3x3_patch_kernel): split-K slab, or fp32 accumulators ->
 // LDS (64 rows per pass) -> per row-chunk: bias / time-embedding / rank-r adapter update (float4 operand loads) -> fp16 ->
 // + residual (or the fused GEGLU forms) -> 16-byte coalesced stores.  NT threads = WM x WN waves, wave tile FM x FN MFMA tiles.
-template <int BM, int BN, int WM, int WN, int NT, int SMEM, bool HOIST = false>
+// The rank-4 update of one 8-column chunk from registers: v[e] += sum_j t4[j] * u(e, j), with the up-matrix values of the thread's
+// column in `ureg` (TR: ureg[2j + (e >> 2)][e & 3], else ureg[e][j]).  CLORA_DIAG_SCALAR_FMA (diagnostic build): every multiply-add
+// is one explicit v_fma_f32, so the compiler cannot form v_pk_fma_f32 pairs here -- the experiment that separates "packed fp32
+// math in the hoisted epilogue" from everything else the hoist changes.
+template <bool TR>
+__device__ __forceinline__ void hoisted_rank4(float (&v)[8], const floatx4& t4, const floatx4 (&ureg)[8]) {
+#ifdef CLORA_DIAG_SCALAR_FMA
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float u = TR ? ureg[2 * j + (e >> 2)][e & 3] : ureg[e][j];
+            asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(v[e]) : "v"(t4[j]), "v"(u));
+        }
+#else
+    if (TR) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += t4[j] * ureg[2 * j + (e >> 2)][e & 3];
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += t4[0] * ureg[e][0] + t4[1] * ureg[e][1] + t4[2] * ureg[e][2] + t4[3] * ureg[e][3];
+    }
+#endif
+}
+
+// EXT > 0 (gemm_dma_kernel<..., EXT = 16>: the adapter down-projection rides in the main loop, clora_epilogue_t.lora_dpack): tacc
+// holds this wave's share of the tile's [BM x 16] extra columns (8 "hi" + 8 "lo" partial sums per row); they are staged in LDS
+// next to the accumulators, every chunk takes its T row from there (+ the optional lora_t_in part), and the first tile of a
+// column segment writes T to lora_t for the backward.
+template <int BM, int BN, int WM, int WN, int NT, int SMEM, bool HOIST = false, int EXT = 0>
 __device__ __forceinline__ void dma_epilogue(const GemmArgs& p, floatx4 (&acc)[BM / WM / 16][BN / WN / 16], int m0, int n0, int split,
-                                             half_t* smem, int t) {
+                                             half_t* smem, int t, const floatx4* tacc = nullptr) {
     constexpr int FM = BM / WM / 16, FN = BN / WN / 16;
     const int w = t >> 6, l = t & 63, g = l >> 4, li = l & 15;
     const int wm = w / WN, wn = w % WN;
@@ -404,6 +436,10 @@ __device__ __forceinline__ void dma_epilogue(const GemmArgs& p, floatx4 (&acc)[B
     constexpr int NPASS = BM / PR;
     static_assert(PR * F_LD * 2 <= SMEM, "fp32 staging must fit in the LDS allocation");
     float* Cf = reinterpret_cast<float*>(smem);
+    static_assert(EXT == 0 || (PR * F_LD + BM * 16) * 2 <= SMEM, "T staging must fit behind the accumulator staging");
+    static_assert(EXT == 0 || HOIST, "the in-launch adapter down-projection lives on the hoisted (8-wave) epilogue");
+    float* const Ts = Cf + PR * F_LD;                          // EXT: [BM][16] raw hi | lo sums, valid from pass 0 to the end
+    constexpr int TM = EXT > 0 ? (BM / WM / 16 + WN - 1) / WN : 0;
     constexpr int CPR = BN / 8;
     constexpr int RPIT = NT / CPR;                             // rows one sweep of the block covers (threads past RPIT*CPR idle: BN = 160 / 320)
     static_assert(RPIT >= 1, "tile wider than the block");
@@ -421,10 +457,15 @@ __device__ __forceinline__ void dma_epilogue(const GemmArgs& p, floatx4 (&acc)[B
     // produced a handful of wrong elements per launch on MI355X at M = 16384, N = K = 320 -- sporadic, different on every run, rows
     // 6 / 7 (mod 8) of a fragment, with the two-phase loop on AND off (profiles/r03_epi_diag.txt); the emulator and the 8-wave tiles
     // are clean.  Not understood (164 VGPRs at 3 blocks per CU; no spills), so the 64x64 tile keeps the one-chunk-at-a-time epilogue.
+#ifdef CLORA_SMALL2_ON
+    constexpr bool SMALL2 = BM == 64 && BN == 64 && NT == 256 && NPASS == 1 && SMEM >= 24576;   // diagnostic build: the round-3 experiment as it was
+#else
     constexpr bool SMALL2 = false;
+#endif
     constexpr bool FIXED_COL = HOIST_PAYS || SMALL2;           // thread -> one fixed chunk column, rows t / CPR + it * RPIT
+    static_assert(EXT == 0 || HOIST_PAYS, "EXT tiles take the fixed-column hoisted epilogue");
     constexpr bool TWO_PHASE = (HOIST_PAYS && NT == 512 && BM <= 128) || SMALL2;
-    const bool hoist = FIXED_COL && p.epi.lora_t != nullptr && p.epi.lora_r == 4 && p.epi.geglu == 0 && n < p.N &&
+    const bool hoist = FIXED_COL && (EXT > 0 || p.hoist_on) && p.epi.lora_t != nullptr && p.epi.lora_r == 4 && p.epi.geglu == 0 && n < p.N &&
                        ((p.epi.ldt | ((n / p.epi.lora_seg) * 4)) & 3) == 0 && (p.epi.lora_u_tr ? (p.epi.ldu & 3) == 0 : p.epi.ldu == 4);
     // `two`: this thread takes the two-phase chunk loop -- adapter launches it can hoist, and launches without an adapter
     // (proj_in / proj_out / FF2 and the dgrads: bias and / or residual only)
@@ -464,6 +505,18 @@ __device__ __forceinline__ void dma_epilogue(const GemmArgs& p, floatx4 (&acc)[B
                         Cf[(frow - ph * PR + 4 * g + r) * F_LD + wn * FN * 16 + j * 16 + li] = acc[i][j][r];
             }
         }
+        if constexpr (EXT > 0) {
+            if (ph == 0) {
+#pragma unroll
+                for (int q = 0; q < TM; ++q) {
+                    const int i = q * WN + wn;                 // the M fragment whose T columns this wave accumulated
+                    if (i < FM) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) Ts[(wrow0 + i * 16 + 4 * g + r) * 16 + li] = tacc[q][r];
+                    }
+                }
+            }
+        }
         __syncthreads();
         if (p.epi.geglu == 1) {
             // forward GEGLU: tile columns come in groups of [64 a | 64 g]; one thread takes an a-chunk and its g-chunk
@@ -498,6 +551,15 @@ __device__ __forceinline__ void dma_epilogue(const GemmArgs& p, floatx4 (&acc)[B
             }
             continue;
         }
+        // EXT: T row of tile row mt = hi + lo sums from LDS (+ the precomputed part), written to lora_t by the thread of chunk
+        // column 0 when this tile is the first of its column segment
+        const bool ext_in = EXT > 0 && p.epi.lora_t_in != nullptr && ((p.epi.lora_t_in_mask >> (n0 / p.epi.lora_seg)) & 1u);
+        const bool ext_store = EXT > 0 && (n0 % p.epi.lora_seg) == 0 && nc == 0;
+        auto ext_t4 = [&](int mt, floatx4 tin) -> floatx4 {
+            const floatx4 hi = *reinterpret_cast<const floatx4*>(Ts + mt * 16);
+            const floatx4 lo = *reinterpret_cast<const floatx4*>(Ts + mt * 16 + 8);
+            return hi + lo + tin;
+        };
         // one 8-column chunk of one staged row: bias / time embedding / adapter update -> fp16 -> + residual (or GEGLU') -> store
         auto chunk = [&](int ml, int nc, int n) {
             const int m = m0 + ph * PR + ml;
@@ -505,6 +567,9 @@ __device__ __forceinline__ void dma_epilogue(const GemmArgs& p, floatx4 (&acc)[B
                 const floatx4 f0 = *reinterpret_cast<const floatx4*>(Cf + ml * F_LD + nc * 8);
                 const floatx4 f1 = *reinterpret_cast<const floatx4*>(Cf + ml * F_LD + nc * 8 + 4);
                 float v[8] = {f0[0], f0[1], f0[2], f0[3], f1[0], f1[1], f1[2], f1[3]};
+#ifdef CLORA_DIAG_EPI_NOP
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 7\n\ts_nop 7" ::: "memory");   // diagnostic build: drain + idle slots after the LDS reads
+#endif
                 if (hoist) {
                     if (p.epi.bias) {
 #pragma unroll
@@ -515,17 +580,18 @@ __device__ __forceinline__ void dma_epilogue(const GemmArgs& p, floatx4 (&acc)[B
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] += (float)ra[e];
                     }
-                    floatx4 t4 = *reinterpret_cast<const floatx4*>(p.epi.lora_t + (size_t)m * p.epi.ldt + utoff);
-                    t4 *= p.epi.lora_scale;
-                    if (p.epi.lora_u_tr) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) v[e] += t4[j] * ureg[2 * j + (e >> 2)][e & 3];
+                    floatx4 t4;
+                    if constexpr (EXT > 0) {
+                        floatx4 tin = zero4f();
+                        if (ext_in) tin = *reinterpret_cast<const floatx4*>(p.epi.lora_t_in + (size_t)(p.epi.lora_t_in_rows > 0 ? m % p.epi.lora_t_in_rows : m) * p.epi.ldt_in + utoff);
+                        t4 = ext_t4(ph * PR + ml, tin);
+                        if (ext_store) *reinterpret_cast<floatx4*>(const_cast<float*>(p.epi.lora_t) + (size_t)m * p.epi.ldt + utoff) = t4;
                     } else {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] += t4[0] * ureg[e][0] + t4[1] * ureg[e][1] + t4[2] * ureg[e][2] + t4[3] * ureg[e][3];
+                        t4 = *reinterpret_cast<const floatx4*>(p.epi.lora_t + (size_t)m * p.epi.ldt + utoff);
                     }
+                    t4 *= p.epi.lora_scale;
+                    if (p.epi.lora_u_tr) hoisted_rank4<true>(v, t4, ureg);
+                    else hoisted_rank4<false>(v, t4, ureg);
                 } else {
                     epi_chunk8(v, m, n, p.epi);
                 }
@@ -575,7 +641,12 @@ __device__ __forceinline__ void dma_epilogue(const GemmArgs& p, floatx4 (&acc)[B
                     const int ml = t / CPR + it * RPIT, m = m0 + ph * PR + ml;
                     const int mc = (col_ok && ml < PR && m < p.M) ? m : m0;
                     // unconditional loads (an absent operand reads the 16-byte zero page): no branch between them, one batch
-                    const float* tp = hoist ? p.epi.lora_t + (size_t)mc * p.epi.ldt + utoff : reinterpret_cast<const float*>(g_clora_zero16);
+                    const float* tp;
+                    if constexpr (EXT > 0)
+                        tp = ext_in ? p.epi.lora_t_in + (size_t)(p.epi.lora_t_in_rows > 0 ? mc % p.epi.lora_t_in_rows : mc) * p.epi.ldt_in + utoff
+                                    : reinterpret_cast<const float*>(g_clora_zero16);
+                    else
+                        tp = hoist ? p.epi.lora_t + (size_t)mc * p.epi.ldt + utoff : reinterpret_cast<const float*>(g_clora_zero16);
                     const half_t* rp = has_res ? (const half_t*)p.epi.residual + (size_t)mc * p.epi.ldr + n
                                                : reinterpret_cast<const half_t*>(g_clora_zero16);
                     t4s[it] = *reinterpret_cast<const floatx4*>(tp);
@@ -595,21 +666,22 @@ __device__ __forceinline__ void dma_epilogue(const GemmArgs& p, floatx4 (&acc)[B
                         const floatx4 f0 = *reinterpret_cast<const floatx4*>(Cf + ml * F_LD + nc * 8);
                         const floatx4 f1 = *reinterpret_cast<const floatx4*>(Cf + ml * F_LD + nc * 8 + 4);
                         float v[8] = {f0[0], f0[1], f0[2], f0[3], f1[0], f1[1], f1[2], f1[3]};
+#ifdef CLORA_DIAG_EPI_NOP
+                        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 7\n\ts_nop 7" ::: "memory");
+#endif
                         if (p.epi.bias) {
 #pragma unroll
                             for (int e = 0; e < 8; ++e) v[e] += bias8[e];
                         }
                         if (hoist) {
-                            const floatx4 t4 = t4s[it] * p.epi.lora_scale;
-                            if (p.epi.lora_u_tr) {
-#pragma unroll
-                                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                                    for (int e = 0; e < 8; ++e) v[e] += t4[j] * ureg[2 * j + (e >> 2)][e & 3];
-                            } else {
-#pragma unroll
-                                for (int e = 0; e < 8; ++e) v[e] += t4[0] * ureg[e][0] + t4[1] * ureg[e][1] + t4[2] * ureg[e][2] + t4[3] * ureg[e][3];
+                            floatx4 t4 = t4s[it];
+                            if constexpr (EXT > 0) {
+                                t4 = ext_t4(ph * PR + ml, t4);
+                                if (ext_store) *reinterpret_cast<floatx4*>(const_cast<float*>(p.epi.lora_t) + (size_t)m * p.epi.ldt + utoff) = t4;
                             }
+                            t4 *= p.epi.lora_scale;
+                            if (p.epi.lora_u_tr) hoisted_rank4<true>(v, t4, ureg);
+                            else hoisted_rank4<false>(v, t4, ureg);
                         }
                         half8 o;
 #pragma unroll
@@ -663,7 +735,11 @@ template <int BM, int BN, int NST, int BK, int NW = 4> struct DmaOcc {
 // ds_read_b128's REAL lane groups ({0-3,12-15,20-27}, ...: MI355X_MICROARCH.md section LDS) -- PMC on MI355X:
 // SQ_LDS_BANK_CONFLICT = half of SQ_LDS_IDX_ACTIVE with it, 0 with the default key (-(r >> 2)) & 3
 // (profiles/r02_pmc_gemm_variants.md, tools/lds_bank_check.py).
-template <int BM, int BN, int WM, int WN, int NST, int CONV, int BK = 32, int FLAGS = 0>
+// EXT = 16 (8-wave 320-column tiles, plain GEMM only): 16 extra B rows per stage = the packed down matrix of this tile's column
+// segment (clora_epilogue_t.lora_dpack: 8 rows fp16(D), 8 rows fp16(D - fp16(D))), filled by one extra DMA instruction of waves
+// 0 and 1; T = A . D^T costs one extra MFMA per k-substep on the waves with wn < FM (two for FM = 4) and never leaves the CU
+// before the epilogue uses it.
+template <int BM, int BN, int WM, int WN, int NST, int CONV, int BK = 32, int FLAGS = 0, int EXT = 0>
 __global__ __launch_bounds__(WM * WN * 64, (DmaOcc<BM, BN, NST, BK, WM * WN>::v)) void gemm_dma_kernel(GemmArgs p) {
     constexpr int NW = WM * WN, NT = NW * 64;                // 4 waves, or 8 for the wide tiles (128x320, 64x320, 128x256: one block per CU)
     constexpr int ORD = FLAGS & 1;
@@ -674,10 +750,17 @@ __global__ __launch_bounds__(WM * WN * 64, (DmaOcc<BM, BN, NST, BK, WM * WN>::v)
     constexpr int KS = BK / 32;                             // MFMA k-substeps per stage
     constexpr int A_IN = BM / RPI / NW, B_IN = BN / RPI / NW; // DMA wave-instructions per stage per wave
     static_assert(BM % (RPI * NW) == 0 && BN % (RPI * NW) == 0, "tile rows must split evenly over the waves' DMA instructions");
-    constexpr int STAGE = (BM + BN) * BK;                   // halves
+    static_assert(EXT == 0 || (EXT == 16 && CONV == 0 && BK == 64 && NW == 8), "extra operand rows: 8-wave BK = 64 plain GEMMs");
+    constexpr int STAGE = (BM + BN + EXT) * BK;             // halves
     constexpr int SMEM_RING = NST * STAGE;
-    constexpr int SMEM_EPI = 64 * (BN + 4) * 2;             // fp32 staging of 64 output rows, in halves
+    constexpr int SMEM_EPI = (64 * (BN + 4) + (EXT ? BM * 16 : 0)) * 2;   // fp32 staging of 64 output rows (+ the tile's T rows), in halves
+#ifdef CLORA_DIAG_MIN_SMEM
+    // diagnostic build: a larger LDS request than the ring needs, so that fewer blocks fit on a CU (same instruction stream)
+    constexpr int SMEM0 = SMEM_RING > SMEM_EPI ? SMEM_RING : SMEM_EPI;
+    constexpr int SMEM = SMEM0 > (CLORA_DIAG_MIN_SMEM) ? SMEM0 : (CLORA_DIAG_MIN_SMEM);
+#else
     constexpr int SMEM = SMEM_RING > SMEM_EPI ? SMEM_RING : SMEM_EPI;
+#endif
     __shared__ __attribute__((aligned(16))) half_t smem[SMEM];
 
     const int t = threadIdx.x;
@@ -699,6 +782,10 @@ __global__ __launch_bounds__(WM * WN * 64, (DmaOcc<BM, BN, NST, BK, WM * WN>::v)
     const int w = t >> 6, l = t & 63, g = l >> 4, li = l & 15;
     constexpr bool conv = CONV == 1;
     const half_t* zero_page = reinterpret_cast<const half_t*>(g_clora_zero16);
+    // EXT: wave id as a scalar (the extra DMA instruction and its counted wait are wave-uniform branches)
+    const int wu = EXT > 0 ? __builtin_amdgcn_readfirstlane(t >> 6) : 0;
+    constexpr int X_W = EXT > 0 ? EXT / (64 / (BK / 8)) : 0;   // waves that issue one extra DMA instruction per stage
+    const half_t* const bx_base = EXT > 0 ? reinterpret_cast<const half_t*>(p.epi.lora_dpack) + (size_t)(n0 / p.epi.lora_seg) * 16 * p.K : nullptr;
 
     // ---- loader: wave w, instruction i fills rows (w*IN + i)*RPI .. +RPI of the tile; lane -> (row l/CH, slot l%CH)
     const int lrow = l / CH, pos = l % CH;
@@ -812,6 +899,12 @@ __global__ __launch_bounds__(WM * WN * 64, (DmaOcc<BM, BN, NST, BK, WM * WN>::v)
 #endif
             CLORA_GLDS16(src, Bs + (w * B_IN + i) * RPI * BK);
         }
+        if constexpr (EXT > 0) {
+            if (wu < X_W) {
+                const half_t* src = kok ? bx_base + (size_t)(wu * RPI + lrow) * p.K + k : zero_page;
+                CLORA_GLDS16(src, Bs + (BN + wu * RPI) * BK);
+            }
+        }
         k += BK;
         if (conv) {
             ci += BK;
@@ -829,6 +922,11 @@ __global__ __launch_bounds__(WM * WN * 64, (DmaOcc<BM, BN, NST, BK, WM * WN>::v)
     for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = zero4f();
+    constexpr int TM = EXT > 0 ? (FM + WN - 1) / WN : 1;     // M fragments of the T columns per wave: i = q * WN + wn
+    floatx4 tacc[TM];
+#pragma unroll
+    for (int q = 0; q < TM; ++q) tacc[q] = zero4f();
+    const int wnu = EXT > 0 ? wu % WN : 0;
 
     // NST-1 stages are always in flight: stages past the end of K fetch the zero page (cheap L2 hits), which keeps
     // the counted wait a compile-time constant
@@ -836,7 +934,8 @@ __global__ __launch_bounds__(WM * WN * 64, (DmaOcc<BM, BN, NST, BK, WM * WN>::v)
     for (int st = 0; st < NST - 1; ++st) issue_stage(st);
     int rd = 0, wr = NST - 1;
     for (int kt = 0; kt < nk; ++kt) {
-        CLORA_WAIT_VMCNT((NST - 2) * (A_IN + B_IN));          // stage kt has landed (loads retire in order)
+        if (EXT > 0 && wu < X_W) CLORA_WAIT_VMCNT((NST - 2) * (A_IN + B_IN + 1));
+        else CLORA_WAIT_VMCNT((NST - 2) * (A_IN + B_IN));      // stage kt has landed (loads retire in order)
         CLORA_RAW_BARRIER();                                   // ... for every wave, and stage kt-1 is fully consumed
         if (ORD == 0) { issue_stage(wr); wr = (wr + 1 == NST) ? 0 : wr + 1; }
         const half_t* As = smem + rd * STAGE;
@@ -857,14 +956,39 @@ __global__ __launch_bounds__(WM * WN * 64, (DmaOcc<BM, BN, NST, BK, WM * WN>::v)
             for (int i = 0; i < FM; ++i)
 #pragma unroll
                 for (int j = 0; j < FN; ++j) acc[i][j] = mfma16(af[ks][i], bf[ks][j], acc[i][j]);
+        if constexpr (EXT > 0) {
+            const half_t* Es = Bs + BN * BK;
+#pragma unroll
+            for (int q = 0; q < TM; ++q) {
+                if (q * WN + wnu < FM) {                       // wave-uniform
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) {
+                        half8 a = af[ks][q * WN];
+#pragma unroll
+                        for (int j = 1; j < WN; ++j)
+                            if (q * WN + j < FM && wnu == j) a = af[ks][q * WN + j < FM ? q * WN + j : 0];
+                        tacc[q] = mfma16(a, ld8(Es + li * BK + fsw[ks]), tacc[q]);
+                    }
+                }
+            }
+        }
     }
     CLORA_WAIT_VMCNT(0);                                       // trailing zero-page stages: LDS is reused below
+    if constexpr (EXT > 0) {
+        dma_epilogue<BM, BN, WM, WN, NT, SMEM, true, EXT>(p, acc, m0, n0, split, smem, t, tacc);
+        return;
+    }
     // HOIST (U / bias of a thread's column in registers for the whole tile) only on the 8-wave tiles = ONE block per CU.  Round 2 had it
     // on every kernel built for <= 2 blocks per CU; the strict epilogue test of round 3 (no element off by more than a few ulps, two
     // launches bit-identical) caught those variants -- 128x64 BK64 at 2 blocks per CU, and the 64x64 experiment at 3 -- producing a handful
     // of wrong elements per launch at M = 16384, N = K = 320 on hardware, sporadically; the one-block-per-CU kernels and the
     // non-hoisted epilogue are clean and bit-stable (profiles/r03_epi_diag*.txt, r03_gputest_11.log).  Cause not established.
+#ifdef CLORA_HOIST_ALL
+    // diagnostic build (tools/hoist_isa_diff.sh): the hoisted epilogue on every kernel built for <= 2 blocks per CU, as shipped in round 2
+    dma_epilogue<BM, BN, WM, WN, NT, SMEM, (NW > 4 || DmaOcc<BM, BN, NST, BK, NW>::v <= 2)>(p, acc, m0, n0, split, smem, t);
+#else
     dma_epilogue<BM, BN, WM, WN, NT, SMEM, (NW > 4)>(p, acc, m0, n0, split, smem, t);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1301,7 +1425,7 @@ int conv_mode(const GemmArgs& a, int bk) {
 // activations and n-major ranges (m fastest) are the cheaper assignment.  The model counts, per XCD and split, the distinct
 // panels of its range under either order.   "tile_order": 0 m-major always, 1 n-major always
 // (tests), 2 pick by the model.
-int g_opts[CLORA_OPT_COUNT] = {2, 1, 0, 0, 512, 1, 1, 0};    // tile_order, ln_rows, attn_fwd_waves (0 = auto), attn_bwd_waves (0 = auto), gn_blocks, epi_two_phase, lora_down_mode, gn_unroll
+int g_opts[CLORA_OPT_COUNT] = {2, 1, 0, 0, 512, 1, 1, 0, 1};    // tile_order, ln_rows, attn_fwd_waves (0 = auto), attn_bwd_waves (0 = auto), gn_blocks, epi_two_phase, lora_down_mode, gn_unroll, epi_hoist
 int tile_order_mode() { return g_opts[CLORA_OPT_TILE_ORDER]; }
 
 double fabric_model_bytes(int tiles_m, int tiles_n, int splits, double a_panel, double b_panel, bool n_major) {
@@ -1347,6 +1471,14 @@ int launch_gemm(GemmArgs& a, int splits, hipStream_t s, bool dma) {
     pick_tile_order(a, BM, BN, splits, false);
     if (!dma) a.n_major = 0;                                       // the v1 loop decodes blockIdx directly
     const dim3 grid(tiles_m * a.tiles_n, splits);
+    if (dma && a.epi.lora_dpack) {
+        if constexpr (WM * WN == 8 && BN == 320 && BM <= 128 && BK == 64) {
+            hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, WM, WN, NST, 0, BK, FLAGS, 16>), grid, dim3(WM * WN * 64), 0, s, a);
+            return clora_check_launch();
+        } else {
+            return CLORA_ERR_ARG;
+        }
+    }
     if (dma) {
         const int cm = conv_mode(a, BK);
         if (cm == 0) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, WM, WN, NST, 0, BK, FLAGS>), grid, dim3(WM * WN * 64), 0, s, a);
@@ -1431,6 +1563,7 @@ extern "C" int clora_gemm_f16_ex(const clora_half* A, int lda, const clora_half*
     a.lda = lda; a.ldc = ldc; a.M = M; a.N = N; a.K = K;
     a.tiles_m = 0; a.n_major = 0;
     a.two_phase = g_opts[CLORA_OPT_EPI_TWO_PHASE];
+    a.hoist_on = g_opts[CLORA_OPT_EPI_HOIST];
     if (conv && conv->enabled) {
         a.conv = *conv;
         if ((conv->Cin & 7) || K != conv->ksize * conv->ksize * conv->Cin) return CLORA_ERR_ARG;
@@ -1473,6 +1606,16 @@ extern "C" int clora_gemm_f16_ex(const clora_half* A, int lda, const clora_half*
     //            54..56 = the same with fragment reads before the ring refill; 57, 58 = 256x320 / 256x256 x2 stages (wave tiles 64x160 /
     //            64x128) for the M >= 32768 projections of the batch-32 inference forward
     bool dma = true;
+    if (a.epi.lora_dpack) {
+        // the adapter down-projection rides in this launch (clora_epilogue_t.lora_dpack): 8-wave 320-column tiles only
+        const clora_epilogue_t& e = a.epi;
+        if (a.conv.enabled || !e.lora_t || e.lora_r != 4 || e.geglu || (e.lora_seg % 320) || (N % e.lora_seg) || (K & 63) || split_k > 1 ||
+            (e.ldt & 3) || (e.lora_u_tr ? (e.ldu & 3) != 0 : e.ldu != 4) || N / e.lora_seg > 32 ||
+            (e.lora_t_in && ((e.ldt_in & 3) || e.lora_t_in_rows < 0)))
+            return CLORA_ERR_ARG;
+        if (!(tile_cfg == 51 || tile_cfg == 52 || tile_cfg == 54 || tile_cfg == 55)) tile_cfg = M >= 32768 ? 54 : 55;
+        split_k = 1; splits = 1;
+    }
     if (tile_cfg >= 11 && tile_cfg <= 13) { dma = false; tile_cfg -= 10; }
     int cfg = tile_cfg > 0 ? tile_cfg : tile + 1;
     // untuned shape (no table entry: tile_cfg == 0) that the patch-staged conv kernel can take: it beat every implicit-GEMM
@@ -1601,7 +1744,8 @@ extern "C" int clora_set_option(const char* name, int value) {
     static const Opt kOpts[] = {{"tile_order", CLORA_OPT_TILE_ORDER, 0, 2}, {"ln_rows", CLORA_OPT_LN_ROWS, 0, 1},
                                 {"attn_fwd_waves", CLORA_OPT_ATTN_FWD_WAVES, 0, 8}, {"attn_bwd_waves", CLORA_OPT_ATTN_BWD_WAVES, 0, 8},
                                 {"gn_blocks", CLORA_OPT_GN_BLOCKS, 64, 1 << 16}, {"epi_two_phase", CLORA_OPT_EPI_TWO_PHASE, 0, 1},
-                                {"lora_down_mode", CLORA_OPT_LORA_DOWN_MODE, 0, 2}, {"gn_unroll", CLORA_OPT_GN_UNROLL, 0, 1}};
+                                {"lora_down_mode", CLORA_OPT_LORA_DOWN_MODE, 0, 2}, {"gn_unroll", CLORA_OPT_GN_UNROLL, 0, 1},
+                                {"epi_hoist", CLORA_OPT_EPI_HOIST, 0, 1}};
     for (const Opt& o : kOpts)
         if (!strcmp(name, o.name)) {
             if (value < o.lo || value > o.hi) return CLORA_ERR_ARG;

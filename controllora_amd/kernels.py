@@ -133,10 +133,14 @@ def gemm(A: torch.Tensor, Bw: torch.Tensor, M: int, N: int, K: int, *, lda: Opti
          out: Optional[torch.Tensor] = None,
          split_k: int = 0, tile_cfg: int = 0, _tuned: bool = True,
          geglu: int = 0, geglu_h: Optional[torch.Tensor] = None, geglu_y: Optional[torch.Tensor] = None,
-         geglu_keep_h: bool = True) -> torch.Tensor:
+         geglu_keep_h: bool = True, lora_dpack: Optional[torch.Tensor] = None, lora_t_in: Optional[torch.Tensor] = None,
+         lora_t_in_mask: int = 0, lora_t_in_rows: int = 0) -> torch.Tensor:
     """C[M,N] = A . Bw^T with the fused epilogue of clora_epilogue_t.
     geglu=1 (Bw / bias packed by ops.GegluPack, N = 2F): returns (y [M,F], h [M,2F] or None when not geglu_keep_h);
-    geglu=2 (N = F, geglu_h = the saved h): returns dh [M, 2F]."""
+    geglu=2 (N = F, geglu_h = the saved h): returns dh [M, 2F].
+    lora_dpack ([N / lora_seg * 16, K] fp16 from lora_pack): the launch also computes T = A . D^T per column segment, WRITES it to
+    lora_t and uses it in its epilogue (clora_epilogue_t.lora_dpack); lora_t_in / lora_t_in_mask: precomputed part added to the
+    segments of the mask (row m reads row m % lora_t_in_rows when that is > 0)."""
     assert A.dtype == f16 and Bw.dtype == f16 and Bw.shape == (N, K) and Bw.is_contiguous()
     e = Epilogue()
     if geglu == 1:
@@ -166,6 +170,13 @@ def gemm(A: torch.Tensor, Bw: torch.Tensor, M: int, N: int, K: int, *, lda: Opti
         e.lora_t, e.ldt, e.lora_u, e.ldu, e.lora_u_tr = ptr(lora_t), lora_t.stride(0), ptr(lora_u), lora_u.stride(0), int(lora_u_tr)
         e.lora_r = lora_r if lora_r is not None else (lora_u.shape[0] if lora_u_tr else lora_u.shape[1])
         e.lora_seg, e.lora_scale = (lora_seg or N), float(lora_scale)
+    if lora_dpack is not None:
+        assert lora_t is not None and lora_dpack.dtype == f16 and lora_dpack.is_contiguous() and lora_dpack.shape == (N // e.lora_seg * 16, K)
+        e.lora_dpack = ptr(lora_dpack)
+        if lora_t_in is not None:
+            assert lora_t_in.dtype == f32 and lora_t_in.stride(1) == 1
+            e.lora_t_in, e.ldt_in, e.lora_t_in_rows, e.lora_t_in_mask = ptr(lora_t_in), lora_t_in.stride(0), int(lora_t_in_rows), int(lora_t_in_mask)
+        split_k = 1
     if _tuned and split_k == 0 and tile_cfg == 0:
         hit = globals()["_tuned"](M, N, K, conv)
         if hit is not None:
@@ -360,6 +371,12 @@ def geglu_bwd(h, dy):
 
 
 # ------------------------------------------------------------------ adapters
+def lora_pack(table: torch.Tensor, njobs: int, max_k: int):
+    """one launch over a device-resident clora_lora_pack_job_t table (ops.AdapterPacks builds it)"""
+    assert table.dtype == torch.uint8 and table.numel() >= njobs * C.sizeof(capi.LoraPackJob)
+    _call("clora_lora_pack_f16", ptr(table), njobs, max_k)
+
+
 def lora_down(X, D, T, toff, M, K, accumulate=False, x_rows=0, ldx=None, kmajor=False, R=None, d_scale=1.0):
     """T[:, toff:toff+R] (+)= X . (d_scale * D)^T ; X [rows, K] fp16 (row pitch ldx), T [M, ldt] fp32.
     D is [R, K] fp32, or with kmajor=True an up-projection matrix [K, R] used as its own transpose."""

@@ -171,8 +171,11 @@ class LoRACrossAttnProcessor(nn.Module):
 
     def _attend(self, attn, h2, q_in, e2, B, N, Nk, scale, out_in_fn, residual, own_out_always):
         packs = attn.fused_packs()
+        # the control term's share of the q adapter's down-projection, evaluated for the whole level in one launch
+        # (_batched_control_terms); only meaningful when q_in = (h, c) with that very c
+        t_pre = getattr(self, "_control_T", None) if (isinstance(q_in, tuple) and len(q_in) == 2 and q_in[1] is getattr(self, "_control_term", None)) else None
         if attn.is_cross:
-            q = ops.lora_proj(h2, packs[0], [self._seg("to_q_lora", q_in, scale)])
+            q = ops.lora_proj(h2, packs[0], [self._seg("to_q_lora", q_in, scale)], t_pre=t_pre[:, :4] if t_pre is not None else None)
             cache = _TEXT_KV if not torch.is_grad_enabled() else None
             key = (id(self), id(attn), e2.data_ptr(), e2._version, tuple(e2.shape), float(scale)) if cache is not None else None
             kv = cache.get(key) if cache is not None else None
@@ -185,7 +188,7 @@ class LoRACrossAttnProcessor(nn.Module):
         else:
             qkv = ops.lora_proj(h2, packs[0], [self._seg("to_q_lora", q_in, scale),
                                                self._seg("to_k_lora", h2, scale, self.key_states_skipped),
-                                               self._seg("to_v_lora", h2, scale, self.value_states_skipped)])
+                                               self._seg("to_v_lora", h2, scale, self.value_states_skipped)], t_pre=t_pre)
             a = attn.attend(qkv, None, B, N, N)
         a = out_in_fn(a)
         out_seg = self._seg("to_out_lora", a, scale, (not own_out_always) and self.output_states_skipped)
@@ -214,11 +217,13 @@ class _ControlMixin:
     def inject_control_states(self, control_states):
         self.control_states = control_states
         self._control_term = None          # a term precomputed for the previous control states is stale now
+        self._control_T = None
 
-    def inject_control_term(self, term, scale=1.0):
+    def inject_control_term(self, term, scale=1.0, t_q=None):
         """ControlLoRA.forward evaluates `scale * to_control(control)` for all sites of a level in one batched launch
-        pair (ops.control_terms) and hands each site its slice; used when the call's `scale` matches."""
-        self._control_term, self._control_term_scale = term, float(scale)
+        pair (ops.control_terms) and hands each site its slice; used when the call's `scale` matches.  t_q (fp32 [Mc, 12], columns
+        0..3 valid): the term's share of the q adapter's down-projection, `term . D_q^T` (see ops.lora_proj `t_pre`)."""
+        self._control_term, self._control_term_scale, self._control_T = term, float(scale), t_q
 
     def _control_tokens(self, hidden_states):
         """models.py:202-206 / :337-341: flatten NCHW -> [B, HW, C] once and cache on self (quirk C5).  The hint
@@ -556,8 +561,11 @@ def _batched_control_terms(procs, c):
     if len(sites) < 2 or len({tuple(p.to_control.down.weight.shape) + tuple(p.to_control.up.weight.shape) for p in sites}) != 1:
         return
     terms = ops.control_terms(c.reshape(-1, c.shape[-1]), [(p.to_control.down.weight, p.to_control.up.weight) for p in sites], 1.0)
-    for p, t in zip(sites, terms):
-        p.inject_control_term(t, 1.0)
+    # rank-4 q adapters ride in their projection GEMM (ops._fusable); the GEMM streams h only, so the control term's share
+    # L_q(c) = c . D_q^T of every site of the level is evaluated here, in one more launch for the whole level
+    tq = ops.control_q_parts(terms, [p.to_q_lora.down.weight for p in sites]) if ops.FUSE_DOWN else [None] * len(sites)
+    for p, t, q in zip(sites, terms, tq):
+        p.inject_control_term(t, 1.0, q)
 
 
 def map_processors_to_unet(unet, control_lora) -> dict:

@@ -444,6 +444,111 @@ def _adjacent(ts):
     return True
 
 
+# ---- adapter operand packs for the in-launch down-projection (include/clora.h clora_epilogue_t.lora_dpack) -----------------
+# A rank-4 adapter whose input is the projection's own input is evaluated INSIDE the projection GEMM (16 extra operand rows per
+# ring stage): the separate lora_down launch and its second pass over the activation disappear.  The GEMM needs the down matrix
+# (forward) / the scaled up matrix (backward: dT = dy . (s U)) as a 16-row fp16 block (hi | lo split, fp32-equivalent); the blocks
+# of all adapters are refreshed by ONE launch over a device-resident job table (`repack_adapters`, called by the trainer after
+# every optimizer step -- its flat AdamW kernel updates the weights behind torch's back); an in-place torch update of a
+# parameter is caught by its _version at the point of use.
+FUSE_DOWN = _os.environ.get("CLORA_FUSE_DOWN", "1") != "0"        # "0": separate lora_down launches everywhere (A/B runs)
+FUSE_TILE_N = 320                                                 # column width of the 8-wave tiles that carry the extra rows
+
+
+class _AdapterPacks:
+    def __init__(self):
+        self.groups = {}          # key -> dict(out, jobs, versions, srcs)
+        self.table = None         # device uint8 tensor of clora_lora_pack_job_t, all groups
+        self.njobs = 0
+        self.max_k = 0
+        self.retired = []         # tables baked into captured graphs stay alive
+
+    def _jobs_of(self, srcs, kmajor, scales, out, K):
+        import ctypes as C
+        from . import capi
+        jobs = []
+        for i, (D, sc) in enumerate(zip(srcs, scales)):
+            if D is None:
+                continue
+            R = D.shape[1] if kmajor else D.shape[0]
+            jobs.append(capi.LoraPackJob(D.data_ptr(), out[16 * i:].data_ptr(), D.stride(0), R, K, int(kmajor), float(sc), 0))
+        return jobs
+
+    def _launch(self, jobs, K, device):
+        import ctypes as C
+        from . import capi
+        arr = (capi.LoraPackJob * len(jobs))(*jobs)
+        tab = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
+        K_.lora_pack(tab, len(jobs), K)
+        return tab
+
+    def get(self, srcs, kmajor=False, scales=None):
+        """srcs: the adapter matrices of the column segments of one GEMM (None = no adapter on that segment: zero block);
+        -> [16 * len(srcs), K] fp16, refreshed if a source was updated in place since the last pack"""
+        scales = tuple(1.0 if sc is None else float(sc) for sc in (scales or [None] * len(srcs)))
+        key = (tuple((D.data_ptr(), tuple(D.shape), D.stride(0)) if D is not None else None for D in srcs), bool(kmajor), scales)
+        g = self.groups.get(key)
+        live = [D for D in srcs if D is not None]
+        if g is None:
+            D0 = live[0]
+            assert all(D.dtype == f32 and D.stride(1) == 1 for D in live)
+            K = D0.shape[0] if kmajor else D0.shape[1]
+            out = torch.zeros((16 * len(srcs), K), dtype=f16, device=D0.device)
+            jobs = self._jobs_of(srcs, kmajor, scales, out, K)
+            g = self.groups[key] = dict(out=out, jobs=jobs, K=K, srcs=tuple(srcs), versions=None, tab=None)
+            self.table = None                                   # rebuilt (with the new group) at the next repack
+        vers = tuple(D._version for D in live)
+        if g["versions"] != vers:
+            g["tab"] = self._launch(g["jobs"], g["K"], g["out"].device)    # first use / in-place update: this group alone
+            g["versions"] = vers
+        return g["out"]
+
+    def repack_all(self):
+        """one launch over every registered group (the weights changed behind torch's back: flat optimizer step)"""
+        if not self.groups:
+            return
+        if self.table is None:
+            jobs = [j for g in self.groups.values() for j in g["jobs"]]
+            import ctypes as C
+            from . import capi
+            arr = (capi.LoraPackJob * len(jobs))(*jobs)
+            dev = next(iter(self.groups.values()))["out"].device
+            if self.table is not None:
+                self.retired.append(self.table)
+            self.table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+            self.retired.append(self.table)
+            self.njobs, self.max_k = len(jobs), max(g["K"] for g in self.groups.values())
+        K_.lora_pack(self.table, self.njobs, self.max_k)
+
+
+K_ = K
+ADAPTER_PACKS = _AdapterPacks()
+
+
+def repack_adapters():
+    ADAPTER_PACKS.repack_all()
+
+
+FUSE_MIN_BLOCKS = int(_os.environ.get("CLORA_FUSE_MIN_BLOCKS", "192"))
+
+
+def _fills_the_chip(M, N):
+    """the 8-wave 320-column tiles run one block per CU: below ~3/4 of the 256 CUs the narrow 64x64 tiles (3 blocks per CU, 5x the
+    blocks) win by more than the separate down-projection launch costs (measured r04: the 16x16 / 32x32 levels lost 0.6 ms/step)"""
+    bm = 128 if M >= 32768 else 64
+    return ((M + bm - 1) // bm) * (N // FUSE_TILE_N) >= FUSE_MIN_BLOCKS
+
+
+def _fusable(pack, meta, ranks, seg_w, M):
+    """may the adapters of this projection ride in its GEMM?  rank 4 everywhere, 320-column segments, whole 64-deep k-steps, every
+    adapter fed by x itself (index 0) plus at most one more input"""
+    if not FUSE_DOWN or not ranks or any(rk != 4 for rk in ranks) or seg_w % FUSE_TILE_N or pack.K % 64:
+        return False
+    if not _fills_the_chip(M, pack.N):
+        return False
+    return all(m is None or (m[0][0] == 0 and len(m[0]) <= 2) for m in meta)
+
+
 class _LoraProjFn(torch.autograd.Function):
     """y = x W^T (+b) (+residual) + scale_s * up_s(down_s(xa_s)) on column segment s.
 
@@ -454,7 +559,7 @@ class _LoraProjFn(torch.autograd.Function):
     materialised and h keeps a single consumer.  Tensor arguments are (x, residual, *xas[1:], D_0, U_0, D_1, U_1, ...)."""
 
     @staticmethod
-    def forward(ctx, pack: LinearPack, meta, n_xa, x, residual, *rest):
+    def forward(ctx, pack: LinearPack, meta, n_xa, t_pre, x, residual, *rest):
         xas = [x] + list(rest[:n_xa - 1])
         params = rest[n_xa - 1:]
         S = len(meta)
@@ -463,19 +568,27 @@ class _LoraProjFn(torch.autograd.Function):
         ranks = [params[2 * i].shape[0] for i in range(len(params) // 2)]
         r = max(ranks + [1])
         full = all(m is not None for m in meta) and all(rk == r for rk in ranks)
-        T = (torch.empty if full else torch.zeros)((M, S * r), dtype=f32, device=x.device)
+        fused = _fusable(pack, meta, ranks, seg_w, M)
+        T = (torch.empty if (full or fused) else torch.zeros)((M, S * r), dtype=f32, device=x.device)
         pieces, pi, info, dspecs = [], 0, [], []
+        f_srcs, f_in_mask, f_in = [], 0, []           # fused: down matrices per segment, segments with a second (precomputed) part
         for s, m in enumerate(meta):
             if m is None:
                 pieces.append(torch.zeros((seg_w, r), dtype=f32, device=x.device))
                 info.append(None)
+                f_srcs.append(None)
                 continue
             xis, sc = m
             D, Uw = params[2 * pi], params[2 * pi + 1]
             pi += 1
             rs = D.shape[0]
             assert len(xis) <= 2
-            if rs <= 16:                              # both inputs of a summed adapter input go through ONE job
+            if fused:
+                f_srcs.append(D.detach())
+                if len(xis) > 1:
+                    f_in_mask |= 1 << s
+                    f_in.append((s, xas[xis[1]], D.detach()))
+            elif rs <= 16:                            # both inputs of a summed adapter input go through ONE job
                 x2 = xas[xis[1]] if len(xis) > 1 else None          # may hold fewer rows (control batch 1 broadcast, quirk C6)
                 dspecs.append(dict(X=xas[xis[0]], D=D.detach(), toff=s * r, R=rs, X2=x2, r2=0,
                                    x2_rows=x2.shape[0] if (x2 is not None and x2.shape[0] != M) else 0))
@@ -491,8 +604,23 @@ class _LoraProjFn(torch.autograd.Function):
             K.lora_down_multi([K.down_job(j["X"], j["D"], T, j["toff"], M, j["D"].shape[1], X2=j["X2"], x2_rows=j["x2_rows"],
                                           R=j["R"], r2=j["r2"]) for j in _merge_down_jobs(dspecs)])   # adapters sharing x in one pass
         U = _stack_rows(pieces)
-        y = K.gemm(x, pack.w, M, pack.N, pack.K, bias=pack.bias, residual=residual, lora_t=T, lora_u=U,
-                   lora_seg=seg_w, lora_scale=1.0)
+        if fused:
+            # the part of T that does not come from x (the control term's share of the q adapter, L_q(h + c) = L_q(h) + L_q(c)):
+            # handed in precomputed for the whole level (models._batched_control_terms) or evaluated here on the small input
+            t_in, t_in_rows = None, 0
+            if f_in:
+                rows = f_in[0][1].shape[0]
+                pre = t_pre if (t_pre is not None and t_pre.shape == (rows, S * r)) else None
+                if pre is None:
+                    pre = torch.empty((rows, S * r), dtype=f32, device=x.device)
+                    K.lora_down_multi([K.down_job(xi, Dd, pre, s_ * r, rows, Dd.shape[1]) for s_, xi, Dd in f_in])
+                t_in, t_in_rows = pre, (rows if rows != M else 0)
+            y = K.gemm(x, pack.w, M, pack.N, pack.K, bias=pack.bias, residual=residual, lora_t=T, lora_u=U,
+                       lora_seg=seg_w, lora_scale=1.0, lora_dpack=ADAPTER_PACKS.get(f_srcs), lora_t_in=t_in,
+                       lora_t_in_mask=f_in_mask, lora_t_in_rows=t_in_rows)
+        else:
+            y = K.gemm(x, pack.w, M, pack.N, pack.K, bias=pack.bias, residual=residual, lora_t=T, lora_u=U,
+                       lora_seg=seg_w, lora_scale=1.0)
         ctx.pack, ctx.info, ctx.n_xa, ctx.r, ctx.has_res = pack, info, n_xa, r, residual is not None
         ctx.params = params                       # the Parameter objects themselves (leaf tensors)
         ctx.save_for_backward(T, *xas)
@@ -508,6 +636,9 @@ class _LoraProjFn(torch.autograd.Function):
         seg_w = pack.N // S
         M = dy.shape[0]
         dT = (torch.empty if all(i is not None and i[2] == r for i in info) else torch.zeros)((M, S * r), dtype=f32, device=dy.device)
+        # single-adapter projections (out / cross-attention q): dT = dy . (s U) rides in the dgrad GEMM that streams dy anyway
+        fused_bwd = (FUSE_DOWN and S == 1 and info[0] is not None and info[0][2] == 4 and 0 in info[0][0] and ctx.needs_input_grad[4]
+                     and pack.K % FUSE_TILE_N == 0 and pack.N % 64 == 0 and _fills_the_chip(M, pack.K))
         d_xas: List[Optional[torch.Tensor]] = [None] * n_xa
         own = []                                  # (segment, D) of adapters fed by x itself -> dgrad GEMM epilogue
         djobs, wjobs, later, keep = [], [], [], []
@@ -521,7 +652,9 @@ class _LoraProjFn(torch.autograd.Function):
             dys = dy[:, s * seg_w:(s + 1) * seg_w]
             big = rs > 16
             # dT_s = sc * dy_s . U_s : a "down" projection of dy with U (k-major) as the matrix
-            if big:
+            if fused_bwd:
+                pass
+            elif big:
                 K.lora_down(dys, Uw.detach(), dT, s * r, M, seg_w, ldx=pack.N, kmajor=True, R=rs, d_scale=sc)
             else:
                 djobs.append(K.down_job(dys, Uw.detach(), dT, s * r, M, seg_w, ldx=pack.N, kmajor=True, R=rs, d_scale=sc))
@@ -545,6 +678,11 @@ class _LoraProjFn(torch.autograd.Function):
                     own.append((s, D))
                 else:
                     later.append(("dx", xi, s, D))
+        dx = None
+        if fused_bwd:
+            D0, U0, sc0 = params[0], params[1], info[0][1]
+            dx = K.gemm(dy, pack.wt, M, pack.K, pack.N, lora_t=dT, lora_u=D0.detach(), lora_seg=pack.K, lora_u_tr=True, lora_r=4,
+                        lora_dpack=ADAPTER_PACKS.get([U0.detach()], kmajor=True, scales=[sc0]))
         if djobs:
             K.lora_down_multi(djobs)              # dT of every adapter of this GEMM: one launch
         if wjobs:
@@ -552,7 +690,7 @@ class _LoraProjFn(torch.autograd.Function):
         for item in later:
             if item[0] == "dx":
                 _, xi, s, D = item
-                if ctx.needs_input_grad[4 + xi]:
+                if ctx.needs_input_grad[5 + xi]:
                     g = K.lora_up(None, dT, s * r, D.detach(), M, D.shape[1], 1.0, u_tr=True)
                     rows = xas[xi].shape[0]
                     if rows != M:                                   # the input was broadcast over the batch: sum it back
@@ -561,8 +699,7 @@ class _LoraProjFn(torch.autograd.Function):
             else:
                 A_, T_, to_, G_, gsn, gsj, N_, rs_, sc_, lda_ = item
                 K.lora_wgrad(A_, T_, to_, G_, gsn, gsj, M, N_, rs_, scale=sc_, lda=lda_)
-        dx = None
-        if ctx.needs_input_grad[3]:
+        if ctx.needs_input_grad[4] and not fused_bwd:
             if not own:
                 dx = K.gemm(dy, pack.wt, M, pack.K, pack.N)
             else:
@@ -577,14 +714,15 @@ class _LoraProjFn(torch.autograd.Function):
                     for s, D in own:
                         Dx[s * r:s * r + D.shape[0]] = D.detach()
                     dx = K.gemm(dy, pack.wt, M, pack.K, pack.N, lora_t=dT, lora_u=Dx, lora_seg=pack.K, lora_u_tr=True)
-        dres = dy if ctx.has_res and ctx.needs_input_grad[4] else None
-        return (None, None, None, dx, dres, *d_xas[1:], *([None] * len(params)))
+        dres = dy if ctx.has_res and ctx.needs_input_grad[5] else None
+        return (None, None, None, None, dx, dres, *d_xas[1:], *([None] * len(params)))
 
 
 def lora_proj(x, pack: LinearPack, segs: Sequence[Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor, float]]],
-              residual=None):
+              residual=None, t_pre=None):
     """segs[s] = None or (xa, down_weight [r,K], up_weight [seg,r], scale); xa is a tensor, or a tuple of tensors
-    whose sum is the adapter input."""
+    whose sum is the adapter input.  t_pre (optional, fp32 [rows of the second input, S * r]): the second input's share of the
+    down-projections, already evaluated (models._batched_control_terms); a plain buffer, gradients flow through `xa`."""
     xas = [x]
     meta, params = [], []
     for sg in segs:
@@ -601,7 +739,7 @@ def lora_proj(x, pack: LinearPack, segs: Sequence[Optional[Tuple[torch.Tensor, t
             idxs.append(idx)
         meta.append((tuple(idxs), float(sc)))
         params += [D, U]
-    return _LoraProjFn.apply(pack, tuple(meta), len(xas), x, residual, *xas[1:], *params)
+    return _LoraProjFn.apply(pack, tuple(meta), len(xas), t_pre, x, residual, *xas[1:], *params)
 
 
 class _ControlAddFn(torch.autograd.Function):
@@ -774,6 +912,25 @@ def control_terms(ctrl, layers, scale=1.0):
     """layers: [(down_weight, up_weight), ...] of the sites sharing `ctrl` -> tuple of control terms [Mc, C]"""
     flat = [w for D, U in layers for w in (D, U)]
     return _ControlTermsFn.apply(ctrl, float(scale), len(layers), *flat)
+
+
+@torch.no_grad()
+def control_q_parts(terms, q_downs):
+    """T_l = c_l . D_q,l^T for the control terms c_l [Mc, C] of the sites of one level (one multi-job launch): the share of
+    each site's q down-projection that does not come from the hidden states (reference models.py:237-238, by linearity).
+    Plain fp32 buffers [Mc, 12] (columns 0..3 written; the q | k | v column layout of the fused self-attention projection);
+    None where the adapter cannot ride in the GEMM anyway.  Gradients flow through the terms themselves (ops.lora_proj)."""
+    outs, jobs = [], []
+    for c, D in zip(terms, q_downs):
+        if D.shape[0] != 4 or D.shape[1] % 64 or D.shape[1] % FUSE_TILE_N:
+            outs.append(None)
+            continue
+        T = torch.empty((c.shape[0], 12), dtype=f32, device=c.device)
+        jobs.append(K.down_job(c.detach(), D.detach(), T, 0, c.shape[0], D.shape[1]))
+        outs.append(T)
+    if jobs:
+        K.lora_down_multi(jobs)
+    return outs
 
 
 class _LoraApplyFn(torch.autograd.Function):

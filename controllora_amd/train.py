@@ -110,9 +110,21 @@ class ControlLoRATrainer:
         import ctypes
         from . import capi
         L = capi.lib()
-        if L.cdll.clora_comm_world() == world:
-            return                                                   # already joined (a second trainer in this process)
         rank = torch.distributed.get_rank(pg) if world > 1 else 0
+        have = L.cdll.clora_comm_world()
+        # one communicator per process: reuse it only if every rank of THIS group already holds one of the same shape (a second
+        # trainer on the same group); a communicator built for another world size / rank layout is destroyed and rebuilt.  The
+        # decision is made collectively -- ncclCommInitRank is a collective, a rank that skipped it would hang the others.
+        same = int(have == world and L.cdll.clora_comm_rank() == rank)
+        if world > 1:
+            flag = torch.tensor([same], dtype=torch.int32, device=self.flat.data.device if pg is None or
+                                torch.distributed.get_backend(pg) == "nccl" else "cpu")
+            torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN, group=pg)
+            same = int(flag.item())
+        if same:
+            return
+        if have:
+            L.call("clora_comm_destroy")
         uid = (ctypes.c_char * 128)()
         if rank == 0:
             L.call("clora_comm_unique_id", uid)
@@ -121,6 +133,21 @@ class ControlLoRATrainer:
             torch.distributed.broadcast_object_list(box, src=0, group=pg)
             uid = (ctypes.c_char * 128).from_buffer_copy(box[0])
         L.call("clora_comm_init", uid, rank, world)
+
+    def comm_ranks(self) -> int:
+        """ranks of the communicator the exchange step runs on (1 when the step has no exchange)"""
+        if self.world <= 1 and self.comm != "clora":
+            return 1
+        if self.comm == "clora":
+            from . import capi
+            return int(capi.lib().cdll.clora_comm_world())
+        return torch.distributed.get_world_size(self.pg)
+
+    def close(self):
+        """release the C ABI's RCCL communicator (a no-op for comm="torch"); call before the process group is destroyed"""
+        if self.comm == "clora":
+            from . import capi
+            capi.lib().call("clora_comm_destroy")
 
     def _all_reduce_grads(self):
         g = self.flat.grad
@@ -170,6 +197,8 @@ class ControlLoRATrainer:
                      self.hp["interval"])
         K.adamw_flat(self.flat.data, g, self.flat.exp_avg, self.flat.exp_avg_sq, self.state, self.hp["lr"], self.hp["beta1"],
                      self.hp["beta2"], self.hp["eps"], self.hp["wd"])
+        from . import ops
+        ops.repack_adapters()       # the fp16 operand blocks of the adapters that ride in their projection GEMMs (one launch)
 
     def step(self, noisy_latents, timesteps, encoder_hidden_states, guide, target):
         pred = self.forward_backward(noisy_latents, timesteps, encoder_hidden_states, guide, target)
@@ -241,9 +270,93 @@ class ControlLoRATrainer:
         self.control_lora.save_pretrained(directory)
 
     def load_state(self, directory: str) -> None:
+        """`checkpoint-N` directory written by this trainer (trainer_state.safetensors) or by the REFERENCE's
+        `accelerator.save_state` (reference train_text_to_image_control_lora.py:713-735 / test_...:705-722): model weights +
+        torch AdamW state + GradScaler + LR-scheduler files, see load_accelerate_state."""
         import os
         from safetensors.torch import load_file
-        self.load_state_dict(load_file(os.path.join(directory, "trainer_state.safetensors")))
+        own = os.path.join(directory, "trainer_state.safetensors")
+        if os.path.exists(own):
+            self.load_state_dict(load_file(own))
+        else:
+            self.load_accelerate_state(directory)
+
+    def _module_order_views(self):
+        """(parameter, offset into the flat buffers) in `control_lora.parameters()` order -- the order torch.optim.AdamW numbers
+        its state in when it is built from `control_lora.parameters()` as the reference does (train...:607-613)"""
+        base, out = self.flat.data.data_ptr(), []
+        for p in self.control_lora.parameters():
+            if p.requires_grad:
+                off = (p.data_ptr() - base) // 4
+                assert 0 <= off and off + p.numel() <= self.flat.numel
+                out.append((p, off))
+        return out
+
+    def load_accelerate_state(self, directory: str) -> None:
+        """Resume from a directory in accelerate's `save_state` layout: `pytorch_model.bin` or `model.safetensors` (the
+        ControlLoRA state dict), `optimizer.bin` (torch AdamW state_dict: per-parameter step / exp_avg / exp_avg_sq numbered in
+        `control_lora.parameters()` order), optional `scaler.pt` (GradScaler: scale, _growth_tracker) and `scheduler.bin`
+        (LambdaLR: last_epoch = optimizer steps taken)."""
+        import os
+        f = lambda n: os.path.join(directory, n)
+        if os.path.exists(f("model.safetensors")):
+            from safetensors.torch import load_file
+            sd = load_file(f("model.safetensors"))
+        elif os.path.exists(f("pytorch_model.bin")):
+            sd = torch.load(f("pytorch_model.bin"), map_location="cpu")
+        else:
+            raise FileNotFoundError(f"{directory}: neither trainer_state.safetensors nor an accelerate checkpoint (pytorch_model.bin / model.safetensors)")
+        self.control_lora.load_state_dict(sd)                    # in-place copies: the parameters stay views of the flat buffer
+        opt = torch.load(f("optimizer.bin"), map_location="cpu")
+        views = self._module_order_views()
+        ids = [i for g in opt["param_groups"] for i in g["params"]]
+        if len(ids) != len(views):
+            raise ValueError(f"optimizer.bin holds {len(ids)} parameters, the model has {len(views)} trainable ones")
+        steps = set()
+        with torch.no_grad():
+            self.flat.exp_avg.zero_(); self.flat.exp_avg_sq.zero_()
+            for i, (p, off) in zip(ids, views):
+                st = opt["state"].get(i)
+                if st is None:
+                    continue                                      # a parameter that never received a gradient
+                if tuple(st["exp_avg"].shape) != tuple(p.shape):
+                    raise ValueError(f"optimizer state {i}: shape {tuple(st['exp_avg'].shape)} vs parameter {tuple(p.shape)}")
+                self.flat.exp_avg[off:off + p.numel()].copy_(st["exp_avg"].reshape(-1))
+                self.flat.exp_avg_sq[off:off + p.numel()].copy_(st["exp_avg_sq"].reshape(-1))
+                steps.add(int(st["step"]))
+            step = max(steps) if steps else 0
+            self.state.zero_()
+            self.state[2] = float(step)                           # bias corrections are recomputed from it (clora_optim_prep_f32)
+            self.state[3] = 65536.0
+            if os.path.exists(f("scaler.pt")):
+                sc = torch.load(f("scaler.pt"), map_location="cpu")
+                self.state[3] = float(sc.get("scale", 65536.0))
+                self.state[4] = float(sc.get("_growth_tracker", 0))
+            self.state[11] = float(self.world)
+        self.global_step = step
+        if os.path.exists(f("scheduler.bin")):
+            self.global_step = int(torch.load(f("scheduler.bin"), map_location="cpu").get("last_epoch", step))
+        self._micro = 0
+        from . import ops
+        ops.repack_adapters()
+
+    def save_accelerate_state(self, directory: str, lr: float = None) -> None:
+        """the same checkpoint in accelerate's layout, so a reference run (`accelerator.load_state`) can resume from it"""
+        import os
+        os.makedirs(directory, exist_ok=True)
+        torch.save({k: v.detach().cpu().clone() for k, v in self.control_lora.state_dict().items()}, os.path.join(directory, "pytorch_model.bin"))
+        views = self._module_order_views()
+        step = torch.tensor(float(self.state[2]))
+        state = {i: {"step": step.clone(), "exp_avg": self.flat.exp_avg[off:off + p.numel()].reshape(p.shape).cpu().clone(),
+                     "exp_avg_sq": self.flat.exp_avg_sq[off:off + p.numel()].reshape(p.shape).cpu().clone()}
+                 for i, (p, off) in enumerate(views)}
+        group = {"lr": self.hp["lr"] if lr is None else lr, "betas": (self.hp["beta1"], self.hp["beta2"]), "eps": self.hp["eps"],
+                 "weight_decay": self.hp["wd"], "amsgrad": False, "maximize": False, "foreach": None, "capturable": False,
+                 "differentiable": False, "fused": None, "params": list(range(len(views)))}
+        torch.save({"state": state, "param_groups": [group]}, os.path.join(directory, "optimizer.bin"))
+        torch.save({"scale": float(self.state[3]), "growth_factor": 2.0, "backoff_factor": 0.5, "growth_interval": self.hp["interval"],
+                    "_growth_tracker": int(self.state[4])}, os.path.join(directory, "scaler.pt"))
+        torch.save({"last_epoch": self.global_step, "_step_count": self.global_step + 1}, os.path.join(directory, "scheduler.bin"))
 
     # -- host-visible scalars (each forces a sync; call outside the timed region)
     def loss(self, numel) -> float:

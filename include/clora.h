@@ -78,7 +78,36 @@ typedef struct {
     int geglu_f;                 /* F */
     const clora_half* geglu_h;   /* mode 2 */
     clora_half* geglu_y;         /* mode 1 */
+    /* Adapter down-projection evaluated BY this launch (round 4; reference models.py:232-282: every `attn.to_x(h) + scale *
+     * to_x_lora(h)` pair reads h twice -- once for the frozen projection, once for LoRALinearLayer.down).  lora_dpack != NULL:
+     * the launch computes T[m, s*lora_r + j] = sum_k A[m, k] * D_s[j, k] for the adapter of every column segment s from the A
+     * rows it streams for the projection itself (16 extra operand rows per ring stage: fp16(D) and fp16(D - fp16(D)), i.e. fp32
+     * weights to ~2^-22, as clora_lora_down computes it), WRITES it to lora_t (which must then be writable: the backward reads
+     * it) and uses it in the epilogue without a global round trip.  lora_t_in (optional): a precomputed part that is ADDED to
+     * the computed T of the segments whose bit is set in lora_t_in_mask -- the control term's share of the q adapter,
+     * L_q(h + c) = L_q(h) + L_q(c) (reference models.py:237-238) -- row m reads row m % lora_t_in_rows when lora_t_in_rows > 0
+     * (control batch 1 broadcast), same column layout as lora_t with row pitch ldt_in.
+     * Needs: plain GEMM (no conv), lora_r == 4, lora_seg % 320 == 0, K % 64 == 0, split_k == 1, no GEGLU; runs on the 8-wave
+     * 320-column tiles (tile_cfg 51, 52, 54, 55, 57; 0 = chosen by M); anything else: CLORA_ERR_ARG. */
+    const clora_half* lora_dpack; /* [N / lora_seg][16][K] from clora_lora_pack_f16, or NULL */
+    const float* lora_t_in;
+    int ldt_in, lora_t_in_rows;
+    unsigned lora_t_in_mask;
 } clora_epilogue_t;
+
+/* Packs adapter matrices for `lora_dpack`: out[16][K] fp16, rows 0..R-1 = fp16(scale * D), rows 8..8+R-1 = fp16(scale * D -
+ * fp16(scale * D)), other rows zero; R <= 8.  kmajor = 0: D is a down weight [R, K] with row pitch ldd (LoRALinearLayer.down,
+ * reference models.py:40-44); kmajor = 1: D is an up weight [K, R] with row pitch ldd used as its own transpose (the backward's
+ * dT = dY . (scale * U)).  `table` is a DEVICE array of njobs jobs (built once per model: the pointers are stable), one launch
+ * repacks every adapter of a step -- what the per-call fp32 -> compute-dtype casts of LoRALinearLayer.forward do. */
+typedef struct {
+    const float* D;
+    clora_half* out;
+    int ldd, R, K, kmajor;
+    float scale;
+    int pad_;
+} clora_lora_pack_job_t;
+int clora_lora_pack_f16(const clora_lora_pack_job_t* table, int njobs, int max_k, void* stream);
 
 /* C[M,N] = A[M,K] . B[N,K]^T  (fp16 in, fp32 accumulate on MFMA, fp16 out).
  * Replaces torch Linear / Conv2d forward AND dgrad of the frozen UNet layers
@@ -109,7 +138,9 @@ int clora_gemm_f16_ex(const clora_half* A, int lda, const clora_half* B, clora_h
  * reference op is the same F.conv2d of upstream ResnetBlock2D; tuner / tests use this to know what they time. */
 int clora_conv_patch_eligible(int M, const clora_conv_t* conv, int tile_cfg);
 
-/* Tuning knobs, no reference counterpart: results never depend on them (bit-identical outputs, tests/test_kernels_*.py).
+/* Tuning knobs, no reference counterpart: results never depend on them (bit-identical outputs, tests/test_kernels_*.py; the one
+ * exception is "lora_down_mode", which changes how the fp32 sum over K is partitioned -- bit-identical per mode, equal to
+ * ~1e-7 relative across modes, tests/test_kernels_gpu.py::test_lora_down_launch_modes).
  * This table is the ABI's ONLY process-global state (every other entry point is a pure function of its arguments and the
  * stream); the library reads no environment variable.  A knob takes effect for the launches that follow (a captured hipGraph
  * keeps what it was captured with).
@@ -127,6 +158,9 @@ int clora_conv_patch_eligible(int M, const clora_conv_t* conv, int tile_cfg);
  *   "lora_down_mode"  how clora_lora_down[_multi]_f16 spreads a job: 0 = four waves split K up to 4096 rows, one wave per 16 rows above;
  *                     1 = K-split at every size, sixteen waves per row group up to 1024 rows (default); 2 = as 0 with eight k-steps of
  *                     loads in flight above 4096 rows.
+ *   "epi_hoist"       1 = the 8-wave GEMM tiles keep a thread's adapter up-matrix columns and bias in registers for the whole tile
+ *                     (default), 0 = fetch them per output chunk like the 4-wave tiles do (a switch to take the hoisted epilogue out
+ *                     of the path without a rebuild; launches with lora_dpack always hoist).
  * Unknown names / values: CLORA_ERR_ARG. */
 int clora_set_option(const char* name, int value);
 
@@ -261,11 +295,14 @@ int clora_lora_wgrad_f16(const clora_half* A, int lda, const float* T, int ldt, 
  *   clora_comm_unique_id   rank 0 only: 128 opaque bytes; the host hands them to every rank (any transport)
  *   clora_comm_init        every rank, collectively, after hipSetDevice: creates the communicator (once per process)
  *   clora_comm_world       number of ranks of the live communicator, 0 when there is none
+ *   clora_comm_rank        this process's rank in it, -1 when there is none (a host re-using the process for another group
+ *                          checks both before deciding to keep the communicator)
  *   clora_allreduce_flat_f32  buf[0..n) := sum over ranks, enqueued on `stream` (asynchronous like every other entry point)
  *   clora_comm_destroy     releases the communicator */
 int clora_comm_unique_id(void* id128);
 int clora_comm_init(const void* id128, int rank, int world);
 int clora_comm_world(void);
+int clora_comm_rank(void);
 int clora_allreduce_flat_f32(float* buf, size_t n, void* stream);
 int clora_comm_destroy(void);
 

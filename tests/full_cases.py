@@ -247,12 +247,14 @@ def load_fixture(name):
         return {k: f.get_tensor(k) for k in f.keys()}, f.metadata()
 
 
-def train_step_vs_fixture(dev):
-    """BASELINE configs[1] (configs/fill50k.json, SD-1.5 topology, 512x512, batch 4; reference train...:751-796): the product
-    train step on the GPU against tests/golden/full_train_512_bs4.safetensors -- prediction, loss, the four control maps
-    (strided sample + norm), the flat 6,047,040-element gradient (strided sample, norm, per-parameter norms)."""
+def train_step_vs_fixture(dev, fixture="full_train_512_bs4.safetensors"):
+    """BASELINE configs[1] (configs/fill50k.json, SD-1.5 topology, 512x512, batch 4; reference train...:751-796) -- or, with
+    fixture="full_train_512_bs8_v2.safetensors", BASELINE configs[3] as quoted (configs/mpii-pose-v2.json, batch 8; reference
+    models.py:292-431): the product train step on the GPU against the committed oracle record -- prediction, loss, the four
+    control maps (two strided samples with coprime strides + norm), the flat gradient of every trainable parameter (two strided
+    samples, norm, per-parameter norms)."""
     from oracle import cases as ocases
-    fx, meta = load_fixture("full_train_512_bs4.safetensors")
+    fx, meta = load_fixture(fixture)
     sg, sc = int(meta["stride_grad"]), int(meta["stride_ctrl"])
     o_unet, o_clora, p_unet, p_clora = build_pair(meta["config"], dev)
     assert torch.allclose(ocases.weight_checksum(o_unet), fx["weights_checksum_unet"].double(), rtol=1e-9), "seeded UNet weights differ"
@@ -270,9 +272,13 @@ def train_step_vs_fixture(dev):
             "loss": abs(trainer.loss(pred.numel()) - float(fx["loss"])) / float(fx["loss"]),
             "grads_sample": rel(grads[::sg], fx["grads_sample"]),
             "grads_norm": abs(float(grads.double().norm()) - float(fx["grads_norm"])) / float(fx["grads_norm"])}
+    if "grads_sample2" in fx:                           # second sample, coprime stride (round 4)
+        errs["grads_sample2"] = rel(grads[::int(meta["stride_grad2"])], fx["grads_sample2"])
     for i, c in enumerate(p_clora(inp["guide"].to(dev).to(f16)).control_states):
         c = c.float().cpu()                              # NCHW view: same element order as the oracle's maps
         errs[f"control_{i}"] = rel(c.reshape(-1)[::sc], fx[f"control_{i}_sample"])
+        if f"control_{i}_sample2" in fx:
+            errs[f"control_{i}_s2"] = rel(c.reshape(-1)[::int(meta["stride_ctrl2"])], fx[f"control_{i}_sample2"])
         errs[f"control_{i}_norm"] = abs(float(c.double().norm()) - float(fx[f"control_{i}_norm"])) / float(fx[f"control_{i}_norm"])
     # per-parameter gradient norms: an error confined to one small tensor cannot hide inside the global rel-L2
     names = meta["param_names"].split("\n")
@@ -285,6 +291,75 @@ def train_step_vs_fixture(dev):
     errs["param_norm_small_abs_worst"] = float(((got - want).abs()[~big]).max() / want.max()) if bool((~big).any()) else 0.0
     errs["n_params"] = len(names)
     errs["oracle_seconds"] = float(fx["oracle_seconds"])
+    errs["clora_impl"] = meta.get("clora_impl", "restatement")
+    return errs
+
+
+class _StopSampling(Exception):
+    pass
+
+
+def infer32_vs_fixture(dev):
+    """BASELINE config 5 at its OWN batch (reference apps/gradio_canny2image.py:83-89: 16 images => UNet batch 32, one guide
+    broadcast over the batch, 50-step DDIM schedule, CFG 9.0, 512x512): the product's first UNet evaluation (all 32 samples) and
+    the latents after scheduler steps 1 and 5, replayed from its hipGraph as shipped, vs tests/golden/full_infer_512_b32.safetensors.
+    These are the M = 131072 / 32768 / 8192 / 2048 launch-table entries end to end."""
+    from controllora_amd.pipeline import ddim_sample
+    from oracle import cases as ocases
+    from oracle.make_fullsize_golden import infer32_inputs
+    fx, meta = load_fixture("full_infer_512_b32.safetensors")
+    o_unet, o_clora, p_unet, p_clora = build_pair(meta["config"], dev)
+    assert torch.allclose(ocases.weight_checksum(o_unet), fx["weights_checksum_unet"].double(), rtol=1e-9)
+    assert torch.allclose(ocases.weight_checksum(o_clora), fx["weights_checksum_clora"].double(), rtol=1e-9)
+    guide, cond, uncond, lat0 = infer32_inputs(int(meta["res"]), int(meta["images"]), int(meta["input_seed"]))
+    for k, v in (("guide", guide), ("cond", cond), ("uncond", uncond), ("lat0", lat0)):
+        _assert_same_inputs(fx, f"in_{k}_checksum", v)
+    keep = [int(k) for k in meta["keep"].split(",")]
+    traj = {}
+
+    def cb(i, x, eps):
+        traj[i] = (x.float().cpu().clone(), eps.float().cpu().clone() if i == 1 else None)
+        if i >= max(keep):
+            raise _StopSampling()
+
+    try:
+        ddim_sample(p_unet, p_clora, guide.to(dev).half(), cond.to(dev).half(), uncond.to(dev).half(), steps=int(meta["steps"]),
+                    guidance_scale=float(meta["guidance_scale"]), latents=lat0.to(dev).half(), graph=True, callback=cb)
+    except _StopSampling:
+        pass
+    errs = {"eps_step01": rel(traj[1][1], fx["eps_step01"]), "unet_batch": int(traj[1][1].shape[0]),
+            "oracle_seconds": float(fx["oracle_seconds"])}
+    per = (traj[1][1] - fx["eps_step01"]).flatten(1).norm(dim=1) / fx["eps_step01"].flatten(1).norm(dim=1)
+    errs["eps_step01_worst_sample"] = float(per.max())                   # no single sample of the 32 may hide in the batch norm
+    for i in keep:
+        errs[f"latents_step{i:02d}"] = rel(traj[i][0], fx[f"latents_step{i:02d}"])
+    return errs
+
+
+def vae_512_vs_fixture(dev):
+    """SD-1.5 VAE topology at 512x512, batch 1 (reference train...:753-754 encode, apps/gradio_canny2image.py:88-92 decode): the
+    W = 512 / 256 implicit-GEMM conv path with M = 262144 rows, the 4096-token mid-block attention -- product vs the committed
+    outputs of oracle/vae_ref.py."""
+    from controllora_amd import vae as V
+    from oracle import cases as ocases
+    from oracle.make_fullsize_golden import vae_inputs, vae_oracle
+    fx, meta = load_fixture("full_vae_512.safetensors")
+    o = vae_oracle(int(meta["seed"]))
+    x, eps = vae_inputs(int(meta["res"]), int(meta["batch"]))
+    assert torch.allclose(ocases.weight_checksum(o), fx["weights_checksum"].double(), rtol=1e-9), "seeded VAE weights differ"
+    _assert_same_inputs(fx, "in_x_checksum", x)
+    _assert_same_inputs(fx, "in_eps_checksum", eps)
+    m = V.AutoencoderKL(**V.SD15_VAE)
+    V.load_from_oracle_(m, o)
+    m.to(dev)
+    with torch.no_grad():
+        dist = m.encode(x.to(dev).half()).latent_dist
+        errs = {"mean": rel(dist.mean, fx["mean"]), "logvar": rel(dist.logvar, fx["logvar"]),
+                "sample": rel(dist.sample(noise=eps.to(dev)), fx["z"])}
+        img = m.decode(fx["z"].to(dev).half()).sample.float().cpu().reshape(-1)
+    errs["decode"] = rel(img[::int(meta["stride"])], fx["img_sample"])
+    errs["decode_s2"] = rel(img[::int(meta["stride2"])], fx["img_sample2"])
+    errs["decode_norm"] = abs(float(img.double().norm()) - float(fx["img_norm"])) / float(fx["img_norm"])
     return errs
 
 

@@ -87,6 +87,70 @@ def case_gemm_epilogue_no_rowadd(dev, M=300, N=320, K_=128, tile_cfg=0, split_k=
     assert rel(out, base.half().float() + res.float()) < 6e-4
 
 
+def case_gemm_fused_down(dev, M=150, N=320, K_=128, nseg=1, tile_cfg=0, u_tr=False, t_in_rows=None, bias=True, residual=True):
+    """clora_epilogue_t.lora_dpack: the rank-4 adapter down-projection T = A . D^T evaluated inside the projection GEMM
+    (reference models.py:232-282: `attn.to_x(h) + scale * to_x_lora(h)`).  Checks (a) the T the launch WRITES against fp64
+    A . D^T (+ the precomputed part) and against the stand-alone clora_lora_down kernel, (b) the GEMM output against the
+    unfused formula, elementwise, (c) bit-identical repeat launches.  t_in_rows: None = no precomputed part, 0 = one row per GEMM
+    row, > 0 = broadcast rows (control batch 1).  nseg column segments of N / nseg columns (a multiple of 320)."""
+    from controllora_amd import ops
+    g = torch.Generator().manual_seed(43)
+    A, B = rnd((M, K_), dev, g), rnd((N, K_), dev, g, 1 / math.sqrt(K_))
+    bias_t = rnd((N,), dev, g, dtype=f32) if bias else None
+    res = rnd((M, N), dev, g) if residual else None
+    seg_w = N // nseg
+    Ds = [rnd((4, K_), dev, g, 1 / math.sqrt(K_), dtype=f32) for _ in range(nseg)]
+    if u_tr:
+        assert nseg == 1
+        U = rnd((4, N), dev, g, dtype=f32)
+    else:
+        U = rnd((N, 4), dev, g, dtype=f32)
+    t_in, mask = None, 0
+    if t_in_rows is not None:
+        rows = t_in_rows or M
+        t_in = rnd((rows, 4 * nseg), dev, g, dtype=f32)
+        mask = 1                                                  # segment 0 only (the q adapter)
+    T_ref = torch.cat([A.double() @ D.double().T for D in Ds], 1)
+    if t_in is not None:
+        T_ref[:, :4] += (t_in.double().repeat(M // rows, 1) if rows != M else t_in.double())[:, :4]
+    pack = ops.ADAPTER_PACKS.get(Ds)
+    kw = dict(bias=bias_t, residual=res, lora_u=U, lora_seg=seg_w, lora_scale=0.7, lora_u_tr=u_tr, lora_r=4,
+              split_k=1, tile_cfg=tile_cfg, _tuned=False)
+    T = torch.full((M, 4 * nseg), float("nan"), dtype=f32, device=dev)
+    out = K.gemm(A, B, M, N, K_, lora_t=T, lora_dpack=pack, lora_t_in=t_in, lora_t_in_mask=mask,
+                 lora_t_in_rows=(t_in_rows or 0) if t_in is not None else 0, **kw)
+    eT = float((T.double().cpu() - T_ref.cpu()).norm() / T_ref.norm())
+    assert eT < 2e-6, f"T written by the fused launch: rel {eT:.2e}"
+    T2 = torch.empty_like(T)
+    for s_, D in enumerate(Ds):                                   # the stand-alone kernel computes the same quantity
+        K.lora_down(A, D, T2, 4 * s_, M, K_)
+    if t_in is None:
+        assert rel(T, T2) < 2e-6
+    seg = (torch.arange(N) // seg_w).tolist()
+    Tr = T_ref.float().to(dev)
+    if u_tr:
+        lora = Tr @ U
+    else:
+        lora = torch.stack([Tr[:, s_ * 4:(s_ + 1) * 4] @ U[n] for n, s_ in enumerate(seg)], 1)
+    ref = A.float() @ B.float().T + 0.7 * lora
+    if bias:
+        ref = ref + bias_t
+    ref = ref.half().float()
+    if residual:
+        ref = ref + res.float()
+    assert rel(out, ref) < 6e-4
+    no_outliers(out, ref, "fused down-projection")
+    T3 = torch.empty_like(T)
+    again = K.gemm(A, B, M, N, K_, lora_t=T3, lora_dpack=pack, lora_t_in=t_in, lora_t_in_mask=mask,
+                   lora_t_in_rows=(t_in_rows or 0) if t_in is not None else 0, **kw)
+    assert torch.equal(out, again) and torch.equal(T, T3), "the same launch twice must give the same bits"
+    # the unfused launch fed with the T the fused one wrote gives the same output bits (same epilogue arithmetic)
+    kw["tile_cfg"] = tile_cfg if tile_cfg in (51, 52, 54, 55) else (54 if M >= 32768 else 55)     # the tile the fused launch ran on
+    unf = K.gemm(A, B, M, N, K_, lora_t=T, **kw)
+    assert rel(unf, out) < 1e-6 or torch.equal(unf, out)
+    return eT
+
+
 def case_conv(dev, Bn, H, W, Ci, Co, stride=1, pad=1, ups=False, asym=False, seed=2, tile_cfg=0, kchunk=0):
     """forward, dgrad and wgrad of one 3x3 conv configuration against F.conv2d autograd.
     kchunk > 0: forward and dgrad additionally run with the channel-chunk-major K order (clora_conv_t.kchunk)."""

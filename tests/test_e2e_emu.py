@@ -33,6 +33,54 @@ def test_trainer_accumulation_lr_schedule_and_resume(golden_dir):
     E.check_trainer_features("cpu", golden_dir, real_backward=False)
 
 
+def test_resume_from_an_accelerate_format_checkpoint(tmp_path):
+    """reference train_text_to_image_control_lora.py:713-735 (`accelerator.save_state`) / :705-722 (`load_state`): a `checkpoint-N`
+    directory in accelerate's layout -- pytorch_model.bin + the state_dict of a REAL torch.optim.AdamW built from
+    `control_lora.parameters()` + GradScaler / LambdaLR state -- resumes the flat trainer: same moments, same step count, and
+    the NEXT optimizer step lands on the same parameters as torch's AdamW does.  Round trip through save_accelerate_state."""
+    from controllora_amd.train import ControlLoRATrainer
+    from oracle import cases
+    unet, clora, _ = E.build_product_case("v1", "cpu")
+    ref = __import__("copy").deepcopy(clora).float()
+    params = [p for p in ref.parameters()]
+    opt = torch.optim.AdamW(params, lr=1e-3, betas=(0.9, 0.999), weight_decay=1e-2, eps=1e-8)
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda s: 1.0)
+    g = torch.Generator().manual_seed(5)
+    for _ in range(3):
+        for p_ in params:
+            p_.grad = torch.randn(p_.shape, generator=g) * 1e-2
+        opt.step(); sched.step()
+    d = tmp_path / "checkpoint-3"
+    d.mkdir()
+    torch.save(ref.state_dict(), d / "pytorch_model.bin")
+    torch.save(opt.state_dict(), d / "optimizer.bin")
+    torch.save(sched.state_dict(), d / "scheduler.bin")
+    torch.save({"scale": 1024.0, "growth_factor": 2.0, "backoff_factor": 0.5, "growth_interval": 2000, "_growth_tracker": 7}, d / "scaler.pt")
+    tr = ControlLoRATrainer(unet, clora, lr=1e-3, max_grad_norm=0.0, dynamic_scale=False)
+    tr.load_state(str(d))
+    assert tr.global_step == 3 and float(tr.state[2]) == 3.0 and float(tr.state[3]) == 1024.0 and float(tr.state[4]) == 7.0
+    for (p_, off), q in zip(tr._module_order_views(), params):
+        assert torch.equal(p_.detach().cpu(), q.detach()), "weights"
+        assert torch.equal(tr.flat.exp_avg[off:off + q.numel()].cpu().reshape(q.shape), opt.state[q]["exp_avg"])
+        assert torch.equal(tr.flat.exp_avg_sq[off:off + q.numel()].cpu().reshape(q.shape), opt.state[q]["exp_avg_sq"])
+    # the next step: the same gradient through torch's AdamW and through the flat kernels (scaled by the loss scale)
+    tr.flat.zero_grad()
+    for (p_, off), q in zip(tr._module_order_views(), params):
+        q.grad = torch.randn(q.shape, generator=g) * 1e-2
+        p_.grad.copy_(q.grad * 1024.0)
+    opt.step()
+    tr._optimizer_kernels()
+    worst = max(float((p_.detach().cpu() - q.detach()).abs().max()) for (p_, _), q in zip(tr._module_order_views(), params))
+    assert worst < 2e-7, worst
+    # and back: what save_accelerate_state writes loads into a fresh torch AdamW
+    tr.save_accelerate_state(str(tmp_path / "checkpoint-4"))
+    opt2 = torch.optim.AdamW([torch.nn.Parameter(q.detach().clone()) for q in params], lr=1e-3)
+    opt2.load_state_dict(torch.load(tmp_path / "checkpoint-4" / "optimizer.bin"))
+    st = opt2.state_dict()["state"]
+    assert len(st) == len(params) and int(st[0]["step"]) == 4
+    assert torch.allclose(st[0]["exp_avg"], opt.state[params[0]]["exp_avg"], atol=1e-8)
+
+
 def test_vae_encode_decode_matches_oracle():
     from tests import vae_cases
     print(vae_cases.check_vae("cpu", res=32, batch=1))
@@ -81,7 +129,7 @@ def test_ddim_text_kv_cache_is_exact():
     a = ddim_sample(*args, steps=3, guidance_scale=5.0, latents=inp["latents"][:1].half(), cache_text_kv=False)
     calls = []
     orig = M.ops.lora_proj
-    M.ops.lora_proj = lambda x, pack, segs, residual=None: (calls.append(x.shape[0]), orig(x, pack, segs, residual))[1]
+    M.ops.lora_proj = lambda x, pack, segs, residual=None, **kw: (calls.append(x.shape[0]), orig(x, pack, segs, residual, **kw))[1]
     try:
         b = ddim_sample(*args, steps=3, guidance_scale=5.0, latents=inp["latents"][:1].half(), cache_text_kv=True)
     finally:

@@ -52,6 +52,15 @@ def test_gemm_epilogue_without_rowadd(tile):
     KC.case_gemm_epilogue_no_rowadd("cpu", M=70, N=144, K_=64, tile_cfg=tile)
 
 
+@pytest.mark.parametrize("kw", [dict(M=150, N=320, K_=128, tile_cfg=55), dict(M=150, N=320, K_=128, tile_cfg=52, t_in_rows=0),
+                                dict(M=140, N=640, K_=64, nseg=2, tile_cfg=55, t_in_rows=70), dict(M=200, N=960, K_=192, nseg=3, tile_cfg=54, t_in_rows=0),
+                                dict(M=130, N=320, K_=320, tile_cfg=51, u_tr=True, bias=False), dict(M=70, N=640, K_=64, nseg=1, tile_cfg=0, residual=False),
+                                dict(M=100, N=320, K_=128, tile_cfg=21)])
+def test_gemm_with_adapter_down_projection_in_the_launch(kw):
+    """clora_epilogue_t.lora_dpack on the 8-wave 320-column tiles (an incapable tile_cfg is replaced by the library's choice)"""
+    KC.case_gemm_fused_down("cpu", **kw)
+
+
 @pytest.mark.parametrize("order", ["n", "auto"])
 @pytest.mark.parametrize("tile", [21, 43, 53, 72, 76])
 def test_tile_order_does_not_change_results(tile, order):

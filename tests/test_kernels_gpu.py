@@ -76,6 +76,19 @@ def test_conv_patch_kernel_row_segments_vae_shapes(tile, Bn, H, W, Ci, Co):
     KC.case_conv_patch(DEV, Bn, H, W, Ci, Co, tile, fwd_only=True)
 
 
+@pytest.mark.parametrize("kw", [dict(M=16384, N=320, K_=320, tile_cfg=55), dict(M=16384, N=320, K_=320, tile_cfg=52, t_in_rows=0),
+                                dict(M=16384, N=320, K_=320, tile_cfg=54, t_in_rows=4096), dict(M=16384, N=320, K_=320, tile_cfg=51, u_tr=True, bias=False),
+                                dict(M=16384, N=960, K_=320, nseg=3, tile_cfg=0, t_in_rows=0), dict(M=32768, N=960, K_=320, nseg=3, tile_cfg=0, t_in_rows=4096),
+                                dict(M=4096, N=640, K_=640, tile_cfg=0, t_in_rows=0), dict(M=1024, N=1280, K_=1280, tile_cfg=0, u_tr=True, residual=False),
+                                dict(M=4099, N=1920, K_=640, nseg=3, tile_cfg=55, t_in_rows=0), dict(M=131072, N=320, K_=320, tile_cfg=0, t_in_rows=4096)])
+def test_gemm_with_adapter_down_projection_in_the_launch(kw):
+    """clora_epilogue_t.lora_dpack at the projection shapes of the step (level 0 q | k | v, out, cross-attention q; the deeper
+    levels; the batch-8 and batch-32 row counts; ragged M): T written == A . D^T, output == the unfused formula elementwise,
+    repeat launches bit-identical (reference models.py:232-282)"""
+    e = KC.case_gemm_fused_down(DEV, **kw)
+    print("FUSED_DOWN", kw, f"T rel {e:.2e}")
+
+
 @pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7, 8, 21, 22, 23, 26, 31, 32, 33, 41, 42, 43, 51, 52, 53, 54, 55, 56, 57, 58])
 def test_gemm_epilogue_without_rowadd(tile):
     """projection epilogues at real shapes (M = 16384 x N = 320 / 960, ragged variants): two-phase chunk loop of the 8-wave tiles"""
@@ -165,7 +178,7 @@ def _lora_down_mode_case(mode, M, Kd):
         again = torch.empty_like(T)
         K.lora_down_multi([K.down_job(X, D, again, 0, M, Kd, X2=X2, r2=4)])
     finally:
-        K.set_option("lora_down_mode", 0)
+        K.set_option("lora_down_mode", 1)                   # the library default
     assert KC.rel(T, ref) < 1e-5 and torch.equal(T, again), (mode, M, Kd, KC.rel(T, ref))
     KC.no_outliers(T, ref, f"lora_down mode {mode} M={M} K={Kd}")
 
