@@ -64,6 +64,9 @@ __device__ __forceinline__ half4v clora_ds_read_tr16(const half_t* lptr) {
 // (s_load needs a provably unclobbered address range; MemorySSA treats volatile asm as a write).  Only where the kept value
 // feeds a select, not a conditional block (a pure asm may be sunk together with its load).
 #define CLORA_KEEP_PURE(x) asm("" : "+v"(x))
+// acc += a * b as ONE v_fma_f32 the compiler cannot merge into a packed v_pk_fma_f32 (see hoisted_rank4 in clora_gemm.hip: the
+// packed form of that block produced sporadic wrong low-half results on MI355X when several workgroups shared a CU)
+#define CLORA_FMA_F32(acc, a, b) asm("v_fma_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b))
 #endif
 
 __device__ __forceinline__ floatx4 mfma16(half8 a, half8 b, floatx4 c) {

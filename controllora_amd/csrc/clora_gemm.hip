@@ -371,18 +371,23 @@ __device__ __attribute__((aligned(16))) const unsigned g_clora_zero16[4] = {0u, 
 // LDS (64 rows per pass) -> per row-chunk: bias / time-embedding / rank-r adapter update (float4 operand loads) -> fp16 ->
 // + residual (or the fused GEGLU forms) -> 16-byte coalesced stores.  NT threads = WM x WN waves, wave tile FM x FN MFMA tiles.
 // The rank-4 update of one 8-column chunk from registers: v[e] += sum_j t4[j] * u(e, j), with the up-matrix values of the thread's
-// column in `ureg` (TR: ureg[2j + (e >> 2)][e & 3], else ureg[e][j]).  CLORA_DIAG_SCALAR_FMA (diagnostic build): every multiply-add
-// is one explicit v_fma_f32, so the compiler cannot form v_pk_fma_f32 pairs here -- the experiment that separates "packed fp32
-// math in the hoisted epilogue" from everything else the hoist changes.
+// column in `ureg` (TR: ureg[2j + (e >> 2)][e & 3], else ureg[e][j]).
+// Every multiply-add is ONE explicit v_fma_f32 (CLORA_FMA_F32).  Written as plain C++ the block compiles to runs of dependent
+// v_pk_fma_f32 with op_sel broadcasts of t4[j], and THAT form is what produced the sporadic wrong elements of round 3 on MI355X
+// (profiles/r04_hoist_diag*.txt): only with two or three workgroups resident per CU, only in lanes 48..63,
+// only in the LOW half of a packed pair (chunk elements 0 / 2 / 4), with every s_waitcnt of the ISA in place; the same kernel is
+// clean with -mllvm -amdgpu-waitcnt-forcezero, with one workgroup per CU (larger LDS request, same instructions), with
+// -fno-slp-vectorize, and with nothing changed but this block forced to scalar FMAs.  -DCLORA_HOIST_PACKED_FMA restores the
+// packed form for diagnosis.
 template <bool TR>
 __device__ __forceinline__ void hoisted_rank4(float (&v)[8], const floatx4& t4, const floatx4 (&ureg)[8]) {
-#ifdef CLORA_DIAG_SCALAR_FMA
+#ifndef CLORA_HOIST_PACKED_FMA
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const float u = TR ? ureg[2 * j + (e >> 2)][e & 3] : ureg[e][j];
-            asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(v[e]) : "v"(t4[j]), "v"(u));
+            const float u = TR ? ureg[2 * j + (e >> 2)][e & 3] : ureg[e][j], tj = t4[j];
+            CLORA_FMA_F32(v[e], tj, u);
         }
 #else
     if (TR) {
@@ -453,14 +458,15 @@ __device__ __forceinline__ void dma_epilogue(const GemmArgs& p, floatx4 (&acc)[B
     constexpr bool HOIST_PAYS = HOIST && (BM * CPR / NT) >= 4 && (BM / WM / 16) * (BN / WN / 16) * 4 < 128;
     // the two-phase chunk loop (below) only where the register file has the room: the 8-wave tiles up to 128 rows (64x320, 128x320,
     // 128x256: one block per CU, 256 VGPRs per wave); the 256-row tiles and the 2-blocks-per-CU kernels would spill
-    // SMALL2 (the 64x64 BK = 64 tile: a thread owns two chunks of one column) is NOT enabled: with the hoisted U registers that kernel
-    // produced a handful of wrong elements per launch on MI355X at M = 16384, N = K = 320 -- sporadic, different on every run, rows
-    // 6 / 7 (mod 8) of a fragment, with the two-phase loop on AND off (profiles/r03_epi_diag.txt); the emulator and the 8-wave tiles
-    // are clean.  Not understood (164 VGPRs at 3 blocks per CU; no spills), so the 64x64 tile keeps the one-chunk-at-a-time epilogue.
-#ifdef CLORA_SMALL2_ON
-    constexpr bool SMALL2 = BM == 64 && BN == 64 && NT == 256 && NPASS == 1 && SMEM >= 24576;   // diagnostic build: the round-3 experiment as it was
+    // SMALL2: the 64x64 BK = 64 tile (4 waves; ~170 launches per step: out / proj / FF2 projections at the 32x32 .. 8x8 levels).  A thread
+    // owns TWO chunks of one column there; with its accumulators dead after the single staging pass, U, bias and both rows' T /
+    // residual chunks are one batch of loads instead of ~12 dependent ones per chunk.  Round 3 switched it off after it produced
+    // sporadic wrong elements on MI355X; round 4 traced those to the packed-fp32 form of the rank-4 update (hoisted_rank4 above),
+    // which is now explicit scalar FMAs -- the strict epilogue tests (no outlier element, bit-identical repeats) run over this tile.
+#ifdef CLORA_SMALL2_OFF
+    constexpr bool SMALL2 = false;                              // the round-3 state (A/B)
 #else
-    constexpr bool SMALL2 = false;
+    constexpr bool SMALL2 = BM == 64 && BN == 64 && NT == 256 && NPASS == 1 && SMEM >= 24576;
 #endif
     constexpr bool FIXED_COL = HOIST_PAYS || SMALL2;           // thread -> one fixed chunk column, rows t / CPR + it * RPIT
     static_assert(EXT == 0 || HOIST_PAYS, "EXT tiles take the fixed-column hoisted epilogue");
@@ -983,11 +989,12 @@ __global__ __launch_bounds__(WM * WN * 64, (DmaOcc<BM, BN, NST, BK, WM * WN>::v)
     // launches bit-identical) caught those variants -- 128x64 BK64 at 2 blocks per CU, and the 64x64 experiment at 3 -- producing a handful
     // of wrong elements per launch at M = 16384, N = K = 320 on hardware, sporadically; the one-block-per-CU kernels and the
     // non-hoisted epilogue are clean and bit-stable (profiles/r03_epi_diag*.txt, r03_gputest_11.log).  Cause not established.
-#ifdef CLORA_HOIST_ALL
-    // diagnostic build (tools/hoist_isa_diff.sh): the hoisted epilogue on every kernel built for <= 2 blocks per CU, as shipped in round 2
-    dma_epilogue<BM, BN, WM, WN, NT, SMEM, (NW > 4 || DmaOcc<BM, BN, NST, BK, NW>::v <= 2)>(p, acc, m0, n0, split, smem, t);
+#ifdef CLORA_HOIST_8WAVE_ONLY
+    dma_epilogue<BM, BN, WM, WN, NT, SMEM, (NW > 4)>(p, acc, m0, n0, split, smem, t);                   // the round-3 restriction (A/B)
 #else
-    dma_epilogue<BM, BN, WM, WN, NT, SMEM, (NW > 4)>(p, acc, m0, n0, split, smem, t);
+    // the hoisted epilogue on every kernel built for <= 2 blocks per CU (the round-2 scope), restored in round 4 with the scalar
+    // rank-4 update of hoisted_rank4
+    dma_epilogue<BM, BN, WM, WN, NT, SMEM, (NW > 4 || DmaOcc<BM, BN, NST, BK, NW>::v <= 2)>(p, acc, m0, n0, split, smem, t);
 #endif
 }
 

@@ -235,11 +235,15 @@ class _ControlMixin:
             self.control_states = ctrl
         b1, b2 = ctrl.shape[0], hidden_states.shape[0]
         if b1 != b2 and b1 != 1:
-            # the reference repeat-interleaves the control batch (models.py:209-213, 343-347: c0,c0,c1,c1,...) in the
-            # concat path and cannot broadcast at all in the plain path; the kernels broadcast by tiling, which is
-            # only the same thing for a control batch of 1 (quirk C6, the inference call pattern)
-            raise NotImplementedError(f"control batch {b1} vs UNet batch {b2}: only equal batches or a control batch of 1 "
-                                      "are supported")
+            # 1 < control batch < UNet batch.  The reference repeat-interleaves the control batch in the concat path
+            # (models.py:209-213, 343-347: c0,c0,c1,c1,...) and cannot broadcast at all in the plain path (`hidden + control`
+            # raises there).  The kernels broadcast by TILING, which is the same thing only for a control batch of 1 (quirk C6,
+            # the inference call pattern), so here the repeat-interleaved tensor is materialised -- concat path only, like the
+            # reference; autograd sums the copies' gradients back.
+            if not self.concat_hidden or b2 % b1:
+                raise ValueError(f"control batch {b1} vs UNet batch {b2}: the reference (models.py:237-238 `hidden_states + "
+                                 "process_control_states(...)`) broadcasts only equal batches or a control batch of 1 here")
+            ctrl = ctrl.repeat_interleave(b2 // b1, dim=0)
         return ctrl.contiguous()
 
     def process_control_states(self, hidden_states, scale=1.0, is_out=False):
@@ -282,6 +286,10 @@ class ControlLoRACrossAttnProcessor(_ControlMixin, LoRACrossAttnProcessor):
         else:
             # hidden + control term feeds ONLY the q adapter (models.py:237-238); Lq(h + c) = Lq(h) + Lq(c), so the sum is
             # never formed: h keeps one consumer (no autograd gradient add) and the q/k/v downs share their read of h
+            b1 = self.control_states.shape[0]
+            if b1 not in (1, B):               # the precomputed term would be TILED over the batch: only right for 1 (quirk C6)
+                raise ValueError(f"control batch {b1} vs UNet batch {B}: the reference (models.py:237-238 `hidden_states + "
+                                 "process_control_states(...)`) broadcasts only equal batches or a control batch of 1 here")
             c = getattr(self, "_control_term", None)
             if c is None or self._control_term_scale != float(scale):
                 ctrl = self._control_tokens(hidden_states)

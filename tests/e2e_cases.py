@@ -164,6 +164,28 @@ def check_inference_broadcast(case, dev, tol=6e-3):
     return errs
 
 
+def check_control_batch_repeat_interleave(case, dev, tol=6e-3):
+    """1 < control batch < UNet batch on the concat-hidden processors (v2 / sketch): the reference repeat-interleaves the control
+    batch (models.py:209-213, 343-347: guide 0 for samples 0-1, guide 1 for samples 2-3), the product materialises the same
+    tensor -- forward vs the oracle restatement; a tiled order (g0,g1,g0,g1) must NOT match.  The plain path raises like the
+    reference's broadcast does."""
+    inp = cases.seeded_inputs(batch=4)
+    o_unet, _, o_clora = cases.build_oracle_case(case)
+    unet, _, clora = build_product_case(case, dev)
+    guide = inp["guide"][:2]
+    with torch.no_grad():
+        o_clora(guide)
+        clora(guide.to(dev).to(f16))
+        ref = o_unet(inp["latents"], 501, inp["ehs"]).sample
+        out = unet(inp["latents"].to(dev).to(f16), 501, inp["ehs"].to(dev).to(f16)).sample
+        err = rel(out, ref)
+        o_clora(guide[[0, 1, 0, 1]])                  # what tiling would compute: explicitly permuted guides, batch 4
+        tiled = o_unet(inp["latents"], 501, inp["ehs"]).sample
+    assert err < tol, err
+    assert rel(tiled, ref) > 2 * err, ("the two orders must be distinguishable on this case", rel(tiled, ref), err)
+    return err
+
+
 def check_pre_post_chain(kind, dev, B=2, side=4, C=64, heads=4, ctx=48, ctrl_c=32, tol_y=4e-3, tol_dh=1e-2, tol_dc=2e-2, tol_w=3e-2):
     """pre_loras / post_loras chaining (reference models.py:232-243, 249-265, 276-282; mix_lora_and_control_lora.py:111-123):
     the product processors (unfused generic path) vs the oracle restatement -- site output, d(hidden), d(control) and

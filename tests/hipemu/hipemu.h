@@ -113,6 +113,7 @@ static inline hipemu_half4 hipemu_tr16(const void* p) {
 #define CLORA_RCP(x) (1.0f / (x))
 #define CLORA_KEEP(x) ((void)0)
 #define CLORA_KEEP_PURE(x) ((void)0)
+#define CLORA_FMA_F32(acc, a, b) ((acc) = fmaf((a), (b), (acc)))
 static inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }
 static inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v; return o; }
 static inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }

@@ -118,6 +118,22 @@ def test_inference_with_control_batch_broadcast(case):
     print(case, E.check_inference_broadcast(case, "cpu"))
 
 
+@pytest.mark.parametrize("case", ["v2", "sketch"])
+def test_control_batch_repeat_interleave(case):
+    print(case, E.check_control_batch_repeat_interleave(case, "cpu"))
+
+
+def test_control_batch_mismatch_raises_in_the_plain_path():
+    """reference models.py:237-238: `hidden_states + process_control_states(...)` cannot broadcast 2 control samples over 4"""
+    from oracle import cases
+    unet, _, clora = E.build_product_case("v1", "cpu")
+    inp = cases.seeded_inputs(batch=4)
+    with torch.no_grad():
+        clora(inp["guide"][:2].half())
+        with pytest.raises((ValueError, RuntimeError, AssertionError)):
+            unet(inp["latents"].half(), 501, inp["ehs"].half())
+
+
 def test_ddim_text_kv_cache_is_exact():
     """the per-loop cache of the cross-attention K/V projections (pipeline.ddim_sample) changes nothing but the work"""
     from controllora_amd import models as M

@@ -20,6 +20,8 @@ ap.add_argument("--merge", action="store_true", help="keep the entries already i
 ap.add_argument("--cfgs", default="", help="comma list of tile_cfg values to sweep instead of the full set (with --merge the current "
                 "table entry of a signature is timed too and only replaced by a faster candidate)")
 ap.add_argument("--plain-only", action="store_true", help="only the plain (non-conv) GEMM signatures")
+ap.add_argument("--vae", type=int, default=0, metavar="B", help="tune the GEMM / conv signatures of the SD-1.5 VAE instead (encode + decode "
+                "of B images at --res: reference train...:753-754, apps/gradio_canny2image.py:88-92); implies --merge")
 ap.add_argument("--patch-only", action="store_true", help="only the signatures the patch-staged 3x3 conv kernel can take (tile_cfg 71..75)")
 args = ap.parse_args()
 dev = torch.device("cuda", 0)
@@ -50,7 +52,16 @@ def rec(A, Bw, M, N, Kd, **kw):
     return orig(A, Bw, M, N, Kd, **kw)
 K.gemm = rec
 import controllora_amd.ops as ops
-trainer.step(noisy, batch["timesteps"], batch["ehs"], batch["guide"], batch["noise"])
+if args.vae:
+    from controllora_amd import vae as V
+    args.merge, args.infer_batch = True, 0
+    vm = V.AutoencoderKL(**V.SD15_VAE); V.init_random_(vm, 1); vm.to(dev)
+    with torch.no_grad():
+        xv = (torch.rand(args.vae, 3, args.res, args.res, device=dev) * 2 - 1).half()
+        zv = vm.encode(xv).latent_dist.sample()
+        vm.decode(zv.half())
+else:
+    trainer.step(noisy, batch["timesteps"], batch["ehs"], batch["guide"], batch["noise"])
 if args.infer_batch > 0:
     with torch.no_grad():
         nb = args.infer_batch
