@@ -52,7 +52,15 @@ class LoraDownJob(C.Structure):
     _fields_ = [("X", C.c_void_p), ("ldx", C.c_int), ("D", C.c_void_p), ("ldd", C.c_int), ("T", C.c_void_p), ("ldt", C.c_int),
                 ("toff", C.c_int), ("M", C.c_int), ("K", C.c_int), ("R", C.c_int), ("accumulate", C.c_int), ("x_rows", C.c_int),
                 ("d_kmajor", C.c_int), ("d_scale", C.c_float), ("X2", C.c_void_p), ("ldx2", C.c_int), ("x2_rows", C.c_int),
-                ("r2", C.c_int)]
+                ("r2", C.c_int), ("T_in", C.c_void_p), ("ldt_in", C.c_int), ("t_in_rows", C.c_int), ("t_in_r", C.c_int)]
+
+
+class RankSite(C.Structure):
+    """mirror of clora_rank_site_t"""
+    _fields_ = [("Dq", C.c_void_p), ("lddq", C.c_int), ("Uc", C.c_void_p), ("lduc", C.c_int), ("M", C.c_void_p),
+                ("Tc", C.c_void_p), ("ldtc", C.c_int), ("toff", C.c_int), ("Tq", C.c_void_p), ("ldtq", C.c_int),
+                ("dTc", C.c_void_p), ("lddtc", C.c_int), ("gDq", C.c_void_p), ("gUc", C.c_void_p),
+                ("rows", C.c_int), ("C", C.c_int), ("rc", C.c_int), ("scale", C.c_float)]
 
 
 class LoraUpJob(C.Structure):
@@ -93,6 +101,9 @@ _PROTOS = {
     "clora_lora_down_multi_f16": [C.POINTER(LoraDownJob), _I, _P],
     "clora_lora_wgrad_multi_f16": [C.POINTER(LoraWgradJob), _I, _P, _Z, _P],
     "clora_lora_pack_f16": [_P, _I, _I, _P],
+    "clora_rank_compose_f32": [C.POINTER(RankSite), _I, _P],
+    "clora_rank_mix_f32": [C.POINTER(RankSite), _I, _I, _P, _Z, _P],
+    "clora_rank_compose_bwd_f32": [C.POINTER(RankSite), _I, _P, _P],
     "clora_lora_up_f16": [_P, _I, _P, _I, _I, _P, _I, _I, _P, _I, _I, _I, _I, _F, _P],
     "clora_lora_up_multi_f16": [C.POINTER(LoraUpJob), _I, _P],
     "clora_lora_wgrad_f16": [_P, _I, _P, _I, _I, _P, _I, _I, _I, _I, _I, _F, _I, _P, _Z, _P],
@@ -118,6 +129,7 @@ _PROTOS = {
     "clora_abi_version": [],
     "clora_groupnorm_workspace_bytes": [_I, _I, _I, _I, _I, _I],
     "clora_lora_wgrad_workspace_bytes": [_I, _I, _I],
+    "clora_rank_gram_ws_bytes": [_I, _I],
 }
 
 
@@ -139,6 +151,7 @@ class Lib:
         self.cdll.clora_build_info.restype = C.c_char_p
         self.cdll.clora_groupnorm_workspace_bytes.restype = C.c_size_t
         self.cdll.clora_lora_wgrad_workspace_bytes.restype = C.c_size_t
+        self.cdll.clora_rank_gram_ws_bytes.restype = C.c_size_t
         self._options_from_env()
 
     # The library reads no environment variable; A/B runs set its knobs (clora_set_option, the ABI's single piece of

@@ -119,7 +119,9 @@ __global__ __launch_bounds__(NW * 64) void lora_down_kernel(DownJobs jobs) {
             const int mm = m0 + 4 * g + r;
             if (mm < M) {
                 float* out = T + (size_t)mm * ldt + toff + li;
-                *out = p.accumulate ? *out + acc[r] : acc[r];
+                float v = acc[r];
+                if (p.T_in && li < p.t_in_r) v += p.T_in[(size_t)(p.t_in_rows > 0 ? mm % p.t_in_rows : mm) * p.ldt_in + li];
+                *out = p.accumulate ? *out + v : v;
             }
         }
     }
@@ -344,6 +346,7 @@ extern "C" int clora_lora_down_multi_f16(const clora_lora_down_job_t* jobs, int 
         const clora_lora_down_job_t& j = jobs[i];
         if (!j.X || !j.D || !j.T || j.M <= 0 || j.K <= 0 || j.R <= 0 || j.R > 16 || (j.K & 7) || (j.ldx & 7)) return CLORA_ERR_ARG;
         if (j.X2 && (j.ldx2 & 7)) return CLORA_ERR_ARG;
+        if (j.T_in && (j.t_in_r <= 0 || j.t_in_r > j.R || j.t_in_rows < 0)) return CLORA_ERR_ARG;
         if (!j.d_kmajor && ((j.ldd & 3) || ((uintptr_t)j.D & 15))) return CLORA_ERR_ARG;
         dj.j[i] = j;
         if (j.M > maxM) maxM = j.M;
@@ -375,6 +378,7 @@ extern "C" int clora_lora_down_f16(const clora_half* X, int ldx, const float* D,
         j.X = X; j.ldx = ldx; j.D = d_kmajor ? D + r0 : (D ? D + (size_t)r0 * ldd : D); j.ldd = ldd; j.T = T; j.ldt = ldt;
         j.toff = toff + r0; j.M = M; j.K = K; j.R = (R - r0 < 16) ? R - r0 : 16; j.accumulate = accumulate;
         j.x_rows = x_rows; j.d_kmajor = d_kmajor; j.d_scale = d_scale; j.X2 = nullptr; j.ldx2 = 0; j.x2_rows = 0; j.r2 = 0;
+        j.T_in = nullptr; j.ldt_in = 0; j.t_in_rows = 0; j.t_in_r = 0;
         const int rc = clora_lora_down_multi_f16(&j, 1, stream);
         if (rc != CLORA_OK) return rc;
     }
@@ -505,6 +509,188 @@ __global__ __launch_bounds__(256) void lora_pack_kernel(const clora_lora_pack_jo
 extern "C" int clora_lora_pack_f16(const clora_lora_pack_job_t* table, int njobs, int max_k, void* stream) {
     if (!table || njobs <= 0 || njobs > 65535 || max_k <= 0) return CLORA_ERR_ARG;
     hipLaunchKernelGGL(lora_pack_kernel, dim3(clora_cdiv(max_k, 256), njobs), dim3(256), 0, (hipStream_t)stream, table, njobs);
+    return clora_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------------
+// The v1 control term in rank space (include/clora.h, clora_rank_*): 4 x r_c matrices and [rows, 4] / [rows, r_c] tensors only.
+namespace {
+constexpr int kRankMaxSites = 16, kRankMixRows = 256;      // rows of one rank_mix block (= one partial Gram sum)
+struct RankSites { clora_rank_site_t s[kRankMaxSites]; };
+
+// M[j, i] = scale * sum_c Dq[j, c] * Uc[c, i]: one block per site, threads stride over c, fixed-order LDS fold
+__global__ __launch_bounds__(256) void rank_compose_kernel(RankSites a) {
+    const clora_rank_site_t& p = a.s[blockIdx.x];
+    __shared__ float red[256][33];
+    const int t = threadIdx.x, rc = p.rc;
+    float acc[32];
+#pragma unroll
+    for (int q = 0; q < 32; ++q) acc[q] = 0.f;
+    for (int c = t; c < p.C; c += 256) {
+        float d[4], u[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) d[j] = p.Dq[(size_t)j * p.lddq + c];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) u[i] = i < rc ? p.Uc[(size_t)c * p.lduc + i] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[j * 8 + i] += d[j] * u[i];
+    }
+#pragma unroll
+    for (int q = 0; q < 32; ++q) red[t][q] = acc[q];
+    __syncthreads();
+    if (t < 32) {
+        float s = 0.f;
+        for (int r = 0; r < 256; ++r) s += red[r][t];
+        const int j = t >> 3, i = t & 7;
+        if (i < rc) p.M[j * rc + i] = p.scale * s;
+    }
+}
+
+// forward: Tq = Tc_l . M^T.  backward: dTc_l = dTq . M and this block's partial Gram sum G[j, i] = sum_m dTq[m, j] Tc[m, i].
+template <bool BWD>
+__global__ __launch_bounds__(256) void rank_mix_kernel(RankSites a, float* gram_ws, int nblk) {
+    const clora_rank_site_t& p = a.s[blockIdx.y];
+    __shared__ float red[256][33];
+    const int t = threadIdx.x, rc = p.rc, m = blockIdx.x * kRankMixRows + t;
+    float Mv[32];
+#pragma unroll
+    for (int q = 0; q < 32; ++q) Mv[q] = ((q & 7) < rc) ? p.M[(q >> 3) * rc + (q & 7)] : 0.f;
+    float g[32];
+#pragma unroll
+    for (int q = 0; q < 32; ++q) g[q] = 0.f;
+    if (m < p.rows) {
+        float tc[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) tc[i] = i < rc ? p.Tc[(size_t)m * p.ldtc + p.toff + i] : 0.f;
+        if (!BWD) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float s = 0.f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) s += tc[i] * Mv[j * 8 + i];
+                p.Tq[(size_t)m * p.ldtq + j] = s;
+            }
+        } else {
+            float dq[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dq[j] = p.Tq[(size_t)m * p.ldtq + j];
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (i < rc) {
+                    float s = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) s += dq[j] * Mv[j * 8 + i];
+                    p.dTc[(size_t)m * p.lddtc + p.toff + i] = s;
+                }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) g[j * 8 + i] = dq[j] * tc[i];
+        }
+    }
+    if (BWD) {
+#pragma unroll
+        for (int q = 0; q < 32; ++q) red[t][q] = g[q];
+        __syncthreads();
+        if (t < 32) {
+            float s = 0.f;
+            for (int r = 0; r < 256; ++r) s += red[r][t];          // fixed order: deterministic
+            gram_ws[((size_t)blockIdx.y * nblk + blockIdx.x) * 32 + t] = s;
+        }
+    }
+}
+
+// fold the partial Gram sums of a site (fixed order) and accumulate gUc[c, i] += scale * sum_j Dq[j, c] G[j, i],
+// gDq[j, c] += scale * sum_i G[j, i] Uc[c, i]
+__global__ __launch_bounds__(256) void rank_compose_bwd_kernel(RankSites a, const float* gram_ws, int nblk) {
+    const clora_rank_site_t& p = a.s[blockIdx.y];
+    __shared__ float G[32];
+    const int t = threadIdx.x, rc = p.rc;
+    if (t < 32) {
+        float s = 0.f;
+        const int nb = (p.rows + kRankMixRows - 1) / kRankMixRows;
+        for (int b = 0; b < nb; ++b) s += gram_ws[((size_t)blockIdx.y * nblk + b) * 32 + t];
+        G[t] = s * p.scale;
+    }
+    __syncthreads();
+    for (int c = blockIdx.x * 256 + t; c < p.C; c += gridDim.x * 256) {
+        float d[4], u[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) d[j] = p.Dq[(size_t)j * p.lddq + c];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) u[i] = i < rc ? p.Uc[(size_t)c * p.lduc + i] : 0.f;
+        if (p.gUc) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (i < rc) {
+                    float s = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) s += d[j] * G[j * 8 + i];
+                    p.gUc[(size_t)c * p.lduc + i] += s;
+                }
+        }
+        if (p.gDq) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float s = 0.f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) s += G[j * 8 + i] * u[i];
+                p.gDq[(size_t)j * p.lddq + c] += s;
+            }
+        }
+    }
+}
+
+int rank_check(const clora_rank_site_t* sites, int n, RankSites& a) {
+    if (!sites || n <= 0 || n > kRankMaxSites) return CLORA_ERR_ARG;
+    for (int i = 0; i < n; ++i) {
+        const clora_rank_site_t& p = sites[i];
+        if (!p.Dq || !p.Uc || !p.M || p.rc <= 0 || p.rc > 8 || p.C <= 0 || p.rows <= 0) return CLORA_ERR_ARG;
+        a.s[i] = p;
+    }
+    return CLORA_OK;
+}
+}  // namespace
+
+extern "C" int clora_rank_compose_f32(const clora_rank_site_t* sites, int n, void* stream) {
+    RankSites a;
+    if (rank_check(sites, n, a) != CLORA_OK) return CLORA_ERR_ARG;
+    hipLaunchKernelGGL(rank_compose_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, a);
+    return clora_check_launch();
+}
+
+extern "C" size_t clora_rank_gram_ws_bytes(int rows, int n) {
+    if (rows <= 0 || n <= 0) return 0;
+    return (size_t)n * ((rows + kRankMixRows - 1) / kRankMixRows) * 32 * sizeof(float);
+}
+
+extern "C" int clora_rank_mix_f32(const clora_rank_site_t* sites, int n, int backward, float* gram_ws, size_t gram_ws_bytes, void* stream) {
+    RankSites a;
+    if (rank_check(sites, n, a) != CLORA_OK) return CLORA_ERR_ARG;
+    int rows = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!sites[i].Tc || !sites[i].Tq || (backward && !sites[i].dTc)) return CLORA_ERR_ARG;
+        rows = sites[i].rows > rows ? sites[i].rows : rows;
+    }
+    const int nblk = (rows + kRankMixRows - 1) / kRankMixRows;
+    if (backward) {
+        if (!gram_ws || gram_ws_bytes < clora_rank_gram_ws_bytes(rows, n)) return CLORA_ERR_WORKSPACE;
+        hipLaunchKernelGGL(rank_mix_kernel<true>, dim3(nblk, n), dim3(256), 0, (hipStream_t)stream, a, gram_ws, nblk);
+    } else {
+        hipLaunchKernelGGL(rank_mix_kernel<false>, dim3(nblk, n), dim3(256), 0, (hipStream_t)stream, a, (float*)nullptr, nblk);
+    }
+    return clora_check_launch();
+}
+
+extern "C" int clora_rank_compose_bwd_f32(const clora_rank_site_t* sites, int n, const float* gram_ws, void* stream) {
+    RankSites a;
+    if (rank_check(sites, n, a) != CLORA_OK || !gram_ws) return CLORA_ERR_ARG;
+    int rows = 0, C = 0;
+    for (int i = 0; i < n; ++i) { rows = sites[i].rows > rows ? sites[i].rows : rows; C = sites[i].C > C ? sites[i].C : C; }
+    const int nblk = (rows + kRankMixRows - 1) / kRankMixRows;
+    hipLaunchKernelGGL(rank_compose_bwd_kernel, dim3(clora_cdiv(C, 256), n), dim3(256), 0, (hipStream_t)stream, a, gram_ws, nblk);
     return clora_check_launch();
 }
 

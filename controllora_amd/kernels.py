@@ -377,6 +377,36 @@ def lora_pack(table: torch.Tensor, njobs: int, max_k: int):
     _call("clora_lora_pack_f16", ptr(table), njobs, max_k)
 
 
+def rank_site(Dq, Uc, Mbuf, Tc, toff, Tq, rows, scale, dTc=None, gDq=None, gUc=None):
+    """one site of the rank-space control term (clora_rank_site_t)"""
+    assert Dq.dtype == f32 and Uc.dtype == f32 and Dq.shape[0] == 4 and Dq.stride(1) == 1 and Uc.stride(1) == 1 and Tq.stride(1) == 1
+    return capi.RankSite(ptr(Dq), Dq.stride(0), ptr(Uc), Uc.stride(0), ptr(Mbuf), ptr(Tc), Tc.stride(0), toff, ptr(Tq), Tq.stride(0),
+                         ptr(dTc) if dTc is not None else None, dTc.stride(0) if dTc is not None else 0,
+                         ptr(gDq) if gDq is not None else None, ptr(gUc) if gUc is not None else None,
+                         rows, Dq.shape[1], Uc.shape[1], float(scale))
+
+
+def rank_compose(sites):
+    arr = (capi.RankSite * len(sites))(*sites)
+    _call("clora_rank_compose_f32", arr, len(sites))
+
+
+def rank_mix(sites, backward=False, device=None):
+    """forward: Tq = Tc_l . M_l^T; backward: dTc_l = dTq . M_l plus the partial Gram sums -> returns the workspace holding them"""
+    arr = (capi.RankSite * len(sites))(*sites)
+    ws = None
+    if backward:
+        rows = max(s_.rows for s_ in sites)
+        ws = torch.empty(capi.lib().cdll.clora_rank_gram_ws_bytes(rows, len(sites)) // 4, dtype=f32, device=device)
+    _call("clora_rank_mix_f32", arr, len(sites), int(backward), ptr(ws) if ws is not None else None, ws.numel() * 4 if ws is not None else 0)
+    return ws
+
+
+def rank_compose_bwd(sites, gram_ws):
+    arr = (capi.RankSite * len(sites))(*sites)
+    _call("clora_rank_compose_bwd_f32", arr, len(sites), ptr(gram_ws))
+
+
 def lora_down(X, D, T, toff, M, K, accumulate=False, x_rows=0, ldx=None, kmajor=False, R=None, d_scale=1.0):
     """T[:, toff:toff+R] (+)= X . (d_scale * D)^T ; X [rows, K] fp16 (row pitch ldx), T [M, ldt] fp32.
     D is [R, K] fp32, or with kmajor=True an up-projection matrix [K, R] used as its own transpose."""
@@ -387,14 +417,21 @@ def lora_down(X, D, T, toff, M, K, accumulate=False, x_rows=0, ldx=None, kmajor=
     return T
 
 
-def down_job(X, D, T, toff, M, K, accumulate=False, x_rows=0, ldx=None, kmajor=False, R=None, d_scale=1.0, X2=None, x2_rows=0, r2=0):
+def down_job(X, D, T, toff, M, K, accumulate=False, x_rows=0, ldx=None, kmajor=False, R=None, d_scale=1.0, X2=None, x2_rows=0, r2=0,
+             T_in=None, t_in_r=0):
     """one problem of lora_down_multi (same arguments as lora_down; rank <= 16); X2: second input, T = (X + X2) . D^T;
-    r2 > 0: X2 feeds only the first r2 rows of D (several adapters sharing X stacked into this one job)"""
+    r2 > 0: X2 feeds only the first r2 rows of D (several adapters sharing X stacked into this one job);
+    T_in (fp32 [rows, >= t_in_r]): added to the first t_in_r output columns (row m reads m % rows when rows != M)"""
     assert D.dtype == f32 and D.stride(1) == 1 and T.dtype == f32 and T.stride(1) == 1
     rank = R if R is not None else (D.shape[1] if kmajor else D.shape[0])
+    tin_rows = 0
+    if T_in is not None:
+        assert T_in.dtype == f32 and T_in.stride(1) == 1 and t_in_r > 0
+        tin_rows = T_in.shape[0] if T_in.shape[0] != M else 0
     return capi.LoraDownJob(ptr(X, f16), ldx if ldx is not None else X.stride(0), ptr(D), D.stride(0), ptr(T), T.stride(0), toff,
                             M, K, rank, int(accumulate), x_rows, int(kmajor), float(d_scale),
-                            ptr(X2, f16) if X2 is not None else None, X2.stride(0) if X2 is not None else 0, x2_rows, int(r2))
+                            ptr(X2, f16) if X2 is not None else None, X2.stride(0) if X2 is not None else 0, x2_rows, int(r2),
+                            ptr(T_in) if T_in is not None else None, T_in.stride(0) if T_in is not None else 0, tin_rows, int(t_in_r))
 
 
 def up_job(base, T, toff, U, Y, M, N, scale, u_tr=False):

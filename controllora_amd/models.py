@@ -169,11 +169,13 @@ class LoRACrossAttnProcessor(nn.Module):
             out = ops.add(out, _flat2(residual))
         return out.reshape(B, N, C_)
 
-    def _attend(self, attn, h2, q_in, e2, B, N, Nk, scale, out_in_fn, residual, own_out_always):
+    def _attend(self, attn, h2, q_in, e2, B, N, Nk, scale, out_in_fn, residual, own_out_always, t_pre=None):
         packs = attn.fused_packs()
-        # the control term's share of the q adapter's down-projection, evaluated for the whole level in one launch
-        # (_batched_control_terms); only meaningful when q_in = (h, c) with that very c
-        t_pre = getattr(self, "_control_T", None) if (isinstance(q_in, tuple) and len(q_in) == 2 and q_in[1] is getattr(self, "_control_term", None)) else None
+        # t_pre: the control term's share of the q adapter's down-projection -- in rank space (ops.control_terms_rank: q_in is
+        # the hidden states alone then), or, with the materialised term (q_in = (h, c)), c . D_q^T evaluated for the whole level
+        # in one launch (ops.control_q_parts; only meaningful with that very c)
+        if t_pre is None and isinstance(q_in, tuple) and len(q_in) == 2 and q_in[1] is getattr(self, "_control_term", None):
+            t_pre = getattr(self, "_control_T", None)
         if attn.is_cross:
             q = ops.lora_proj(h2, packs[0], [self._seg("to_q_lora", q_in, scale)], t_pre=t_pre[:, :4] if t_pre is not None else None)
             cache = _TEXT_KV if not torch.is_grad_enabled() else None
@@ -291,6 +293,11 @@ class ControlLoRACrossAttnProcessor(_ControlMixin, LoRACrossAttnProcessor):
                 raise ValueError(f"control batch {b1} vs UNet batch {B}: the reference (models.py:237-238 `hidden_states + "
                                  "process_control_states(...)`) broadcasts only equal batches or a control batch of 1 here")
             c = getattr(self, "_control_term", None)
+            tq = getattr(self, "_control_T", None)
+            if c is None and tq is not None and self._control_term_scale == float(scale):
+                # rank-space control term (ops.control_terms_rank): the q adapter reads h alone and gets the term's share as t_pre
+                out = self._attend(attn, h2, h2, e2, B, N, Nk, scale, lambda a: a, residual, own_out_always=True, t_pre=tq)
+                return out.reshape(B, N, C_)
             if c is None or self._control_term_scale != float(scale):
                 ctrl = self._control_tokens(hidden_states)
                 c = ops.control_term(_flat2(ctrl), self.to_control.down.weight, self.to_control.up.weight, scale, B * N)
@@ -567,6 +574,12 @@ def _batched_control_terms(procs, c):
     sites = [p for p in procs if isinstance(p, ControlLoRACrossAttnProcessor) and not p.concat_hidden
              and not p._needs_generic_path() and p.to_control.down.weight.shape[0] <= 16]
     if len(sites) < 2 or len({tuple(p.to_control.down.weight.shape) + tuple(p.to_control.up.weight.shape) for p in sites}) != 1:
+        return
+    tri = [(p.to_control.down.weight, p.to_control.up.weight, p.to_q_lora.down.weight) for p in sites]
+    if ops.RANK_CONTROL and ops.rank_control_ok(tri):
+        # the terms stay in rank space: no [M, C] tensor per site, forward or backward (ops._ControlTermsRankFn)
+        for p, tq in zip(sites, ops.control_terms_rank(c.reshape(-1, c.shape[-1]), tri, 1.0)):
+            p.inject_control_term(None, 1.0, tq)
         return
     terms = ops.control_terms(c.reshape(-1, c.shape[-1]), [(p.to_control.down.weight, p.to_control.up.weight) for p in sites], 1.0)
     # rank-4 q adapters ride in their projection GEMM (ops._fusable); the GEMM streams h only, so the control term's share

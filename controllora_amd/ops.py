@@ -583,6 +583,7 @@ class _LoraProjFn(torch.autograd.Function):
             pi += 1
             rs = D.shape[0]
             assert len(xis) <= 2
+            tin = t_pre.detach() if (t_pre is not None and s == 0) else None     # rank-space share of segment 0 (the q adapter)
             if fused:
                 f_srcs.append(D.detach())
                 if len(xis) > 1:
@@ -591,7 +592,8 @@ class _LoraProjFn(torch.autograd.Function):
             elif rs <= 16:                            # both inputs of a summed adapter input go through ONE job
                 x2 = xas[xis[1]] if len(xis) > 1 else None          # may hold fewer rows (control batch 1 broadcast, quirk C6)
                 dspecs.append(dict(X=xas[xis[0]], D=D.detach(), toff=s * r, R=rs, X2=x2, r2=0,
-                                   x2_rows=x2.shape[0] if (x2 is not None and x2.shape[0] != M) else 0))
+                                   x2_rows=x2.shape[0] if (x2 is not None and x2.shape[0] != M) else 0,
+                                   T_in=tin, t_in_r=rs if tin is not None else 0))
             else:
                 for n_in, xi in enumerate(xis):       # separate launches: stream order makes the accumulation safe
                     K.lora_down(xas[xi], D.detach(), T, s * r, M, D.shape[1], accumulate=n_in > 0)
@@ -602,13 +604,16 @@ class _LoraProjFn(torch.autograd.Function):
             info.append((xis, sc, rs))
         if dspecs:                                    # every adapter down-projection of this GEMM in one launch,
             K.lora_down_multi([K.down_job(j["X"], j["D"], T, j["toff"], M, j["D"].shape[1], X2=j["X2"], x2_rows=j["x2_rows"],
-                                          R=j["R"], r2=j["r2"]) for j in _merge_down_jobs(dspecs)])   # adapters sharing x in one pass
+                                          R=j["R"], r2=j["r2"], T_in=j.get("T_in"), t_in_r=j.get("t_in_r", 0))
+                               for j in _merge_down_jobs(dspecs)])   # adapters sharing x in one pass
         U = _stack_rows(pieces)
         if fused:
             # the part of T that does not come from x (the control term's share of the q adapter, L_q(h + c) = L_q(h) + L_q(c)):
             # handed in precomputed for the whole level (models._batched_control_terms) or evaluated here on the small input
             t_in, t_in_rows = None, 0
-            if f_in:
+            if t_pre is not None and not f_in:                       # rank-space control term (ops.control_terms_rank)
+                t_in, t_in_rows, f_in_mask = t_pre.detach(), (t_pre.shape[0] if t_pre.shape[0] != M else 0), 1
+            elif f_in:
                 rows = f_in[0][1].shape[0]
                 pre = t_pre if (t_pre is not None and t_pre.shape == (rows, S * r)) else None
                 if pre is None:
@@ -622,6 +627,7 @@ class _LoraProjFn(torch.autograd.Function):
             y = K.gemm(x, pack.w, M, pack.N, pack.K, bias=pack.bias, residual=residual, lora_t=T, lora_u=U,
                        lora_seg=seg_w, lora_scale=1.0)
         ctx.pack, ctx.info, ctx.n_xa, ctx.r, ctx.has_res = pack, info, n_xa, r, residual is not None
+        ctx.t_pre_rows = t_pre.shape[0] if t_pre is not None else 0
         ctx.params = params                       # the Parameter objects themselves (leaf tensors)
         ctx.save_for_backward(T, *xas)
         return y
@@ -715,7 +721,12 @@ class _LoraProjFn(torch.autograd.Function):
                         Dx[s * r:s * r + D.shape[0]] = D.detach()
                     dx = K.gemm(dy, pack.wt, M, pack.K, pack.N, lora_t=dT, lora_u=Dx, lora_seg=pack.K, lora_u_tr=True)
         dres = dy if ctx.has_res and ctx.needs_input_grad[5] else None
-        return (None, None, None, None, dx, dres, *d_xas[1:], *([None] * len(params)))
+        d_tpre = None
+        if ctx.t_pre_rows and ctx.needs_input_grad[3]:           # d(rank-space share of the q adapter) = dT of segment 0
+            d_tpre = dT[:, :info[0][2]]
+            if ctx.t_pre_rows != M:                               # it was broadcast over the batch: sum the copies
+                d_tpre = d_tpre.reshape(M // ctx.t_pre_rows, ctx.t_pre_rows, -1).sum(0)
+        return (None, None, None, d_tpre, dx, dres, *d_xas[1:], *([None] * len(params)))
 
 
 def lora_proj(x, pack: LinearPack, segs: Sequence[Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor, float]]],
@@ -912,6 +923,81 @@ def control_terms(ctrl, layers, scale=1.0):
     """layers: [(down_weight, up_weight), ...] of the sites sharing `ctrl` -> tuple of control terms [Mc, C]"""
     flat = [w for D, U in layers for w in (D, U)]
     return _ControlTermsFn.apply(ctrl, float(scale), len(layers), *flat)
+
+
+RANK_CONTROL = _os.environ.get("CLORA_RANK_CONTROL", "1") != "0"      # "0": materialise the control terms c_l [M, C] (round-3 path, A/B)
+
+
+class _ControlTermsRankFn(torch.autograd.Function):
+    """The v1 control terms of all sites of one UNet level in RANK SPACE (include/clora.h clora_rank_*; reference
+    models.py:214-218, 237-238).  c_l = s U_c,l (D_c,l ctrl) only ever meets the q adapter's down matrix, D_q,l (h + c_l) =
+    D_q,l h + (s D_q,l U_c,l)(D_c,l ctrl): the function returns Tq_l = (D_c,l ctrl) M_l^T  [Mc, 4] with M_l = s D_q,l U_c,l (4 x r_c),
+    which ops.lora_proj adds to the q adapter's T (`t_pre`) -- the [Mc, C] tensors c_l are never formed, forward or backward.
+    Backward gets dTq_l (= dT of each site's q adapter): dTc_l = dTq_l M_l, G_l = dTq_l^T Tc_l (4 x r_c Gram matrix, deterministic
+    two-stage reduction), dU_c,l += s D_q,l^T G_l, dD_q,l += s G_l U_c,l^T (the control share of the q adapter's down gradient),
+    dD_c,l = dTc_l^T ctrl (deferred adapter weight-gradient job), d ctrl = [dTc_1 | ...] [D_c,1; ...].
+    params = (D_c,1, U_c,1, D_q,1, D_c,2, ...)."""
+
+    @staticmethod
+    def forward(ctx, ctrl, scale, n, *params):
+        Mc, Cc = ctrl.shape
+        Dcs, Ucs, Dqs = params[0::3], params[1::3], params[2::3]
+        rc = Dcs[0].shape[0]
+        dev = ctrl.device
+        Tc = torch.empty((Mc, n * rc), dtype=f32, device=dev)
+        K.lora_down_multi([K.down_job(ctrl, D.detach(), Tc, l * rc, Mc, Cc) for l, D in enumerate(Dcs)])
+        Mbuf = torch.empty((n, 4 * rc), dtype=f32, device=dev)
+        Tq = [torch.empty((Mc, 4), dtype=f32, device=dev) for _ in range(n)]
+        sites = [K.rank_site(Dqs[l].detach(), Ucs[l].detach(), Mbuf[l], Tc, l * rc, Tq[l], Mc, scale) for l in range(n)]
+        K.rank_compose(sites)
+        K.rank_mix(sites)
+        ctx.save_for_backward(ctrl, Tc, Mbuf)
+        ctx.params, ctx.cfg = params, (scale, n, rc)
+        return tuple(Tq)
+
+    @staticmethod
+    def backward(ctx, *dTq):
+        ctrl, Tc, Mbuf = ctx.saved_tensors
+        scale, n, rc = ctx.cfg
+        Dcs, Ucs, Dqs = ctx.params[0::3], ctx.params[1::3], ctx.params[2::3]
+        Mc, Cc = ctrl.shape
+        live = [l for l in range(n) if dTq[l] is not None]
+        dTc = (torch.empty if len(live) == n else torch.zeros)((Mc, n * rc), dtype=f32, device=ctrl.device)
+        keep = []
+        if live:
+            sites = []
+            for l in live:
+                g = dTq[l] if dTq[l].stride(1) == 1 else dTq[l].contiguous()
+                keep.append(g)
+                sites.append(K.rank_site(Dqs[l].detach(), Ucs[l].detach(), Mbuf[l], Tc, l * rc, g, Mc, scale, dTc=dTc,
+                                         gDq=_grad_buffer(Dqs[l]) if Dqs[l].requires_grad else None,
+                                         gUc=_grad_buffer(Ucs[l]) if Ucs[l].requires_grad else None))
+            ws = K.rank_mix(sites, backward=True, device=ctrl.device)
+            K.rank_compose_bwd(sites, ws)
+            keep.append(ws)
+        wj = [K.wgrad_job(ctrl, dTc, l * rc, _grad_buffer(Dcs[l]), 1, Cc, Mc, Cc, rc) for l in live if Dcs[l].requires_grad]
+        if wj:
+            K.lora_wgrad_defer(wj, ctrl.device, ctrl, dTc, *keep)
+        dctrl = None
+        if ctx.needs_input_grad[0]:
+            dctrl = K.lora_up(None, dTc, 0, _stack_rows([D.detach() for D in Dcs]), Mc, Cc, 1.0, u_tr=True)
+        return (dctrl, None, None) + (None,) * (3 * n)
+
+
+def control_terms_rank(ctrl, layers, scale=1.0):
+    """layers: [(to_control.down, to_control.up, to_q_lora.down), ...] of the sites sharing `ctrl` -> tuple of Tq_l [Mc, 4] (fp32),
+    the control terms' shares of the sites' q down-projections (pass each to ops.lora_proj as `t_pre`)"""
+    flat = [w for tri in layers for w in tri]
+    return _ControlTermsRankFn.apply(ctrl, float(scale), len(layers), *flat)
+
+
+def rank_control_ok(layers):
+    """shapes the rank-space kernels take: control rank <= 8, q adapter rank 4, one shape for all sites of the level"""
+    shapes = {(tuple(Dc.shape), tuple(Uc.shape), tuple(Dq.shape)) for Dc, Uc, Dq in layers}
+    if len(shapes) != 1:
+        return False
+    Dc, Uc, Dq = layers[0]
+    return Dc.shape[0] <= 8 and Dq.shape[0] == 4 and Uc.shape[1] == Dc.shape[0] and Dq.shape[1] == Uc.shape[0] and len(layers) <= 16
 
 
 @torch.no_grad()

@@ -258,6 +258,9 @@ typedef struct {
     int r2;                           /* > 0: X2 only feeds rows 0..r2-1 of D -- several adapters that share X stacked into ONE job
                                        * (D = [D_q; D_k; D_v], one pass over X) while only the first of them also reads X2
                                        * (reference models.py:237-238: the control term enters the q adapter only); 0 = all R rows */
+    const float* T_in; int ldt_in, t_in_rows, t_in_r;  /* optional: T_in[m % t_in_rows (or m), j] is added to output column j < t_in_r --
+                                       * a share of the down-projection that was evaluated elsewhere (clora_rank_mix_f32: the control
+                                       * term's part of the q adapter, in rank space) */
 } clora_lora_down_job_t;
 typedef struct {
     const clora_half* A; int lda; const float* T; int ldt; int toff; float* G; int gs_n, gs_j;
@@ -268,6 +271,36 @@ int clora_lora_down_multi_f16(const clora_lora_down_job_t* jobs, int njobs, void
 /* workspace >= sum over jobs of clora_lora_wgrad_workspace_bytes(M, N, R) */
 int clora_lora_wgrad_multi_f16(const clora_lora_wgrad_job_t* jobs, int njobs, void* workspace, size_t workspace_bytes,
                                void* stream);
+
+/* ---- the v1 control term in RANK SPACE (round 4).  Reference models.py:214-218, 237-238: every plain ControlLoRA site adds
+ * c = scale * to_control(control) = scale * U_c (D_c control) to the hidden states that feed its q adapter, q += scale * U_q D_q (h + c).
+ * By linearity D_q (h + c) = D_q h + (scale * D_q U_c) (D_c control): the [M, C] tensor c never has to exist -- its share of the
+ * q adapter's down-projection is a 4 x r_c matrix M_l = scale * D_q U_c applied to the r_c numbers per row that D_c control yields,
+ * and the whole backward of the term (d control, dU_c, dD_c and the control share of dD_q) runs on [M, 4] / [M, r_c] tensors and
+ * 4 x r_c Gram matrices.  (fp32 throughout: the reference's two fp16 roundings of c are NOT reproduced -- the result is closer
+ * to the reference's fp32 arithmetic than its own fp16 run; parity limits unchanged.)  One site = one clora_rank_site_t; the
+ * sites of a UNet level (10) go in one launch each (n <= 16; the array is read on the host).
+ *   clora_rank_compose_f32      M_l[j, i] = scale * sum_c D_q[j, c] U_c[c, i]                       (4 x r_c, r_c <= 8)
+ *   clora_rank_mix_f32  fwd     Tq[m, j]  = sum_i Tc[m, toff + i] M_l[j, i]                          (rows x 4)
+ *                       bwd     dTc[m, toff + i] = sum_j dTq[m, j] M_l[j, i]   and per-block partial Gram sums of
+ *                               G_l[j, i] = sum_m dTq[m, j] Tc[m, toff + i]  into `gram_ws` (clora_rank_gram_ws_bytes)
+ *   clora_rank_compose_bwd_f32  folds the partial Gram sums in a fixed order (deterministic) and accumulates
+ *                               gUc[c, i] += scale * sum_j D_q[j, c] G[j, i]   gDq[j, c] += scale * sum_i G[j, i] U_c[c, i] */
+typedef struct {
+    const float* Dq; int lddq;        /* to_q_lora.down.weight [4, C] */
+    const float* Uc; int lduc;        /* to_control.up.weight   [C, r_c] */
+    float* M;                         /* [4 * r_c] work buffer (device) */
+    const float* Tc; int ldtc, toff;  /* D_c control: [rows, ldtc], this site's r_c columns start at toff */
+    float* Tq; int ldtq;              /* fwd: out [rows, >= 4]; bwd: the incoming gradient dTq (read) */
+    float* dTc; int lddtc;            /* bwd: out, same layout as Tc */
+    float* gDq; float* gUc;           /* bwd: parameter gradients to accumulate into (either may be NULL) */
+    int rows, C, rc;
+    float scale;
+} clora_rank_site_t;
+int clora_rank_compose_f32(const clora_rank_site_t* sites, int n, void* stream);
+int clora_rank_mix_f32(const clora_rank_site_t* sites, int n, int backward, float* gram_ws, size_t gram_ws_bytes, void* stream);
+size_t clora_rank_gram_ws_bytes(int rows, int n);
+int clora_rank_compose_bwd_f32(const clora_rank_site_t* sites, int n, const float* gram_ws, void* stream);
 
 /* Y[m,n] = (base ? base[m,n] : 0) + fp16(scale * fp16(sum_j T[m,toff+j] U[n,j]))  -- the explicit
  * "hidden + to_control(control)" of models.py:214-218,237-238 and the V2 pre/post adds (:369,:415). */

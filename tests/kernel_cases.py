@@ -151,6 +151,32 @@ def case_gemm_fused_down(dev, M=150, N=320, K_=128, nseg=1, tile_cfg=0, u_tr=Fal
     return eT
 
 
+def case_rank_control(dev, Mc=300, Cc=64, C_=128, rc=4, n=3, scale=0.8, strided_grad=True):
+    """ops.control_terms_rank (clora_rank_compose / _mix / _compose_bwd + the deferred weight-gradient jobs) against the formula it
+    replaces, evaluated by torch autograd in fp32: c_l = s U_c,l (D_c,l ctrl), Tq_l = c_l D_q,l^T (reference models.py:214-218,
+    237-238) -- outputs, d ctrl and the gradients of all three matrices of every site."""
+    from controllora_amd import ops
+    g = torch.Generator().manual_seed(17)
+    ctrl = rnd((Mc, Cc), dev, g).requires_grad_(True)
+    P = lambda *sh, sc=1.0: torch.nn.Parameter((torch.randn(sh, generator=g) * sc).to(dev))
+    layers = [(P(rc, Cc, sc=Cc ** -0.5), P(C_, rc, sc=0.5), P(4, C_, sc=C_ ** -0.5)) for _ in range(n)]
+    outs = ops.control_terms_rank(ctrl, layers, scale)
+    # the incoming gradients: column blocks of one [Mc, 12] buffer (what lora_proj hands back for a fused q | k | v projection)
+    gbuf = [torch.randn((Mc, 12), generator=g).to(dev) for _ in range(n)]
+    grads = [b[:, :4] if strided_grad else b[:, :4].contiguous() for b in gbuf]
+    torch.autograd.backward(outs, grads)
+    K.lora_wgrad_flush()
+    c32 = ctrl.detach().float().clone().requires_grad_(True)
+    refp = [tuple(w.detach().clone().requires_grad_(True) for w in tri) for tri in layers]
+    ref = [(scale * ((c32 @ Dc.T) @ Uc.T)) @ Dq.T for Dc, Uc, Dq in refp]
+    torch.autograd.backward(ref, [b[:, :4].float() for b in gbuf])
+    errs = {"Tq": max(rel(o, r_) for o, r_ in zip(outs, ref)), "dctrl": rel(ctrl.grad, c32.grad)}
+    for k, idx in (("dDc", 0), ("dUc", 1), ("dDq", 2)):
+        errs[k] = max(rel(layers[l][idx].grad, refp[l][idx].grad) for l in range(n))
+    assert errs["Tq"] < 1e-5 and errs["dctrl"] < 1e-3 and errs["dUc"] < 1e-5 and errs["dDq"] < 1e-5 and errs["dDc"] < 5e-4, errs
+    return errs
+
+
 def case_conv(dev, Bn, H, W, Ci, Co, stride=1, pad=1, ups=False, asym=False, seed=2, tile_cfg=0, kchunk=0):
     """forward, dgrad and wgrad of one 3x3 conv configuration against F.conv2d autograd.
     kchunk > 0: forward and dgrad additionally run with the channel-chunk-major K order (clora_conv_t.kchunk)."""

@@ -61,6 +61,11 @@ def test_gemm_with_adapter_down_projection_in_the_launch(kw):
     KC.case_gemm_fused_down("cpu", **kw)
 
 
+@pytest.mark.parametrize("kw", [dict(), dict(Mc=70, Cc=40, C_=64, rc=8, n=2, strided_grad=False), dict(Mc=513, Cc=32, C_=320, rc=4, n=10)])
+def test_control_terms_in_rank_space(kw):
+    print(KC.case_rank_control("cpu", **kw))
+
+
 @pytest.mark.parametrize("order", ["n", "auto"])
 @pytest.mark.parametrize("tile", [21, 43, 53, 72, 76])
 def test_tile_order_does_not_change_results(tile, order):

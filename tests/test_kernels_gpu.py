@@ -157,6 +157,13 @@ def test_lora(M, K, N, R, xr):
     KC.case_lora(DEV, M, K, N, R, x_rows=xr)
 
 
+@pytest.mark.parametrize("kw", [dict(Mc=16384, Cc=320, C_=320, rc=4, n=10), dict(Mc=4096, Cc=640, C_=640, rc=4, n=10),
+                                dict(Mc=256, Cc=1280, C_=1280, rc=8, n=2, strided_grad=False)])
+def test_control_terms_in_rank_space(kw):
+    """reference models.py:214-218, 237-238 at the level shapes of the step: the rank-space kernels vs torch autograd of the formula"""
+    print("RANK_CONTROL", kw, KC.case_rank_control(DEV, **kw))
+
+
 @pytest.mark.parametrize("mode", [0, 1, 2])
 def test_lora_down_launch_modes(mode):
     """option "lora_down_mode": how an adapter down-projection is spread over waves (K-split everywhere / eight k-steps in flight):
