@@ -487,27 +487,27 @@ extern "C" int clora_lora_wgrad_f16(const clora_half* A, int lda, const float* T
 }
 
 // ------------------------------------------------------------------------------------------------
-// clora_lora_pack_f16: fp32 adapter matrices -> the 16-row fp16 operand blocks of clora_epilogue_t.lora_dpack (rows 0..7 fp16(v),
-// rows 8..15 fp16(v - fp16(v)), v = scale * D).  One launch for a whole device-resident job table: grid.y = job.
+// clora_lora_pack_f16: fp32 adapter matrices -> the 8-row fp16 operand blocks of clora_epilogue_t.lora_dpack (rows 0..3 fp16(v),
+// rows 4..7 fp16(v - fp16(v)), v = scale * D; rank <= 4).  One launch for a whole device-resident job table: grid.y = job.
 namespace {
 __global__ __launch_bounds__(256) void lora_pack_kernel(const clora_lora_pack_job_t* table, int njobs) {
     const clora_lora_pack_job_t j = table[blockIdx.y];
     half_t* out = (half_t*)j.out;
     for (int k = blockIdx.x * 256 + threadIdx.x; k < j.K; k += gridDim.x * 256) {
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
+        for (int r = 0; r < 4; ++r) {
             float v = 0.f;
             if (r < j.R) v = j.scale * (j.kmajor ? j.D[(size_t)k * j.ldd + r] : j.D[(size_t)r * j.ldd + k]);
             const half_t hi = (half_t)v;
             out[(size_t)r * j.K + k] = hi;
-            out[(size_t)(8 + r) * j.K + k] = (half_t)(v - (float)hi);
+            out[(size_t)(4 + r) * j.K + k] = (half_t)(v - (float)hi);
         }
     }
 }
 }  // namespace
 
 extern "C" int clora_lora_pack_f16(const clora_lora_pack_job_t* table, int njobs, int max_k, void* stream) {
-    if (!table || njobs <= 0 || njobs > 65535 || max_k <= 0) return CLORA_ERR_ARG;
+    if (!table || njobs <= 0 || njobs > 65535 || max_k <= 0) return CLORA_ERR_ARG;     // (job.R <= 4 is the caller's contract: device table)
     hipLaunchKernelGGL(lora_pack_kernel, dim3(clora_cdiv(max_k, 256), njobs), dim3(256), 0, (hipStream_t)stream, table, njobs);
     return clora_check_launch();
 }

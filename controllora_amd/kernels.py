@@ -138,7 +138,7 @@ def gemm(A: torch.Tensor, Bw: torch.Tensor, M: int, N: int, K: int, *, lda: Opti
     """C[M,N] = A . Bw^T with the fused epilogue of clora_epilogue_t.
     geglu=1 (Bw / bias packed by ops.GegluPack, N = 2F): returns (y [M,F], h [M,2F] or None when not geglu_keep_h);
     geglu=2 (N = F, geglu_h = the saved h): returns dh [M, 2F].
-    lora_dpack ([N / lora_seg * 16, K] fp16 from lora_pack): the launch also computes T = A . D^T per column segment, WRITES it to
+    lora_dpack ([N / lora_seg * 8, K] fp16 from lora_pack): the launch also computes T = A . D^T per column segment, WRITES it to
     lora_t and uses it in its epilogue (clora_epilogue_t.lora_dpack); lora_t_in / lora_t_in_mask: precomputed part added to the
     segments of the mask (row m reads row m % lora_t_in_rows when that is > 0)."""
     assert A.dtype == f16 and Bw.dtype == f16 and Bw.shape == (N, K) and Bw.is_contiguous()
@@ -171,7 +171,7 @@ def gemm(A: torch.Tensor, Bw: torch.Tensor, M: int, N: int, K: int, *, lda: Opti
         e.lora_r = lora_r if lora_r is not None else (lora_u.shape[0] if lora_u_tr else lora_u.shape[1])
         e.lora_seg, e.lora_scale = (lora_seg or N), float(lora_scale)
     if lora_dpack is not None:
-        assert lora_t is not None and lora_dpack.dtype == f16 and lora_dpack.is_contiguous() and lora_dpack.shape == (N // e.lora_seg * 16, K)
+        assert lora_t is not None and lora_dpack.dtype == f16 and lora_dpack.is_contiguous() and lora_dpack.shape == (N // e.lora_seg * 8, K)
         e.lora_dpack = ptr(lora_dpack)
         if lora_t_in is not None:
             assert lora_t_in.dtype == f32 and lora_t_in.stride(1) == 1

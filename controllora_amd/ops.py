@@ -445,9 +445,9 @@ def _adjacent(ts):
 
 
 # ---- adapter operand packs for the in-launch down-projection (include/clora.h clora_epilogue_t.lora_dpack) -----------------
-# A rank-4 adapter whose input is the projection's own input is evaluated INSIDE the projection GEMM (16 extra operand rows per
+# A rank-4 adapter whose input is the projection's own input is evaluated INSIDE the projection GEMM (8 extra operand rows per
 # ring stage): the separate lora_down launch and its second pass over the activation disappear.  The GEMM needs the down matrix
-# (forward) / the scaled up matrix (backward: dT = dy . (s U)) as a 16-row fp16 block (hi | lo split, fp32-equivalent); the blocks
+# (forward) / the scaled up matrix (backward: dT = dy . (s U)) as an 8-row fp16 block (hi | lo split, fp32-equivalent); the blocks
 # of all adapters are refreshed by ONE launch over a device-resident job table (`repack_adapters`, called by the trainer after
 # every optimizer step -- its flat AdamW kernel updates the weights behind torch's back); an in-place torch update of a
 # parameter is caught by its _version at the point of use.
@@ -471,7 +471,8 @@ class _AdapterPacks:
             if D is None:
                 continue
             R = D.shape[1] if kmajor else D.shape[0]
-            jobs.append(capi.LoraPackJob(D.data_ptr(), out[16 * i:].data_ptr(), D.stride(0), R, K, int(kmajor), float(sc), 0))
+            assert R <= 4
+            jobs.append(capi.LoraPackJob(D.data_ptr(), out[8 * i:].data_ptr(), D.stride(0), R, K, int(kmajor), float(sc), 0))
         return jobs
 
     def _launch(self, jobs, K, device):
@@ -484,7 +485,7 @@ class _AdapterPacks:
 
     def get(self, srcs, kmajor=False, scales=None):
         """srcs: the adapter matrices of the column segments of one GEMM (None = no adapter on that segment: zero block);
-        -> [16 * len(srcs), K] fp16, refreshed if a source was updated in place since the last pack"""
+        -> [8 * len(srcs), K] fp16, refreshed if a source was updated in place since the last pack"""
         scales = tuple(1.0 if sc is None else float(sc) for sc in (scales or [None] * len(srcs)))
         key = (tuple((D.data_ptr(), tuple(D.shape), D.stride(0)) if D is not None else None for D in srcs), bool(kmajor), scales)
         g = self.groups.get(key)
@@ -493,7 +494,7 @@ class _AdapterPacks:
             D0 = live[0]
             assert all(D.dtype == f32 and D.stride(1) == 1 for D in live)
             K = D0.shape[0] if kmajor else D0.shape[1]
-            out = torch.zeros((16 * len(srcs), K), dtype=f16, device=D0.device)
+            out = torch.zeros((8 * len(srcs), K), dtype=f16, device=D0.device)
             jobs = self._jobs_of(srcs, kmajor, scales, out, K)
             g = self.groups[key] = dict(out=out, jobs=jobs, K=K, srcs=tuple(srcs), versions=None, tab=None)
             self.table = None                                   # rebuilt (with the new group) at the next repack
@@ -539,14 +540,32 @@ def _fills_the_chip(M, N):
     return ((M + bm - 1) // bm) * (N // FUSE_TILE_N) >= FUSE_MIN_BLOCKS
 
 
+SMALL_FUSE_TILES = {21: 128, 41: 128, 22: 64, 42: 64, 26: 64, 23: 64, 43: 64}     # 4-wave BK = 64 tiles that can carry the extra rows: columns
+FUSE_SMALL = _os.environ.get("CLORA_FUSE_SMALL", "1") != "0"                        # "0": only the 8-wave 320-column tiles (A/B runs)
+
+
+def _fuse_plan(M, N, Kd, seg_w):
+    """None: keep the separate down-projection launch; 0: fuse on the 320-column tiles (table entry or library choice);
+    > 0: fuse on this 4-wave tile -- the tuned table's own choice for the shape, when it is one that can carry the extra rows
+    (the deeper UNet levels, where the 320-column tiles would leave most CUs idle)"""
+    if not FUSE_DOWN or Kd % 64 or seg_w % 64:
+        return None
+    if seg_w % FUSE_TILE_N == 0 and _fills_the_chip(M, N):
+        return 0
+    hit = K._tuned(M, N, Kd, None) if FUSE_SMALL else None
+    if hit is not None and hit[1] == 1 and hit[0] in SMALL_FUSE_TILES and seg_w % SMALL_FUSE_TILES[hit[0]] == 0:
+        return hit[0]
+    return None
+
+
 def _fusable(pack, meta, ranks, seg_w, M):
-    """may the adapters of this projection ride in its GEMM?  rank 4 everywhere, 320-column segments, whole 64-deep k-steps, every
-    adapter fed by x itself (index 0) plus at most one more input"""
-    if not FUSE_DOWN or not ranks or any(rk != 4 for rk in ranks) or seg_w % FUSE_TILE_N or pack.K % 64:
-        return False
-    if not _fills_the_chip(M, pack.N):
-        return False
-    return all(m is None or (m[0][0] == 0 and len(m[0]) <= 2) for m in meta)
+    """may the adapters of this projection ride in its GEMM?  rank 4 everywhere, whole 64-deep k-steps, every adapter fed by x
+    itself (index 0) plus at most one more input, and a tile that can take it (_fuse_plan) -> the plan, or None"""
+    if not ranks or any(rk != 4 for rk in ranks):
+        return None
+    if not all(m is None or (m[0][0] == 0 and len(m[0]) <= 2) for m in meta):
+        return None
+    return _fuse_plan(M, pack.N, pack.K, seg_w)
 
 
 class _LoraProjFn(torch.autograd.Function):
@@ -568,7 +587,8 @@ class _LoraProjFn(torch.autograd.Function):
         ranks = [params[2 * i].shape[0] for i in range(len(params) // 2)]
         r = max(ranks + [1])
         full = all(m is not None for m in meta) and all(rk == r for rk in ranks)
-        fused = _fusable(pack, meta, ranks, seg_w, M)
+        plan = _fusable(pack, meta, ranks, seg_w, M)
+        fused = plan is not None
         T = (torch.empty if (full or fused) else torch.zeros)((M, S * r), dtype=f32, device=x.device)
         pieces, pi, info, dspecs = [], 0, [], []
         f_srcs, f_in_mask, f_in = [], 0, []           # fused: down matrices per segment, segments with a second (precomputed) part
@@ -622,7 +642,7 @@ class _LoraProjFn(torch.autograd.Function):
                 t_in, t_in_rows = pre, (rows if rows != M else 0)
             y = K.gemm(x, pack.w, M, pack.N, pack.K, bias=pack.bias, residual=residual, lora_t=T, lora_u=U,
                        lora_seg=seg_w, lora_scale=1.0, lora_dpack=ADAPTER_PACKS.get(f_srcs), lora_t_in=t_in,
-                       lora_t_in_mask=f_in_mask, lora_t_in_rows=t_in_rows)
+                       lora_t_in_mask=f_in_mask, lora_t_in_rows=t_in_rows, tile_cfg=plan)
         else:
             y = K.gemm(x, pack.w, M, pack.N, pack.K, bias=pack.bias, residual=residual, lora_t=T, lora_u=U,
                        lora_seg=seg_w, lora_scale=1.0)
@@ -643,8 +663,9 @@ class _LoraProjFn(torch.autograd.Function):
         M = dy.shape[0]
         dT = (torch.empty if all(i is not None and i[2] == r for i in info) else torch.zeros)((M, S * r), dtype=f32, device=dy.device)
         # single-adapter projections (out / cross-attention q): dT = dy . (s U) rides in the dgrad GEMM that streams dy anyway
-        fused_bwd = (FUSE_DOWN and S == 1 and info[0] is not None and info[0][2] == 4 and 0 in info[0][0] and ctx.needs_input_grad[4]
-                     and pack.K % FUSE_TILE_N == 0 and pack.N % 64 == 0 and _fills_the_chip(M, pack.K))
+        bplan = _fuse_plan(M, pack.K, pack.N, pack.K) if (S == 1 and info[0] is not None and info[0][2] == 4 and 0 in info[0][0]
+                                                          and ctx.needs_input_grad[4]) else None
+        fused_bwd = bplan is not None
         d_xas: List[Optional[torch.Tensor]] = [None] * n_xa
         own = []                                  # (segment, D) of adapters fed by x itself -> dgrad GEMM epilogue
         djobs, wjobs, later, keep = [], [], [], []
@@ -688,7 +709,7 @@ class _LoraProjFn(torch.autograd.Function):
         if fused_bwd:
             D0, U0, sc0 = params[0], params[1], info[0][1]
             dx = K.gemm(dy, pack.wt, M, pack.K, pack.N, lora_t=dT, lora_u=D0.detach(), lora_seg=pack.K, lora_u_tr=True, lora_r=4,
-                        lora_dpack=ADAPTER_PACKS.get([U0.detach()], kmajor=True, scales=[sc0]))
+                        lora_dpack=ADAPTER_PACKS.get([U0.detach()], kmajor=True, scales=[sc0]), tile_cfg=bplan)
         if djobs:
             K.lora_down_multi(djobs)              # dT of every adapter of this GEMM: one launch
         if wjobs:

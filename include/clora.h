@@ -81,22 +81,24 @@ typedef struct {
     /* Adapter down-projection evaluated BY this launch (round 4; reference models.py:232-282: every `attn.to_x(h) + scale *
      * to_x_lora(h)` pair reads h twice -- once for the frozen projection, once for LoRALinearLayer.down).  lora_dpack != NULL:
      * the launch computes T[m, s*lora_r + j] = sum_k A[m, k] * D_s[j, k] for the adapter of every column segment s from the A
-     * rows it streams for the projection itself (16 extra operand rows per ring stage: fp16(D) and fp16(D - fp16(D)), i.e. fp32
+     * rows it streams for the projection itself (8 extra operand rows per ring stage: fp16(D) and fp16(D - fp16(D)), i.e. fp32
      * weights to ~2^-22, as clora_lora_down computes it), WRITES it to lora_t (which must then be writable: the backward reads
      * it) and uses it in the epilogue without a global round trip.  lora_t_in (optional): a precomputed part that is ADDED to
      * the computed T of the segments whose bit is set in lora_t_in_mask -- the control term's share of the q adapter,
      * L_q(h + c) = L_q(h) + L_q(c) (reference models.py:237-238) -- row m reads row m % lora_t_in_rows when lora_t_in_rows > 0
      * (control batch 1 broadcast), same column layout as lora_t with row pitch ldt_in.
-     * Needs: plain GEMM (no conv), lora_r == 4, lora_seg % 320 == 0, K % 64 == 0, split_k == 1, no GEGLU; runs on the 8-wave
-     * 320-column tiles (tile_cfg 51, 52, 54, 55, 57; 0 = chosen by M); anything else: CLORA_ERR_ARG. */
-    const clora_half* lora_dpack; /* [N / lora_seg][16][K] from clora_lora_pack_f16, or NULL */
+     * Needs: plain GEMM (no conv), lora_r == 4, lora_seg % 64 == 0, K % 64 == 0, split_k == 1, no GEGLU (else CLORA_ERR_ARG);
+     * runs on the BK = 64 tiles that lie inside one column segment -- 8-wave 320-column tiles (tile_cfg 51, 52, 54, 55), 64-column
+     * tiles (22, 23, 26, 42, 43), 128x128 (21, 41); any other tile_cfg is replaced by the library's choice (54 / 55, or 43 when
+     * lora_seg is not a multiple of 320).  Every n-tile of a segment recomputes T; the first one writes it. */
+    const clora_half* lora_dpack; /* [N / lora_seg][8][K] from clora_lora_pack_f16, or NULL */
     const float* lora_t_in;
     int ldt_in, lora_t_in_rows;
     unsigned lora_t_in_mask;
 } clora_epilogue_t;
 
-/* Packs adapter matrices for `lora_dpack`: out[16][K] fp16, rows 0..R-1 = fp16(scale * D), rows 8..8+R-1 = fp16(scale * D -
- * fp16(scale * D)), other rows zero; R <= 8.  kmajor = 0: D is a down weight [R, K] with row pitch ldd (LoRALinearLayer.down,
+/* Packs adapter matrices for `lora_dpack`: out[8][K] fp16, rows 0..R-1 = fp16(scale * D), rows 4..4+R-1 = fp16(scale * D -
+ * fp16(scale * D)), other rows zero; R <= 4.  kmajor = 0: D is a down weight [R, K] with row pitch ldd (LoRALinearLayer.down,
  * reference models.py:40-44); kmajor = 1: D is an up weight [K, R] with row pitch ldd used as its own transpose (the backward's
  * dT = dY . (scale * U)).  `table` is a DEVICE array of njobs jobs (built once per model: the pointers are stable), one launch
  * repacks every adapter of a step -- what the per-call fp32 -> compute-dtype casts of LoRALinearLayer.forward do. */

@@ -145,9 +145,12 @@ def case_gemm_fused_down(dev, M=150, N=320, K_=128, nseg=1, tile_cfg=0, u_tr=Fal
                    lora_t_in_rows=(t_in_rows or 0) if t_in is not None else 0, **kw)
     assert torch.equal(out, again) and torch.equal(T, T3), "the same launch twice must give the same bits"
     # the unfused launch fed with the T the fused one wrote gives the same output bits (same epilogue arithmetic)
-    kw["tile_cfg"] = tile_cfg if tile_cfg in (51, 52, 54, 55) else (54 if M >= 32768 else 55)     # the tile the fused launch ran on
+    bn = {51: 320, 52: 320, 54: 320, 55: 320, 21: 128, 41: 128, 22: 64, 42: 64, 26: 64, 23: 64, 43: 64}.get(tile_cfg, 0)
+    if bn == 0 or seg_w % bn:                                    # the library's replacement rule (include/clora.h, lora_dpack)
+        tile_cfg = (54 if M >= 32768 else 55) if seg_w % 320 == 0 else 43
+    kw["tile_cfg"] = tile_cfg                                    # the tile the fused launch ran on
     unf = K.gemm(A, B, M, N, K_, lora_t=T, **kw)
-    assert rel(unf, out) < 1e-6 or torch.equal(unf, out)
+    assert rel(unf, out) < 2e-5 or torch.equal(unf, out)      # same T, same epilogue formula; the non-hoisted variants order the four products differently
     return eT
 
 

@@ -55,7 +55,11 @@ def test_gemm_epilogue_without_rowadd(tile):
 @pytest.mark.parametrize("kw", [dict(M=150, N=320, K_=128, tile_cfg=55), dict(M=150, N=320, K_=128, tile_cfg=52, t_in_rows=0),
                                 dict(M=140, N=640, K_=64, nseg=2, tile_cfg=55, t_in_rows=70), dict(M=200, N=960, K_=192, nseg=3, tile_cfg=54, t_in_rows=0),
                                 dict(M=130, N=320, K_=320, tile_cfg=51, u_tr=True, bias=False), dict(M=70, N=640, K_=64, nseg=1, tile_cfg=0, residual=False),
-                                dict(M=100, N=320, K_=128, tile_cfg=21)])
+                                dict(M=100, N=320, K_=128, tile_cfg=21), dict(M=150, N=128, K_=128, nseg=2, tile_cfg=43, t_in_rows=0),
+                                dict(M=200, N=192, K_=64, nseg=1, tile_cfg=23, u_tr=True, bias=False), dict(M=140, N=256, K_=192, nseg=2, tile_cfg=42, t_in_rows=70),
+                                dict(M=130, N=128, K_=64, nseg=2, tile_cfg=22), dict(M=260, N=256, K_=128, nseg=2, tile_cfg=21, t_in_rows=0),
+                                dict(M=129, N=128, K_=64, nseg=1, tile_cfg=41, residual=False), dict(M=100, N=64, K_=64, tile_cfg=26),
+                                dict(M=100, N=192, K_=64, nseg=3, tile_cfg=0)])
 def test_gemm_with_adapter_down_projection_in_the_launch(kw):
     """clora_epilogue_t.lora_dpack on the 8-wave 320-column tiles (an incapable tile_cfg is replaced by the library's choice)"""
     KC.case_gemm_fused_down("cpu", **kw)

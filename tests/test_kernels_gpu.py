@@ -80,7 +80,12 @@ def test_conv_patch_kernel_row_segments_vae_shapes(tile, Bn, H, W, Ci, Co):
                                 dict(M=16384, N=320, K_=320, tile_cfg=54, t_in_rows=4096), dict(M=16384, N=320, K_=320, tile_cfg=51, u_tr=True, bias=False),
                                 dict(M=16384, N=960, K_=320, nseg=3, tile_cfg=0, t_in_rows=0), dict(M=32768, N=960, K_=320, nseg=3, tile_cfg=0, t_in_rows=4096),
                                 dict(M=4096, N=640, K_=640, tile_cfg=0, t_in_rows=0), dict(M=1024, N=1280, K_=1280, tile_cfg=0, u_tr=True, residual=False),
-                                dict(M=4099, N=1920, K_=640, nseg=3, tile_cfg=55, t_in_rows=0), dict(M=131072, N=320, K_=320, tile_cfg=0, t_in_rows=4096)])
+                                dict(M=4099, N=1920, K_=640, nseg=3, tile_cfg=55, t_in_rows=0), dict(M=131072, N=320, K_=320, tile_cfg=0, t_in_rows=4096),
+                                dict(M=4096, N=640, K_=640, tile_cfg=43, t_in_rows=0), dict(M=1024, N=1280, K_=1280, tile_cfg=43, u_tr=True, residual=False),
+                                dict(M=4096, N=640, K_=640, tile_cfg=42), dict(M=256, N=1280, K_=1280, tile_cfg=23, t_in_rows=64),
+                                dict(M=308, N=1280, K_=768, nseg=2, tile_cfg=43), dict(M=2048, N=1280, K_=1280, tile_cfg=22, u_tr=True, bias=False),
+                                dict(M=1024, N=1280, K_=1280, tile_cfg=21, t_in_rows=0), dict(M=8192, N=640, K_=640, tile_cfg=41),
+                                dict(M=4096, N=640, K_=640, tile_cfg=26)])
 def test_gemm_with_adapter_down_projection_in_the_launch(kw):
     """clora_epilogue_t.lora_dpack at the projection shapes of the step (level 0 q | k | v, out, cross-attention q; the deeper
     levels; the batch-8 and batch-32 row counts; ragged M): T written == A . D^T, output == the unfused formula elementwise,
