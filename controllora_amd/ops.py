@@ -497,6 +497,8 @@ class _AdapterPacks:
             out = torch.zeros((8 * len(srcs), K), dtype=f16, device=D0.device)
             jobs = self._jobs_of(srcs, kmajor, scales, out, K)
             g = self.groups[key] = dict(out=out, jobs=jobs, K=K, srcs=tuple(srcs), versions=None, tab=None)
+            if self.table is not None:
+                self.retired.append(self.table)                 # a captured hipGraph may still replay a launch over the old table
             self.table = None                                   # rebuilt (with the new group) at the next repack
         vers = tuple(D._version for D in live)
         if g["versions"] != vers:
@@ -514,10 +516,7 @@ class _AdapterPacks:
             from . import capi
             arr = (capi.LoraPackJob * len(jobs))(*jobs)
             dev = next(iter(self.groups.values()))["out"].device
-            if self.table is not None:
-                self.retired.append(self.table)
             self.table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
-            self.retired.append(self.table)
             self.njobs, self.max_k = len(jobs), max(g["K"] for g in self.groups.values())
         K_.lora_pack(self.table, self.njobs, self.max_k)
 
