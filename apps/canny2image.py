@@ -42,44 +42,7 @@ def resize_image(img: np.ndarray, resolution: int) -> np.ndarray:
     return np.asarray(Image.fromarray(img).resize((W2, H2), Image.LANCZOS if k > 1 else Image.BOX))
 
 
-def _conv2_same(a: np.ndarray, k: np.ndarray) -> np.ndarray:
-    ph, pw = k.shape[0] // 2, k.shape[1] // 2
-    p = np.pad(a, ((ph, ph), (pw, pw)), mode="edge")
-    out = np.zeros_like(a, dtype=np.float32)
-    for i in range(k.shape[0]):
-        for j in range(k.shape[1]):
-            out += k[i, j] * p[i:i + a.shape[0], j:j + a.shape[1]]
-    return out
-
-
-def canny(img: np.ndarray, low: float, high: float) -> np.ndarray:
-    """Canny edge detector (grey -> Sobel gradient, L1 magnitude like OpenCV's default, non-maximum suppression along the
-    quantised gradient direction, double threshold with 8-connected hysteresis) -> uint8 {0, 255} map [H, W]"""
-    g = img.astype(np.float32)
-    if g.ndim == 3:
-        g = 0.299 * g[..., 0] + 0.587 * g[..., 1] + 0.114 * g[..., 2]
-    kx = np.array([[-1, 0, 1], [-2, 0, 2], [-1, 0, 1]], np.float32)
-    gx, gy = _conv2_same(g, kx), _conv2_same(g, kx.T)
-    mag = np.abs(gx) + np.abs(gy)
-    ang = (np.rad2deg(np.arctan2(gy, gx)) + 180.0) % 180.0
-    sector = ((ang + 22.5) // 45).astype(np.int32) % 4                 # 0: E-W, 1: NE-SW, 2: N-S, 3: NW-SE
-    p = np.pad(mag, 1)
-    H, W = mag.shape
-    nb = {0: (p[1:H + 1, 2:], p[1:H + 1, :W]), 1: (p[2:, 2:], p[:H, :W]), 2: (p[2:, 1:W + 1], p[:H, 1:W + 1]),
-          3: (p[2:, :W], p[:H, 2:])}
-    keep = np.zeros_like(mag, dtype=bool)
-    for s_, (a, b) in nb.items():
-        keep |= (sector == s_) & (mag >= a) & (mag >= b)
-    strong = keep & (mag >= high)
-    weak = keep & (mag >= low)
-    out = strong.copy()
-    while True:                                                        # hysteresis: grow strong edges through weak pixels
-        q = np.pad(out, 1)
-        grown = weak & (q[:-2, :-2] | q[:-2, 1:-1] | q[:-2, 2:] | q[1:-1, :-2] | q[1:-1, 2:] | q[2:, :-2] | q[2:, 1:-1] | q[2:, 2:] | out)
-        if (grown == out).all():
-            break
-        out = grown
-    return out.astype(np.uint8) * 255
+from controllora_amd.process import canny          # noqa: E402  (numpy Canny: shared with the process/diffusiondb_canny data set)
 
 
 def process(pipe, input_image, prompt, a_prompt, n_prompt, num_samples, image_resolution, sample_steps, scale, seed, eta,

@@ -434,7 +434,7 @@ __device__ __forceinline__ void dma_epilogue(const GemmArgs& p, floatx4 (&acc)[B
     // experiment build (tools/build_variant_lib.sh -DCLORA_EPI_SINGLE_PASS, A/B through CLORA_LIB_PATH): the whole tile is staged at once
     // where the ring allocation has room, so every accumulator is dead before the first chunk is processed.  Compiled figures in
     // DESIGN.md section 7 (peak VGPRs 255 -> 186 on 128x256, the 128x64 BK32 spills disappear); untimed, hence not the default.
-    constexpr int PR = (BM * F_LD * 2 <= SMEM) ? BM : 64;
+    constexpr int PR = ((BM * F_LD + (EXT > 0 ? BM * 8 : 0)) * 2 <= SMEM) ? BM : 64;
 #else
     constexpr int PR = 64;
 #endif

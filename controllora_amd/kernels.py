@@ -127,6 +127,12 @@ def _tuned(M, N, K, conv):
     return _TUNING.get(tuning_key(M, N, K, conv))
 
 
+def _tuned_fused(M, N, K):
+    """table entry of a projection launch that carries its adapter's down-projection (key suffix ":x"), or None"""
+    _tuned(M, N, K, None)                                   # loads the table
+    return _TUNING.get(f"{M}x{N}x{K}:x")
+
+
 def gemm(A: torch.Tensor, Bw: torch.Tensor, M: int, N: int, K: int, *, lda: Optional[int] = None,
          conv: Optional[ConvDesc] = None, bias=None, rowadd=None, rows_per_batch=0, residual=None,
          lora_t=None, lora_u=None, lora_seg=0, lora_scale=1.0, lora_u_tr=False, lora_r=None,

@@ -49,6 +49,74 @@ def _flat2(t):
     return t.reshape(-1, t.shape[-1])
 
 
+class _StockLinear:
+    """`to_out[0]` of a foreign attention module seen through the packed-operand interface of unet.Linear"""
+
+    def __init__(self, lin):
+        self.lin, self._pack, self._key = lin, None, None
+
+    def pack(self):
+        b = getattr(self.lin, "bias", None)
+        key = (self.lin.weight.data_ptr(), self.lin.weight._version, None if b is None else (b.data_ptr(), b._version))
+        if self._pack is None or self._key != key:
+            self._pack, self._key = ops.LinearPack(self.lin.weight, b), key
+        return self._pack
+
+    def __call__(self, x, residual=None):
+        return ops.frozen_linear(x, self.pack(), residual)
+
+
+class StockAttentionHost:
+    """What the processors below need from `attn` -- packed q|k|v operands, the flash-attention entry, `to_out[0].pack()` -- built on
+    top of a module that only has the stock diffusers `CrossAttention` surface the reference's processors use (`to_q / to_k / to_v /
+    to_out[0] / heads / scale / prepare_attention_mask`, reference models.py:122-150): the frozen weights are packed once per
+    (storage, version) and the call runs on the same kernels as with this repository's own `unet.CrossAttention`.  Self- vs
+    cross-attention is what the CALL says (`encoder_hidden_states is None`), as in the reference (models.py:128-129)."""
+
+    def __init__(self, attn):
+        self.attn = attn
+        self.heads = int(attn.heads)
+        self.inner_dim = attn.to_q.weight.shape[0]
+        self.dim_head = self.inner_dim // self.heads
+        self.scale = float(getattr(attn, "scale", self.dim_head ** -0.5))
+        self.to_out = [_StockLinear(attn.to_out[0])]
+        self.is_cross = False
+        self._fused = {}
+
+    def prepare_attention_mask(self, attention_mask, target_length, batch_size=None):
+        if attention_mask is not None:
+            raise NotImplementedError("attention masks are never used on this path (SURVEY.md A2)")
+        return None
+
+    def fused_packs(self):
+        a = self.attn
+        key = (self.is_cross,) + tuple((m.weight.data_ptr(), m.weight._version) for m in (a.to_q, a.to_k, a.to_v))
+        hit = self._fused.get(self.is_cross)
+        if hit is None or hit[0] != key:
+            if self.is_cross:
+                packs = (ops.LinearPack(a.to_q.weight, None), ops.LinearPack(torch.cat([a.to_k.weight, a.to_v.weight], 0), None))
+            else:
+                packs = (ops.LinearPack(torch.cat([a.to_q.weight, a.to_k.weight, a.to_v.weight], 0), None),)
+            hit = self._fused[self.is_cross] = (key, packs)
+        return hit[1]
+
+    def attend(self, q_or_qkv, kv, B, N, Nk):
+        if kv is None:
+            return ops.attention_self(q_or_qkv, B, self.heads, N, self.dim_head, self.scale)
+        return ops.attention_cross(q_or_qkv, kv, B, self.heads, N, Nk, self.dim_head, self.scale)
+
+
+def _host(attn, encoder_hidden_states):
+    """this repository's `unet.CrossAttention` as it is; anything else through a StockAttentionHost kept on the module"""
+    if hasattr(attn, "fused_packs"):
+        return attn
+    host = attn.__dict__.get("_clora_host")
+    if host is None:
+        host = attn.__dict__["_clora_host"] = StockAttentionHost(attn)
+    host.is_cross = encoder_hidden_states is not None
+    return host
+
+
 # ---- inference-only cache of the cross-attention K/V projections.  k = Wk e + s Lk(e), v = Wv e + s Lv(e) depend on the
 # text embedding and the (frozen, at inference) adapters only -- not on the latents or the timestep -- so a scheduler loop
 # (apps/gradio_canny2image.py:85-88: 50 UNet calls per image) needs them once.  Active only inside `text_kv_cache()` and
@@ -198,6 +266,7 @@ class LoRACrossAttnProcessor(nn.Module):
         return ops.lora_proj(a, attn.to_out[0].pack(), [out_seg], residual=res2)
 
     def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, scale=1.0, residual=None):
+        attn = _host(attn, encoder_hidden_states)
         attn.prepare_attention_mask(attention_mask, hidden_states.shape[1])
         if self._needs_generic_path():
             return self._generic_call(attn, hidden_states, encoder_hidden_states, scale, residual)
@@ -276,6 +345,7 @@ class ControlLoRACrossAttnProcessor(_ControlMixin, LoRACrossAttnProcessor):
 
     def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, scale=1.0, residual=None):
         assert self.control_states is not None
+        attn = _host(attn, encoder_hidden_states)
         attn.prepare_attention_mask(attention_mask, hidden_states.shape[1])
         if self._needs_generic_path():
             return self._generic_call(attn, hidden_states, encoder_hidden_states, scale, residual)
@@ -324,6 +394,7 @@ class ControlLoRACrossAttnProcessorV2(_ControlMixin, LoRACrossAttnProcessor):
 
     def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, scale=1.0, residual=None):
         assert self.control_states is not None
+        attn = _host(attn, encoder_hidden_states)
         attn.prepare_attention_mask(attention_mask, hidden_states.shape[1])
         if self._needs_generic_path():
             return self._generic_call(attn, hidden_states, encoder_hidden_states, scale, residual)

@@ -549,6 +549,10 @@ def _fuse_plan(M, N, Kd, seg_w):
     (the deeper UNet levels, where the 320-column tiles would leave most CUs idle)"""
     if not FUSE_DOWN or Kd % 64 or seg_w % 64:
         return None
+    hx = K._tuned_fused(M, N, Kd)                              # a tile timed WITH the extra operand rows (tools/tune_fused.py)
+    if hx is not None and seg_w % ({**SMALL_FUSE_TILES, 51: 320, 52: 320, 54: 320, 55: 320}.get(hx[0], 1 << 30)) == 0 and \
+            (FUSE_SMALL or hx[0] not in SMALL_FUSE_TILES):
+        return hx[0]
     if seg_w % FUSE_TILE_N == 0 and _fills_the_chip(M, N):
         return 0
     hit = K._tuned(M, N, Kd, None) if FUSE_SMALL else None

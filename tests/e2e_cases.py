@@ -292,3 +292,80 @@ def check_site_real_shape(dev, hidden=320, side=32, B=2, rank=4, control_rank=25
     bad = {k: v for k, v in errs.items() if k != "y" and v > tol_g}
     assert not bad, (bad, errs)
     return errs
+
+
+def check_stock_attention_host(kind, dev, B=2, side=4, C=64, heads=4, ctx=48, ctrl_c=32, tol_y=4e-3, tol_g=1.2e-2):
+    """The product processors installed on a module that has ONLY the stock diffusers `CrossAttention` surface (reference
+    models.py:122-150: to_q / to_k / to_v / to_out / heads / scale; here oracle/unet_ref.CrossAttention with fp16 weights), called the way
+    diffusers calls them (`attn(hidden, encoder_hidden_states=..., scale=...)` -> `processor(attn, ...)`): models.StockAttentionHost packs
+    the frozen weights and the site runs on the same kernels -- output and every gradient (a) equal to the same processor on this
+    repository's own unet.CrossAttention, bit for bit, and (b) within the site tolerances of the oracle processor on the fp32 module."""
+    import copy
+    from oracle import controllora_ref as cr
+    torch.manual_seed(0)
+    N = side * side
+    worst = {}
+    for self_attn in (True, False):
+        cad = None if self_attn else ctx
+        o_attn = unet_ref.CrossAttention(C, cad, heads=heads, dim_head=C // heads)
+        cases.seeded_weights_(o_attn, seed=5)
+        own = U.CrossAttention(C, cad, heads=heads, dim_head=C // heads)
+        with torch.no_grad():
+            for k, v in own.state_dict().items():
+                v.copy_(o_attn.state_dict()[k].to(v.dtype))
+        own.to(dev)
+        stock = copy.deepcopy(o_attn).half().to(dev).requires_grad_(False)          # what `unet.to(device, dtype=fp16)` leaves (train...:493)
+        assert not hasattr(stock, "fused_packs")
+        for q in o_attn.parameters():
+            q.data = q.data.half().float()
+        if kind == "v1":
+            mk_o, mk_p = (lambda: cr.ControlLoRAProcRef(C, cad, rank=4)), (lambda: M.ControlLoRACrossAttnProcessor(C, cad, rank=4))
+        elif kind == "v2":
+            mk_o = lambda: cr.ControlLoRAProcV2Ref(C, cad, rank=4, control_channels=ctrl_c)
+            mk_p = lambda: M.ControlLoRACrossAttnProcessorV2(C, cad, rank=4, control_channels=ctrl_c)
+        else:
+            mk_o, mk_p = (lambda: cr.LoRAProcRef(C, cad, rank=4)), (lambda: M.LoRACrossAttnProcessor(C, cad, rank=4))
+        o_p = mk_o()
+        cases.seeded_weights_(o_p, seed=3, up_std=0.05)
+        h = torch.randn(B, N, C).half()
+        e = None if self_attn else torch.randn(B, 5, ctx).half()
+        ctrl = torch.randn(B, C if kind == "v1" else ctrl_c, side, side).half()
+        go = torch.randn(B, N, C).half()
+        ho, co = h.float().requires_grad_(True), ctrl.float().requires_grad_(True)
+        if kind != "lora":
+            o_p.inject_control_states(co)
+        o_attn.set_processor(o_p)
+        yo = o_attn(ho, encoder_hidden_states=None if e is None else e.float(), scale=0.7)
+        yo.backward(go.float())
+
+        def run(attn_mod):
+            p = mk_p()
+            p.load_state_dict(o_p.state_dict())
+            p.to(dev)
+            hp = h.clone().to(dev).requires_grad_(True)
+            cp = ctrl.permute(0, 2, 3, 1).reshape(B, N, -1).contiguous().to(dev).requires_grad_(True)
+            if kind != "lora":
+                p.inject_control_states(cp)
+            attn_mod.set_processor(p)
+            y = attn_mod(hp, encoder_hidden_states=None if e is None else e.to(dev), scale=0.7)
+            y.backward(go.to(dev))
+            return y.detach(), hp.grad, (cp.grad if kind != "lora" else None), [q.grad for q in p.parameters()]
+
+        ys, dhs, dcs, dws = run(stock)
+        yw, dhw, dcw, dww = run(own)
+        assert torch.equal(ys, yw) and torch.equal(dhs, dhw), "stock-module host differs from unet.CrossAttention"
+        assert dcs is None or torch.equal(dcs, dcw)
+        assert all((a is None and b is None) or torch.equal(a, b) for a, b in zip(dws, dww))
+        errs = {"y": rel(ys, yo.detach()), "dh": rel(dhs, ho.grad)}
+        if kind != "lora":
+            errs["dctrl"] = rel(dcs, co.grad.permute(0, 2, 3, 1).reshape(B, N, -1))
+        for (n, b_), a in zip(o_p.named_parameters(), dws):
+            if b_.grad is not None and float(b_.grad.norm()) > 0:
+                errs["dw:" + n] = rel(a, b_.grad)
+        assert errs["y"] < tol_y, errs
+        bad = {k: v for k, v in errs.items() if k != "y" and v > (2.5e-2 if k.startswith("dw") else tol_g)}
+        assert not bad, (bad, errs)
+        assert "_clora_host" in stock.__dict__ and "_clora_host" not in dict(stock.named_modules())
+        for k, v in errs.items():
+            worst[k] = max(worst.get(k, 0.0), v)
+    return worst

@@ -18,7 +18,8 @@ def test_sobel_gradient_matches_scipy():
     rng = np.random.default_rng(0)
     g = rng.integers(0, 256, (37, 53)).astype(np.float32)
     kx = np.array([[-1, 0, 1], [-2, 0, 2], [-1, 0, 1]], np.float32)
-    gx, gy = app._conv2_same(g, kx), app._conv2_same(g, kx.T)
+    from controllora_amd.process import _conv2_same
+    gx, gy = _conv2_same(g, kx), _conv2_same(g, kx.T)
     sx, sy = ndi.sobel(g, axis=1, mode="nearest"), ndi.sobel(g, axis=0, mode="nearest")
     assert np.allclose(np.abs(gx), np.abs(sx), atol=1e-3) and np.allclose(np.abs(gy), np.abs(sy), atol=1e-3)
 

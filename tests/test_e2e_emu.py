@@ -27,6 +27,13 @@ def test_pre_post_lora_chain_matches_oracle(kind):
     print(kind, E.check_pre_post_chain(kind, "cpu"))
 
 
+@pytest.mark.parametrize("kind", ["v1", "v2", "lora"])
+def test_processors_run_on_a_stock_cross_attention_module(kind):
+    """reference models.py:122-150: the processors on a module with only the diffusers `CrossAttention` surface (host logic of
+    models.StockAttentionHost on the emulated kernels; the GPU suite repeats it at a real width)"""
+    print(kind, E.check_stock_attention_host(kind, "cpu"))
+
+
 def test_trainer_accumulation_lr_schedule_and_resume(golden_dir):
     """host logic of gradient accumulation / LR multiplier / checkpoint-resume with synthetic gradients (the full
     version with real forward/backward passes runs in the GPU suite: tests/test_e2e_gpu.py)"""

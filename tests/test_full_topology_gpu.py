@@ -85,6 +85,14 @@ def test_pre_post_lora_chain_on_gpu(kind):
     print("CHAIN C=320", kind, E.check_pre_post_chain(kind, "cuda", B=2, side=16, C=320, heads=8, ctx=768, ctrl_c=256))
 
 
+@pytest.mark.parametrize("kind", ["v1", "v2", "lora"])
+def test_processors_on_a_stock_cross_attention_module_on_gpu(kind):
+    """reference models.py:122-150: product processors installed on a module that has only the stock diffusers `CrossAttention`
+    surface -- bit-identical to the same processors on unet.CrossAttention, within site tolerance of the oracle; small and C = 320"""
+    print("STOCK small", kind, E.check_stock_attention_host(kind, "cuda"))
+    print("STOCK C=320", kind, E.check_stock_attention_host(kind, "cuda", B=2, side=16, C=320, heads=8, ctx=768, ctrl_c=256))
+
+
 def test_baseline_full_size_properties():
     """BASELINE configs[1] at its full size (512x512, batch 4) through size-independent properties: zero-init identity (bit exact),
     batch independence, gradient additivity over the batch, linearity of the backward in its seed"""

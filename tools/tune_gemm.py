@@ -22,6 +22,8 @@ ap.add_argument("--cfgs", default="", help="comma list of tile_cfg values to swe
 ap.add_argument("--plain-only", action="store_true", help="only the plain (non-conv) GEMM signatures")
 ap.add_argument("--vae", type=int, default=0, metavar="B", help="tune the GEMM / conv signatures of the SD-1.5 VAE instead (encode + decode "
                 "of B images at --res: reference train...:753-754, apps/gradio_canny2image.py:88-92); implies --merge")
+ap.add_argument("--geglu", action="store_true", help="only the FeedForward GEMMs that carry the fused GEGLU activation (forward / backward), "
+                "timed WITH it (the activation is most of such a launch: the default pass times the bare GEMM); implies --merge")
 ap.add_argument("--patch-only", action="store_true", help="only the signatures the patch-staged 3x3 conv kernel can take (tile_cfg 71..75)")
 args = ap.parse_args()
 dev = torch.device("cuda", 0)
@@ -35,6 +37,7 @@ seen = {}
 epis = {}            # signature -> {epilogue shape: count}: each signature is timed with its most frequent epilogue
 orig = K.gemm
 wide_only = set()           # signatures used with the GEGLU-forward epilogue: tiles must be >= 128 columns wide
+geglu_mode = {}             # signature -> (1 forward | 2 backward, keep_h): timed WITH the fused activation (it is most of the launch)
 def rec(A, Bw, M, N, Kd, **kw):
     conv = kw.get("conv")
     ck = tuple(getattr(conv, f) for f, _ in ConvDesc._fields_) if conv is not None else None
@@ -49,6 +52,9 @@ def rec(A, Bw, M, N, Kd, **kw):
     epis[(M, N, Kd, ck)][epi] += 1
     if kw.get("geglu") == 1:
         wide_only.add((M, N, Kd, ck))
+        geglu_mode[(M, N, Kd, ck)] = (1, bool(kw.get("geglu_keep_h", True)))
+    elif kw.get("geglu") == 2:
+        geglu_mode[(M, N, Kd, ck)] = (2, True)
     return orig(A, Bw, M, N, Kd, **kw)
 K.gemm = rec
 import controllora_amd.ops as ops
@@ -92,6 +98,8 @@ CFGS = [1, 2, 3, 4, 5, 6, 7, 8, 21, 22, 23, 26, 31, 32, 33, 41, 42, 43, 51, 52, 
 if args.cfgs:
     CFGS = [int(c) for c in args.cfgs.split(",")]
 path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "controllora_amd", "gemm_tuning_gfx950.json")
+if args.geglu:
+    args.merge = True
 table = json.load(open(path))["table"] if (args.merge and os.path.exists(path)) else {}
 tot_auto = tot_best = tot_r01 = 0.0
 for (M, N, Kd, ck), cnt in sorted(seen.items(), key=lambda kv: -kv[0][0] * kv[0][1] * kv[0][2]):
@@ -114,6 +122,19 @@ for (M, N, Kd, ck), cnt in sorted(seen.items(), key=lambda kv: -kv[0][0] * kv[0]
         ekw.update(lora_t=torch.randn(M, max(tcols, lr), device=dev), lora_seg=lseg, lora_u_tr=u_tr, lora_r=lr,
                    lora_u=(torch.randn(max(1, tcols), Kd if False else N, device=dev) if u_tr else torch.randn(N, lr, device=dev)))
     run = lambda sk, tile: K.gemm(A, Bw, M, N, Kd, conv=conv, out=out, split_k=sk, tile_cfg=tile, _tuned=False, **ekw)
+    gm = geglu_mode.get((M, N, Kd, ck))
+    if gm is not None and args.geglu:
+        if gm[0] == 1:
+            gy = torch.empty(M, N // 2, device=dev, dtype=torch.float16)
+            gb = torch.randn(N, device=dev) if has_bias else None
+            run = lambda sk, tile: K.gemm(A, Bw, M, N, Kd, bias=gb, geglu=1, geglu_y=gy, geglu_keep_h=gm[1], tile_cfg=tile, _tuned=False)
+        else:
+            gh = torch.randn(M, 2 * N, device=dev).half()
+            go = torch.empty(M, 2 * N, device=dev, dtype=torch.float16)
+            run = lambda sk, tile: K.gemm(A, Bw, M, N, Kd, geglu=2, geglu_h=gh, out=go, tile_cfg=tile, _tuned=False)
+    elif args.geglu:
+        del A, Bw, out, res_
+        continue
     if (args.patch_only and not (conv is not None and any(K.conv_patch_eligible(M, conv, c) for c in K.PATCH_TILE_CFGS))) or \
             (args.plain_only and conv is not None):
         del A, Bw, out, res_
@@ -133,7 +154,7 @@ for (M, N, Kd, ck), cnt in sorted(seen.items(), key=lambda kv: -kv[0][0] * kv[0]
             continue                                       # would only re-time the fallback
         prev = None
         for sk in (1, 2, 3, 4, 6, 8, 12, 16):
-            if sk > 1 and (geglu_sig or (Kd // 32) // sk < 4 or sk * M * N * 4 > K.GEMM_WS_BYTES or M * N > 16384 * 1280):
+            if sk > 1 and (geglu_sig or (gm is not None and args.geglu) or (Kd // 32) // sk < 4 or sk * M * N * 4 > K.GEMM_WS_BYTES or M * N > 16384 * 1280):
                 break
             if tile in K.PATCH_TILE_CFGS and sk > conv.Cin // 64:
                 break

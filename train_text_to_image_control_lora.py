@@ -88,6 +88,9 @@ def build_dataset(args, tokenizer):
     if args.dataset_name is not None and args.dataset_name.startswith("synthetic:"):
         n = args.max_train_samples or 50000
         return data.SyntheticFill50k(args.resolution, n, seed=args.seed if args.seed is not None else 42, tokenizer=tokenizer)
+    if args.dataset_name is not None and args.dataset_name.startswith("process/"):       # reference train...:546-550
+        from controllora_amd import process
+        return process.Dataset.from_name(args.dataset_name)(tokenizer, resolution=args.resolution, use_crop=True)
     from datasets import load_dataset
     if args.dataset_name is not None:
         ds = load_dataset(args.dataset_name, args.dataset_config_name, cache_dir=args.cache_dir)
