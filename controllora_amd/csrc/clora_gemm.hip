@@ -1433,7 +1433,7 @@ int conv_mode(const GemmArgs& a, int bk) {
 // activations and n-major ranges (m fastest) are the cheaper assignment.  The model counts, per XCD and split, the distinct
 // panels of its range under either order.   "tile_order": 0 m-major always, 1 n-major always
 // (tests), 2 pick by the model.
-int g_opts[CLORA_OPT_COUNT] = {2, 1, 0, 0, 512, 1, 1, 0, 1};    // tile_order, ln_rows, attn_fwd_waves (0 = auto), attn_bwd_waves (0 = auto), gn_blocks, epi_two_phase, lora_down_mode, gn_unroll, epi_hoist
+int g_opts[CLORA_OPT_COUNT] = {2, 1, 0, 0, 512, 1, 1, 0, 1, 1};    // tile_order, ln_rows, attn_fwd_waves (0 = auto), attn_bwd_waves (0 = auto), gn_blocks, epi_two_phase, lora_down_mode, gn_unroll, epi_hoist, gn_resident
 int tile_order_mode() { return g_opts[CLORA_OPT_TILE_ORDER]; }
 
 double fabric_model_bytes(int tiles_m, int tiles_n, int splits, double a_panel, double b_panel, bool n_major) {
@@ -1761,7 +1761,7 @@ extern "C" int clora_set_option(const char* name, int value) {
                                 {"attn_fwd_waves", CLORA_OPT_ATTN_FWD_WAVES, 0, 8}, {"attn_bwd_waves", CLORA_OPT_ATTN_BWD_WAVES, 0, 8},
                                 {"gn_blocks", CLORA_OPT_GN_BLOCKS, 64, 1 << 16}, {"epi_two_phase", CLORA_OPT_EPI_TWO_PHASE, 0, 1},
                                 {"lora_down_mode", CLORA_OPT_LORA_DOWN_MODE, 0, 2}, {"gn_unroll", CLORA_OPT_GN_UNROLL, 0, 1},
-                                {"epi_hoist", CLORA_OPT_EPI_HOIST, 0, 1}};
+                                {"epi_hoist", CLORA_OPT_EPI_HOIST, 0, 1}, {"gn_resident", CLORA_OPT_GN_RESIDENT, 0, 1}};
     for (const Opt& o : kOpts)
         if (!strcmp(name, o.name)) {
             if (value < o.lo || value > o.hi) return CLORA_ERR_ARG;

@@ -407,6 +407,198 @@ __global__ __launch_bounds__(256) void gn_bwd_params_kernel(GnArgs p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------ GroupNorm in ONE launch
+// The 16x16 / 8x8 (and, at 512 threads, 32x32) feature maps: a whole (batch element, channel slab) is 20-160 KB, the two-launch
+// scheme above spends most of its 9-15 us on fixed cost (two launches, the partials' round trip through L2, two ramp-ups) and reads x
+// twice.  Here a block owns (batch b, slab of whole groups, ALL rows) and keeps its part of x (backward: x and dy) in registers between
+// the statistics and the apply: one launch, one read, one write, no workspace.  Thread map as above (fixed column chunk per thread, row
+// lanes), so loads stay whole 16-byte chunks of contiguous row segments; the block reduction is per channel through LDS, a fixed-order
+// pairwise tree over the row lanes (every thread folds; log2(nrl) steps), then per group (8 threads per group + shuffles).
+// Frozen affine only (no dgamma / dbeta: the UNet's norms; the hint encoder's trainable norms are 256^2 / 512^2 maps and stay above).
+template <int NT>
+__device__ __forceinline__ void gn_res_reduce(float* red, float* chs, const float (&a)[8], const float (&b)[8], int t, int CS, int cpg, int gps,
+                                              int rl, int nrl, int c0, bool active, const float* weight, float* out2, float inv_n) {
+    const int W = CS * 2;
+    if (active) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { red[rl * W + (c0 * 8 + e) * 2] = a[e]; red[rl * W + (c0 * 8 + e) * 2 + 1] = b[e]; }
+    }
+    __syncthreads();
+    // per channel: `seg` adjacent threads each fold every seg-th row lane, then shuffles (fixed order); three barriers in all
+    int seg = 1;
+    while (seg < 8 && seg * 2 * CS <= NT) seg *= 2;
+    {
+        const int c = t / seg, sg = t - c * seg;
+        float sa = 0.f, sb = 0.f;
+        if (c < CS)
+            for (int r = sg; r < nrl; r += seg) { sa += red[r * W + c * 2]; sb += red[r * W + c * 2 + 1]; }
+        if (seg > 1) { sa += __shfl_xor(sa, 1); sb += __shfl_xor(sb, 1); }
+        if (seg > 2) { sa += __shfl_xor(sa, 2); sb += __shfl_xor(sb, 2); }
+        if (seg > 4) { sa += __shfl_xor(sa, 4); sb += __shfl_xor(sb, 4); }
+        if (c < CS && sg == 0) { chs[c * 2] = sa; chs[c * 2 + 1] = sb; }
+    }
+    __syncthreads();
+    // per group: 8 threads, each every 8th channel, then three shuffles
+    const int g = t >> 3, part = t & 7;
+    float sa = 0.f, sb = 0.f;
+    if (g < gps) {
+        for (int c = g * cpg + part; c < (g + 1) * cpg; c += 8) {
+            const float w = weight ? weight[c] : 1.0f;
+            sa += w * chs[c * 2]; sb += w * chs[c * 2 + 1];
+        }
+    }
+    sa += __shfl_xor(sa, 1); sb += __shfl_xor(sb, 1);
+    sa += __shfl_xor(sa, 2); sb += __shfl_xor(sb, 2);
+    sa += __shfl_xor(sa, 4); sb += __shfl_xor(sb, 4);
+    if (g < gps && part == 0) { out2[g * 2] = sa * inv_n; out2[g * 2 + 1] = sb * inv_n; }
+    __syncthreads();
+}
+
+template <int NT, int NPT>
+__global__ __launch_bounds__(NT) void gn_fwd_resident_kernel(GnArgs p) {
+    __shared__ float red[NT * 16];                               // [nrl][CS][2] with nrl * CS <= NT * 8
+    __shared__ float chs[256 * 8 * 2];                           // per-channel totals of the slab (CS <= 2048)
+    __shared__ float mr[64 * 2];
+    const int t = threadIdx.x, b = blockIdx.z, cb = blockIdx.y * p.CS;
+    const int CH = p.CS / 8, cpg = p.C / p.G, gps = p.G / p.nslab;
+    const int nrl = NT / CH, rl = t / CH, c0 = t - rl * CH;
+    const bool active = rl < nrl;
+    const int npt = (p.HW + nrl - 1) / nrl;                      // block-uniform, <= NPT
+    const half_t* base = p.x + (size_t)b * p.HW * p.C + cb + c0 * 8;
+    // the affine parameters of this thread's eight channels travel with the x loads (they were a second dependent round trip after
+    // the reduction)
+    const floatx4* gp = reinterpret_cast<const floatx4*>(p.gamma + cb + c0 * 8);
+    const floatx4* bp = reinterpret_cast<const floatx4*>(p.beta + cb + c0 * 8);
+    const floatx4 ga = gp[0], gb = gp[1], ba = bp[0], bb = bp[1];
+    half8 v[NPT];
+    float s[8], q[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
+    if (active) {
+#pragma unroll
+        for (int k = 0; k < NPT; ++k) {
+            const int r = rl + k * nrl;
+            v[k] = (k < npt) ? ld8(base + (size_t)(r < p.HW ? r : 0) * p.C) : zero8();
+        }
+#pragma unroll
+        for (int k = 0; k < NPT; ++k) {
+            const bool ok = k < npt && rl + k * nrl < p.HW;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float f = ok ? (float)v[k][e] : 0.f; s[e] += f; q[e] += f * f; }
+        }
+    }
+    gn_res_reduce<NT>(red, chs, s, q, t, p.CS, cpg, gps, rl, nrl, c0, active, nullptr, mr, 1.0f / ((float)p.HW * (float)cpg));
+    if (t < gps) {                                               // (E[x], E[x^2]) -> (mean, rstd)
+        const float mean = mr[t * 2];
+        float var = mr[t * 2 + 1] - mean * mean;
+        var = var < 0.f ? 0.f : var;
+        const float rstd = rsqrtf(var + p.eps);
+        mr[t * 2 + 1] = rstd;
+        float* st = p.stats + ((size_t)b * p.G + blockIdx.y * gps + t) * 2;
+        st[0] = mean; st[1] = rstd;
+    }
+    __syncthreads();
+    if (!active) return;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int cl = c0 * 8 + e, g = cl / cpg;
+        sc[e] = mr[g * 2 + 1] * (e < 4 ? ga[e & 3] : gb[e & 3]);
+        sh[e] = (e < 4 ? ba[e & 3] : bb[e & 3]) - mr[g * 2] * sc[e];
+    }
+    half_t* ybase = p.y + (size_t)b * p.HW * p.C + cb + c0 * 8;
+#pragma unroll
+    for (int k = 0; k < NPT; ++k) {
+        const int r = rl + k * nrl;
+        half8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float yv = (float)v[k][e] * sc[e] + sh[e];
+            if (p.fuse_silu) yv = silu_f(yv);
+            o[e] = (half_t)yv;
+        }
+        if (k < npt && r < p.HW) st8(ybase + (size_t)r * p.C, o);
+    }
+}
+
+template <int NT, int NPT>
+__global__ __launch_bounds__(NT) void gn_bwd_resident_kernel(GnArgs p) {
+    __shared__ float red[NT * 16];
+    __shared__ float chs[256 * 8 * 2];
+    __shared__ float gs[64 * 2];
+    const int t = threadIdx.x, b = blockIdx.z, cb = blockIdx.y * p.CS;
+    const int CH = p.CS / 8, cpg = p.C / p.G, gps = p.G / p.nslab;
+    const int nrl = NT / CH, rl = t / CH, c0 = t - rl * CH;
+    const bool active = rl < nrl;
+    const int npt = (p.HW + nrl - 1) / nrl;
+    const size_t boff = (size_t)b * p.HW * p.C + cb + c0 * 8;
+    float mean[8], rstd[8], sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int ch = cb + (active ? c0 : 0) * 8 + e;
+        const float* st = p.stats + ((size_t)b * p.G + ch / cpg) * 2;
+        mean[e] = st[0]; rstd[e] = st[1];
+        sc[e] = rstd[e] * p.gamma[ch];
+        sh[e] = p.beta[ch] - mean[e] * sc[e];
+    }
+    half8 xv[NPT], gv[NPT];
+    float a1[8], a2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { a1[e] = 0.f; a2[e] = 0.f; }
+    if (active) {
+#pragma unroll
+        for (int k = 0; k < NPT; ++k) {
+            const int r = rl + k * nrl;
+            const size_t off = boff + (size_t)(r < p.HW ? r : 0) * p.C;
+            xv[k] = (k < npt) ? ld8(p.x + off) : zero8();
+            gv[k] = (k < npt) ? ld8(p.dy + off) : zero8();
+        }
+#pragma unroll
+        for (int k = 0; k < NPT; ++k) {
+            const bool ok = k < npt && rl + k * nrl < p.HW;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float xf = (float)xv[k][e];
+                const float xh = (xf - mean[e]) * rstd[e];
+                float d = ok ? (float)gv[k][e] : 0.f;
+                if (p.fuse_silu) d *= dsilu_f(xf * sc[e] + sh[e]);
+                a1[e] += d;
+                a2[e] += d * xh;
+            }
+        }
+    }
+    gn_res_reduce<NT>(red, chs, a1, a2, t, p.CS, cpg, gps, rl, nrl, c0, active, p.gamma + cb, gs, 1.0f / ((float)p.HW * (float)cpg));
+    if (!active) return;
+    float k2[8], k3[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int g = (c0 * 8 + e) / cpg;
+        k2[e] = -rstd[e] * rstd[e] * gs[g * 2 + 1];
+        k3[e] = -k2[e] * mean[e] - rstd[e] * gs[g * 2];
+    }
+    const bool has_res = p.dres != nullptr;
+#pragma unroll
+    for (int k = 0; k < NPT; ++k) {
+        const int r = rl + k * nrl;
+        if (!(k < npt && r < p.HW)) continue;
+        const size_t off = boff + (size_t)r * p.C;
+        half8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float xf = (float)xv[k][e];
+            float d = (float)gv[k][e];
+            if (p.fuse_silu) d *= dsilu_f(xf * sc[e] + sh[e]);
+            o[e] = (half_t)(sc[e] * d + k2[e] * xf + k3[e]);
+        }
+        if (has_res) {
+            const half8 rv = ld8(p.dres + off);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (half_t)((float)o[e] + (float)rv[e]);
+        }
+        st8(p.y + off, o);
+    }
+}
+
 // ------------------------------------------------------------------------------------------ LayerNorm
 struct LnArgs {
     const half_t* x;
@@ -719,6 +911,32 @@ int gn_plan(GnArgs& a, void* ws, size_t ws_bytes, bool bwd, bool params) {
     return CLORA_OK;
 }
 
+// One-launch variant: which (threads, rows per thread) instantiation takes this shape, or 0.  Slabs = the smallest whole-group,
+// 8-channel-aligned unit that is at least 40 channels wide (80-byte row segments), one block per (slab, batch element).
+struct GnResident { int nt, npt; };
+GnResident gn_resident_plan(GnArgs& a, bool bwd, bool params) {
+    GnResident none = {0, 0};
+    if (!clora_option(CLORA_OPT_GN_RESIDENT) || params) return none;
+    const int cpg = a.C / a.G;
+    int unit = 1;
+    while ((unit * cpg) & 7) ++unit;
+    if (a.G % unit) return none;
+    int groups = unit;
+    while (groups * cpg < 40 && groups * 2 <= a.G && a.G % (groups * 2) == 0) groups *= 2;
+    const int CS = groups * cpg, CH = CS / 8;
+    if (groups > 64 || CH > 256) return none;
+    const int max_npt = bwd ? 8 : 16;
+    for (int nt = 256; nt <= 512; nt *= 2) {
+        const int nrl = nt / CH, npt = (a.HW + nrl - 1) / nrl;
+        if (npt <= max_npt && groups * 8 <= nt) {
+            a.nslab = a.G / groups; a.CS = CS; a.nchunk = 1; a.rows_per_chunk = a.HW;
+            GnResident r = {nt, npt <= 4 ? 4 : (npt <= 8 ? 8 : 16)};
+            return r;
+        }
+    }
+    return none;
+}
+
 int ew_blocks(size_t n) {
     size_t b = (n + 255) / 256;
     return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
@@ -743,9 +961,20 @@ extern "C" int clora_groupnorm_fwd_f16(const clora_half* x, clora_half* y, const
     GnArgs a = GnArgs();
     a.x = (const half_t*)x; a.y = (half_t*)y; a.gamma = gamma; a.beta = beta; a.stats = stats;
     a.B = B; a.HW = HW; a.C = C; a.G = G; a.eps = eps; a.fuse_silu = fuse_silu;
+    if (B <= 0 || HW <= 0 || C <= 0 || G <= 0 || G > 64 || (C % G) || (C & 7) || C > 4096) return CLORA_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const GnResident res = gn_resident_plan(a, false, false);
+    if (res.nt) {
+        const dim3 rgrid(1, a.nslab, B);
+        if (res.nt == 256 && res.npt == 4) hipLaunchKernelGGL((gn_fwd_resident_kernel<256, 4>), rgrid, dim3(256), 0, s, a);
+        else if (res.nt == 256 && res.npt == 8) hipLaunchKernelGGL((gn_fwd_resident_kernel<256, 8>), rgrid, dim3(256), 0, s, a);
+        else if (res.nt == 256) hipLaunchKernelGGL((gn_fwd_resident_kernel<256, 16>), rgrid, dim3(256), 0, s, a);
+        else if (res.npt <= 8) hipLaunchKernelGGL((gn_fwd_resident_kernel<512, 8>), rgrid, dim3(512), 0, s, a);
+        else hipLaunchKernelGGL((gn_fwd_resident_kernel<512, 16>), rgrid, dim3(512), 0, s, a);
+        return clora_check_launch();
+    }
     int rc = gn_plan(a, workspace, workspace_bytes, false, false);
     if (rc != CLORA_OK) return rc;
-    hipStream_t s = (hipStream_t)stream;
     const dim3 grid(a.nchunk, a.nslab, B);
     if (a.CS / 8 > 256) {                                        // slabs wider than 2048 channels: two column chunks per thread
         hipLaunchKernelGGL(gn_fwd_partial_kernel<2>, grid, dim3(256), 0, s, a);
@@ -771,9 +1000,18 @@ extern "C" int clora_groupnorm_bwd_f16(const clora_half* x, const clora_half* dy
     a.x = (const half_t*)x; a.dy = (const half_t*)dy; a.dres = (const half_t*)dres; a.y = (half_t*)dx; a.gamma = gamma; a.beta = beta;
     a.stats = const_cast<float*>(stats); a.dgamma = dgamma; a.dbeta = dbeta;
     a.B = B; a.HW = HW; a.C = C; a.G = G; a.fuse_silu = fuse_silu; a.accumulate_params = accumulate_params;
+    if (B <= 0 || HW <= 0 || C <= 0 || G <= 0 || G > 64 || (C % G) || (C & 7) || C > 4096) return CLORA_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const GnResident res = gn_resident_plan(a, true, dgamma != nullptr);
+    if (res.nt) {
+        const dim3 rgrid(1, a.nslab, B);
+        if (res.nt == 256 && res.npt == 4) hipLaunchKernelGGL((gn_bwd_resident_kernel<256, 4>), rgrid, dim3(256), 0, s, a);
+        else if (res.nt == 256) hipLaunchKernelGGL((gn_bwd_resident_kernel<256, 8>), rgrid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((gn_bwd_resident_kernel<512, 8>), rgrid, dim3(512), 0, s, a);
+        return clora_check_launch();
+    }
     int rc = gn_plan(a, workspace, workspace_bytes, true, dgamma != nullptr);
     if (rc != CLORA_OK) return rc;
-    hipStream_t s = (hipStream_t)stream;
     const dim3 grid(a.nchunk, a.nslab, B);
     const bool two = a.CS / 8 > 256;                             // slabs wider than 2048 channels
     if (two) hipLaunchKernelGGL(gn_bwd_partial_kernel<2>, grid, dim3(256), 0, s, a);

@@ -140,9 +140,10 @@ int clora_gemm_f16_ex(const clora_half* A, int lda, const clora_half* B, clora_h
  * reference op is the same F.conv2d of upstream ResnetBlock2D; tuner / tests use this to know what they time. */
 int clora_conv_patch_eligible(int M, const clora_conv_t* conv, int tile_cfg);
 
-/* Tuning knobs, no reference counterpart: results never depend on them (bit-identical outputs, tests/test_kernels_*.py; the one
- * exception is "lora_down_mode", which changes how the fp32 sum over K is partitioned -- bit-identical per mode, equal to
- * ~1e-7 relative across modes, tests/test_kernels_gpu.py::test_lora_down_launch_modes).
+/* Tuning knobs, no reference counterpart: results never depend on them (bit-identical outputs, tests/test_kernels_*.py; the two
+ * exceptions re-partition an fp32 sum: "lora_down_mode" (the sum over K) -- bit-identical per mode, equal to ~1e-7 relative across
+ * modes, tests/test_kernels_gpu.py::test_lora_down_launch_modes -- and "gn_resident" (the GroupNorm statistics) -- bit-identical per
+ * setting, a few fp16 ulps on a handful of outputs across settings, tests/kernel_cases.py::case_groupnorm).
  * This table is the ABI's ONLY process-global state (every other entry point is a pure function of its arguments and the
  * stream); the library reads no environment variable.  A knob takes effect for the launches that follow (a captured hipGraph
  * keeps what it was captured with).
@@ -163,6 +164,9 @@ int clora_conv_patch_eligible(int M, const clora_conv_t* conv, int tile_cfg);
  *   "epi_hoist"       1 = the 8-wave GEMM tiles keep a thread's adapter up-matrix columns and bias in registers for the whole tile
  *                     (default), 0 = fetch them per output chunk like the 4-wave tiles do (a switch to take the hoisted epilogue out
  *                     of the path without a rebuild; launches with lora_dpack always hoist).
+ *   "gn_resident"     1 = GroupNorm passes whose (batch element, channel slab) fits in a block's registers run as ONE launch (statistics
+ *                     and apply from the same registers: the 8x8 / 16x16 / 32x32 feature maps of the UNet); 0 = always the two-launch
+ *                     partial + apply scheme.  Frozen affine only; same arithmetic, a different (still fixed) summation order.
  * Unknown names / values: CLORA_ERR_ARG. */
 int clora_set_option(const char* name, int value);
 

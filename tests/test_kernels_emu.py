@@ -162,7 +162,11 @@ def test_attention_rising_maxima(D):
                                                  (2, 64, 32, 32, True, True), (1, 9, 2560, 32, True, False),
                                                  (2, 300, 64, 8, True, False), (2, 256, 320, 32, False, False),
                                                  (1, 40, 2056, 8, True, True),      # one 2056-channel slab: two column chunks per thread
-                                                 (3, 70, 1280, 32, True, False)])   # row chunks that end inside a load batch
+                                                 (3, 70, 1280, 32, True, False),    # row chunks that end inside a load batch
+                                                 # one-launch (register-resident) plan: 5 / 10 / 15 chunk slabs, 256 and 512 threads, row counts
+                                                 # below / not a multiple of the row lanes, a slab of four 10-channel groups, 4-channel groups
+                                                 (2, 64, 1280, 32, True, False), (1, 256, 2560, 32, True, False), (2, 130, 1920, 32, False, False),
+                                                 (1, 600, 640, 32, True, False), (2, 20, 320, 32, True, False), (1, 97, 128, 32, True, False)])
 def test_groupnorm(B, HW, C, G, silu, train):
     KC.case_groupnorm("cpu", B, HW, C, G, silu, train_params=train)
 

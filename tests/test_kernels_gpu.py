@@ -138,7 +138,11 @@ def test_attention_rising_maxima(Nq, Nk, D):
                                                  (1, 64, 2560, 32, True, False), (2, 4096, 32, 32, True, True),
                                                  (1, 1024, 640, 32, False, False), (1, 37, 64, 8, False, True),
                                                  (4, 256, 1280, 32, True, True), (4, 1024, 1920, 32, True, False),
-                                                 (4, 256, 1280, 32, True, False), (4, 64, 2560, 32, False, False), (4, 256, 640, 32, True, False)])
+                                                 (4, 256, 1280, 32, True, False), (4, 64, 2560, 32, False, False), (4, 256, 640, 32, True, False),
+                                                 # the UNet's one-launch shapes (bs 4 / 8 / inference batch 32) + ragged row counts
+                                                 (4, 64, 1280, 32, True, False), (4, 256, 2560, 32, True, False), (4, 256, 1920, 32, True, False),
+                                                 (8, 1024, 640, 32, True, False), (4, 1024, 1280, 32, True, False), (32, 256, 1280, 32, True, False),
+                                                 (2, 1000, 640, 32, False, False), (3, 130, 1920, 32, True, False)])
 def test_groupnorm(B, HW, C, G, silu, train):
     KC.case_groupnorm(DEV, B, HW, C, G, silu, train_params=train)
 
