@@ -4,6 +4,8 @@ operation written in plain torch fp32 on the SAME fp16-rounded inputs; tolerance
 (fp16 output rounding is 2^-11 = 4.9e-4 relative)."""
 import math
 
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -486,7 +488,7 @@ def case_groupnorm(dev, B, HW, C, G, silu, eps=1e-5, seed=4, train_params=False)
             out0, stats0 = K.groupnorm_fwd(x, gamma, beta, G, eps, silu)
             dx0, _, _ = K.groupnorm_bwd(x, dy, gamma, beta, stats0, G, silu, dres=dres)
         finally:
-            K.set_option("gn_resident", 1)
+            K.set_option("gn_resident", int(os.environ.get("CLORA_GN_RESIDENT", "1")))
         assert rel(out, out0) < 2e-4 and rel(stats, stats0) < 1e-5 and rel(dx2, dx0) < 3e-4
         out1, stats1 = K.groupnorm_fwd(x, gamma, beta, G, eps, silu)             # bit-stable
         assert torch.equal(out1, out) and torch.equal(stats1, stats)
