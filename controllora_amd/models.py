@@ -289,6 +289,7 @@ class _ControlMixin:
         self.control_states = control_states
         self._control_term = None          # a term precomputed for the previous control states is stale now
         self._control_T = None
+        self._control_parts = None
 
     def inject_control_term(self, term, scale=1.0, t_q=None):
         """ControlLoRA.forward evaluates `scale * to_control(control)` for all sites of a level in one batched launch
@@ -322,8 +323,13 @@ class _ControlMixin:
         reference forms right after calling its process_control_states (control_self_add is always False, C1)."""
         ctrl = self._control_tokens(hidden_states)
         layer = self.to_control_out if is_out else self.to_control
+        # the control map's share of a concat adapter's down-projection, evaluated for the whole level by ControlLoRA.forward
+        # (_batched_control_terms); valid while the map is used as it was injected (equal batches, or one map for the whole batch)
+        parts = getattr(self, "_control_parts", None)
+        t_ctrl = parts.get(id(layer)) if (parts and self.concat_hidden and ctrl.shape[0] in (1, hidden_states.shape[0])
+                                          and ctrl.shape[0] * ctrl.shape[1] == parts["rows"]) else None
         return ops.control_add(_flat2(hidden_states), _flat2(ctrl), layer.down.weight, layer.up.weight, scale,
-                               self.concat_hidden)
+                               self.concat_hidden, t_ctrl=t_ctrl)
 
 
 class ControlLoRACrossAttnProcessor(_ControlMixin, LoRACrossAttnProcessor):
@@ -642,6 +648,18 @@ class ControlLoRA(nn.Module):
 def _batched_control_terms(procs, c):
     """v1 sites whose control term depends on the control map only (no concat_hidden, no post_add / chained adapters,
     rank <= 16): evaluate `to_control(control)` for all of them at once (reference models.py:214-218, 10 sites/level)."""
+    if ops.CONTROL_PARTS:
+        # concat adapters (v2: to_control + to_control_out; v1 with concat_hidden): the control map's share of every down-projection
+        # of the level in one launch (reference models.py:209-214, 343-349; 20 layers per level under mpii-pose-v2.json)
+        csites = [p for p in procs if getattr(p, "concat_hidden", False) and hasattr(p, "to_control") and not p._needs_generic_path()]
+        layers = [l for p in csites for l in ([p.to_control] + ([p.to_control_out] if hasattr(p, "to_control_out") else []))]
+        Cc = c.shape[-1]
+        if len(layers) >= 2 and all(l.down.weight.shape[0] <= 16 and l.down.weight.shape[1] > Cc for l in layers) and \
+                len({l.down.weight.shape[0] for l in layers}) == 1:
+            parts = ops.control_down_parts(c.reshape(-1, Cc), [l.down.weight for l in layers])
+            by_layer = {id(l): t for l, t in zip(layers, parts)}
+            for p in csites:
+                p._control_parts = dict(by_layer, rows=c.shape[0] * c.shape[1] if c.dim() == 3 else c.shape[0])
     sites = [p for p in procs if isinstance(p, ControlLoRACrossAttnProcessor) and not p.concat_hidden
              and not p._needs_generic_path() and p.to_control.down.weight.shape[0] <= 16]
     if len(sites) < 2 or len({tuple(p.to_control.down.weight.shape) + tuple(p.to_control.up.weight.shape) for p in sites}) != 1:

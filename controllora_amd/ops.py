@@ -783,14 +783,17 @@ class _ControlAddFn(torch.autograd.Function):
     ctrl [Mc, Cc] may hold fewer batch elements than h (control batch 1 broadcast, quirk C6)."""
 
     @staticmethod
-    def forward(ctx, h, ctrl, D, U, scale, concat):
+    def forward(ctx, h, ctrl, D, U, scale, concat, t_ctrl=None):
         M, C_ = h.shape
         Mc, Cc = ctrl.shape
         R = D.shape[0]
         T = torch.empty((M, R), dtype=f32, device=h.device)
         xr = Mc if Mc != M else 0
         Dd, Ud = D.detach(), U.detach()
-        if concat:
+        if concat and t_ctrl is not None:
+            # the control map's share ctrl . D[:, C:]^T was evaluated for the whole level (control_down_parts): one launch here
+            K.lora_down_multi([K.down_job(h, Dd, T, 0, M, C_, T_in=t_ctrl, t_in_r=R)])
+        elif concat:
             K.lora_down(h, Dd, T, 0, M, C_)                          # D[:, :C] acts on h (row pitch ldd = C + Cc)
             K.lora_down(ctrl, Dd[:, C_:], T, 0, M, Cc, accumulate=True, x_rows=xr)
         else:
@@ -798,7 +801,7 @@ class _ControlAddFn(torch.autograd.Function):
         y = K.lora_up(h, T, 0, Ud, M, C_, scale)
         ctx.save_for_backward(h, ctrl, T)
         ctx.params = (D, U)
-        ctx.cfg = (scale, concat, xr)
+        ctx.cfg = (scale, concat, xr, t_ctrl is not None)
         return y
 
     @staticmethod
@@ -806,7 +809,7 @@ class _ControlAddFn(torch.autograd.Function):
         dy = dy.contiguous()
         h, ctrl, T = ctx.saved_tensors
         D, U = ctx.params
-        scale, concat, xr = ctx.cfg
+        scale, concat, xr, parts = ctx.cfg
         M, C_ = h.shape
         Mc, Cc = ctrl.shape
         R = D.shape[0]
@@ -822,7 +825,8 @@ class _ControlAddFn(torch.autograd.Function):
             if D.requires_grad:
                 gD = _grad_buffer(D)
                 wj.append((h, dT, 0, gD, 1, D.shape[1], C_, 1.0, 0))
-                wj.append((ctrl, dT, 0, gD[:, C_:], 1, D.shape[1], Cc, 1.0, xr))
+                if not parts:
+                    wj.append((ctrl, dT, 0, gD[:, C_:], 1, D.shape[1], Cc, 1.0, xr))
             dh = K.lora_up(dy, dT, 0, Dd[:, :C_], M, C_, 1.0, u_tr=True)
             Dc = Dd[:, C_:]
         else:
@@ -835,15 +839,74 @@ class _ControlAddFn(torch.autograd.Function):
         else:
             for a_, t_, to_, g_, gn, gj, n_, sc_, ar_ in wj:
                 K.lora_wgrad(a_, t_, to_, g_, gn, gj, M, n_, R, scale=sc_, a_rows=ar_)
+        if parts:
+            # d(ctrl) and the control columns of dD are formed once per level from every site's dT (_ControlDownPartsFn.backward)
+            dt_ctrl = dT.reshape(M // Mc, Mc, R).sum(0) if xr else dT
+            return dh, None, None, None, None, None, dt_ctrl
         if ctx.needs_input_grad[1]:
             dctrl = K.lora_up(None, dT, 0, Dc, M, Cc, 1.0, u_tr=True)
             if xr:
                 dctrl = dctrl.reshape(M // Mc, Mc, Cc).float().sum(0).to(f16)
-        return dh, dctrl, None, None, None, None
+        return dh, dctrl, None, None, None, None, None
 
 
-def control_add(h, ctrl, D, U, scale, concat):
-    return _ControlAddFn.apply(h, ctrl, D, U, float(scale), bool(concat))
+def control_add(h, ctrl, D, U, scale, concat, t_ctrl=None):
+    return _ControlAddFn.apply(h, ctrl, D, U, float(scale), bool(concat), t_ctrl)
+
+
+CONTROL_PARTS = _os.environ.get("CLORA_CONTROL_PARTS", "1") != "0"      # "0": every concat adapter projects the control map itself (A/B)
+
+
+class _ControlDownPartsFn(torch.autograd.Function):
+    """The control map's share of the CONCAT adapters' down-projections -- `to_control(cat(h, ctrl))` of the v2 processors and of
+    v1 with `concat_hidden` (reference models.py:209-214, 343-349, 366-372, 412-418) -- for every such layer of one UNet level at once:
+    T_l = ctrl . D_l[:, C:]^T  [Mc, r], one multi-job launch (the layers share the level's hint-encoder map); each site then adds its
+    h share in ONE launch (`_ControlAddFn` with t_ctrl).  Independent of the call's `scale`.  The backward receives every site's dT_l
+    after the whole UNet backward: the control columns of dD_l join the deferred weight-gradient queue and
+    d(ctrl) = [dT_1 | ... | dT_n] . [D_1[:, C:]; ...; D_n[:, C:]] is ONE rank-(n r) expand instead of one expand + one gradient
+    accumulation into the shared map per layer.   params = the full down matrices D_l [r, C + Cc]."""
+
+    @staticmethod
+    def forward(ctx, ctrl, n, *Ds):
+        Mc, Cc = ctrl.shape
+        r = Ds[0].shape[0]
+        assert all(D.shape[0] == r and D.shape[1] > Cc for D in Ds) and r <= 16
+        Ts = [torch.empty((Mc, r), dtype=f32, device=ctrl.device) for _ in range(n)]
+        K.lora_down_multi([K.down_job(ctrl, D.detach()[:, D.shape[1] - Cc:], Ts[l], 0, Mc, Cc) for l, D in enumerate(Ds)])
+        ctx.save_for_backward(ctrl)
+        ctx.params, ctx.cfg = Ds, (n, r)
+        return tuple(Ts)
+
+    @staticmethod
+    def backward(ctx, *dTs):
+        ctrl, = ctx.saved_tensors
+        n, r = ctx.cfg
+        Ds = ctx.params
+        Mc, Cc = ctrl.shape
+        live = [l for l in range(n) if dTs[l] is not None]
+        if not live:
+            return (None, None) + (None,) * n
+        gs = [dTs[l] if (dTs[l].stride(1) == 1 and dTs[l].dtype == f32) else dTs[l].float().contiguous() for l in live]
+        wj = []
+        for g, l in zip(gs, live):
+            if Ds[l].requires_grad:
+                C_ = Ds[l].shape[1] - Cc
+                wj.append(K.wgrad_job(ctrl, g, 0, _grad_buffer(Ds[l])[:, C_:], 1, Ds[l].shape[1], Mc, Cc, r))
+        dctrl = None
+        keep = list(gs)
+        if ctx.needs_input_grad[0]:
+            dTcat = torch.cat(gs, 1) if len(gs) > 1 else gs[0]
+            Dcat = torch.cat([Ds[l].detach()[:, Ds[l].shape[1] - Cc:] for l in live], 0)
+            dctrl = K.lora_up(None, dTcat, 0, Dcat, Mc, Cc, 1.0, u_tr=True)
+            keep += [dTcat, Dcat]
+        if wj:
+            K.lora_wgrad_defer(wj, ctrl.device, ctrl, *keep)
+        return (dctrl, None) + (None,) * n
+
+
+def control_down_parts(ctrl, downs):
+    """downs: the down matrices [r, C + Cc] of the concat adapters sharing `ctrl` [Mc, Cc] -> tuple of T_l [Mc, r] fp32"""
+    return _ControlDownPartsFn.apply(ctrl, len(downs), *downs)
 
 
 class _ControlTermFn(torch.autograd.Function):
