@@ -380,6 +380,18 @@ def _grad_buffer(p: torch.Tensor) -> torch.Tensor:
     return p.grad
 
 
+_ZERO_CONST = {}
+
+
+def _zero_const(shape, device):
+    """a read-only all-zero fp32 matrix (the up matrix of a skipped adapter segment: v2 has no k / v adapters), made once"""
+    key = (tuple(shape), str(device))
+    z = _ZERO_CONST.get(key)
+    if z is None:
+        z = _ZERO_CONST[key] = torch.zeros(shape, dtype=f32, device=device)
+    return z
+
+
 def _stack_rows(ts):
     """Row-concatenate [n_i, r] fp32 matrices.  ControlLoRATrainer lays the adapter weights of a processor out
     back to back in its flat parameter buffer, so the concatenation is usually a zero-copy strided view."""
@@ -597,7 +609,7 @@ class _LoraProjFn(torch.autograd.Function):
         f_srcs, f_in_mask, f_in = [], 0, []           # fused: down matrices per segment, segments with a second (precomputed) part
         for s, m in enumerate(meta):
             if m is None:
-                pieces.append(torch.zeros((seg_w, r), dtype=f32, device=x.device))
+                pieces.append(_zero_const((seg_w, r), x.device))
                 info.append(None)
                 f_srcs.append(None)
                 continue
