@@ -416,7 +416,8 @@ def main():
     skipped = float(trainer.state[6])
 
     allreduce_ms = None
-    if world > 1:                                  # the exchange step on its own: 10 flat-buffer all-reduces, HIP events
+    if world > 1 or trainer.comm == "clora":      # the exchange step on its own: 10 flat-buffer all-reduces, HIP events (with --comm clora also
+        #                                            at one rank: the C ABI's communicator / all-reduce call path on hardware, no peer traffic)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         keep = trainer.flat.grad.clone()           # through the trainer's own exchange path (torch process group or the C ABI)
         trainer._all_reduce_grads()
