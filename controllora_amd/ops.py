@@ -555,15 +555,17 @@ SMALL_FUSE_TILES = {21: 128, 41: 128, 22: 64, 42: 64, 26: 64, 23: 64, 43: 64}   
 FUSE_SMALL = _os.environ.get("CLORA_FUSE_SMALL", "1") != "0"                        # "0": only the 8-wave 320-column tiles (A/B runs)
 
 
+_FUSE_TILE_COLS = {**SMALL_FUSE_TILES, 51: 320, 52: 320, 54: 320, 55: 320}      # tile_cfg -> columns a segment must be a multiple of
+
+
 def _fuse_plan(M, N, Kd, seg_w):
-    """None: keep the separate down-projection launch; 0: fuse on the 320-column tiles (table entry or library choice);
-    > 0: fuse on this 4-wave tile -- the tuned table's own choice for the shape, when it is one that can carry the extra rows
-    (the deeper UNet levels, where the 320-column tiles would leave most CUs idle)"""
+    """None: keep the separate down-projection launch; 0: fuse on the 320-column tiles, the library picks which; > 0: fuse on this
+    tile -- the shape's ":x" entry of the launch table (timed WITH the extra operand rows, tools/tune_fused.py), else the plain entry
+    when that is a 4-wave tile that can carry them (the deeper UNet levels, where the 320-column tiles would leave most CUs idle)"""
     if not FUSE_DOWN or Kd % 64 or seg_w % 64:
         return None
-    hx = K._tuned_fused(M, N, Kd)                              # a tile timed WITH the extra operand rows (tools/tune_fused.py)
-    if hx is not None and seg_w % ({**SMALL_FUSE_TILES, 51: 320, 52: 320, 54: 320, 55: 320}.get(hx[0], 1 << 30)) == 0 and \
-            (FUSE_SMALL or hx[0] not in SMALL_FUSE_TILES):
+    hx = K._tuned_fused(M, N, Kd)
+    if hx is not None and seg_w % _FUSE_TILE_COLS.get(hx[0], 1 << 30) == 0 and (FUSE_SMALL or hx[0] not in SMALL_FUSE_TILES):
         return hx[0]
     if seg_w % FUSE_TILE_N == 0 and _fills_the_chip(M, N):
         return 0
