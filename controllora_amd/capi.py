@@ -156,7 +156,7 @@ class Lib:
 
     # The library reads no environment variable; A/B runs set its knobs (clora_set_option, the ABI's single piece of
     # process-global state) through these variables, forwarded here when the library is loaded.
-    _ENV_OPTIONS = {"CLORA_TILE_ORDER": ("tile_order", {"m": 0, "n": 1, "auto": 2, "a": 2}), "CLORA_LN_ROWS": ("ln_rows", None),
+    _ENV_OPTIONS = {"CLORA_TILE_ORDER": ("tile_order", {"m": 0, "n": 1, "auto": 2, "a": 2, "grid": 3, "g": 3}), "CLORA_LN_ROWS": ("ln_rows", None),
                     "CLORA_ATTN_FWD_WAVES": ("attn_fwd_waves", None), "CLORA_ATTN_BWD_WAVES": ("attn_bwd_waves", None),
                     "CLORA_GN_BLOCKS": ("gn_blocks", None), "CLORA_EPI_TWO_PHASE": ("epi_two_phase", None),
                     "CLORA_LORA_DOWN_MODE": ("lora_down_mode", None), "CLORA_GN_UNROLL": ("gn_unroll", None),

@@ -150,7 +150,9 @@ int clora_conv_patch_eligible(int M, const clora_conv_t* conv, int tile_cfg);
  *   "tile_order"      how clora_gemm_f16[_ex] assigns output tiles -- and the attention kernels their (batch, head) blocks -- to
  *                     the eight XCDs.  0 = every XCD a contiguous range of tiles in m-major order, attention blocks in launch
  *                     order; 1 = n-major tile ranges; 2 = per launch the order that fetches fewer distinct A / B panels per XCD
- *                     (default: same-box A/B on MI355X 24.51 -> 24.35 ms/step).  1 and 2 also give every XCD whole attention heads.
+ *                     (default: same-box A/B on MI355X 24.51 -> 24.35 ms/step); 3 = as 2, plus per launch an (split, m, n) RECTANGLE of tiles
+ *                     per XCD where whole divisors exist and the same panel count model prefers it.  1, 2 and 3 also give every XCD whole
+ *                     attention heads.
  *   "ln_rows"         1 = LayerNorm keeps several rows in flight per wave (default), 0 = one row per wave.
  *   "attn_fwd_waves"  0 = pick by grid size (default), 4 | 6 | 8 = waves per forward attention block (head dims <= 64).
  *   "attn_bwd_waves"  0 = pick by grid size (default), 4 | 8 = waves per backward attention block (head dims <= 64).

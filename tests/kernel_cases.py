@@ -307,10 +307,12 @@ def case_tile_order(dev, tile_cfg, order, seed=21):
     from controllora_amd.ops import conv_k_order
     g = torch.Generator().manual_seed(seed)
     M, N, K_ = 600, 336, 192                       # several tiles each way, ragged edges (N % 16 == 0 for the adapter epilogue)
+    if order == "grid":                            # whole divisors each way for every tile shape up to 256 x 256: the rectangle assignment applies
+        M, N = 1024, 512
     A, B = rnd((M, K_), dev, g), rnd((N, K_), dev, g, 1 / math.sqrt(K_))
     bias, res = rnd((N,), dev, g, dtype=f32), rnd((M, N), dev, g)
     T, U = rnd((M, 4), dev, g, dtype=f32), rnd((N, 4), dev, g, dtype=f32)
-    Bn, H, W, Ci, Co = 4, 8, 8, 128, 136
+    Bn, H, W, Ci, Co = (8, 8, 8, 128, 256) if order == "grid" else (4, 8, 8, 128, 136)
     x = rnd((Bn * H * W, Ci), dev, g)
     w = conv_k_order(rnd((Co, 9, Ci), dev, g, 1 / math.sqrt(Ci * 9)), 64)
     cd, _, _ = K.conv_fwd_desc(H, W, Ci, 3, 1, 1, kchunk=64)
@@ -319,7 +321,7 @@ def case_tile_order(dev, tile_cfg, order, seed=21):
     def run():
         outs = []
         if not patch:
-            for sk in (1, 3):
+            for sk in ((1, 2, 3) if order == "grid" else (1, 3)):
                 outs.append(K.gemm(A, B, M, N, K_, split_k=sk, tile_cfg=tile_cfg))
             outs.append(K.gemm(A, B, M, N, K_, bias=bias, residual=res, lora_t=T, lora_u=U, lora_scale=0.5, split_k=1, tile_cfg=tile_cfg))
         for sk in (1, 2):

@@ -70,7 +70,7 @@ def test_control_terms_in_rank_space(kw):
     print(KC.case_rank_control("cpu", **kw))
 
 
-@pytest.mark.parametrize("order", ["n", "auto"])
+@pytest.mark.parametrize("order", ["n", "auto", "grid"])
 @pytest.mark.parametrize("tile", [21, 43, 53, 72, 76])
 def test_tile_order_does_not_change_results(tile, order):
     """the tile -> XCD assignment (clora_set_option "tile_order") only permutes which workgroup computes which tile: bit-identical outputs"""

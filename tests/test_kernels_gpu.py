@@ -102,7 +102,7 @@ def test_gemm_epilogue_without_rowadd(tile):
     KC.case_gemm_epilogue_no_rowadd(DEV, M=1000, N=1296, K_=1280, tile_cfg=tile, split_k=2 if tile else 0)
 
 
-@pytest.mark.parametrize("order", ["n", "auto"])
+@pytest.mark.parametrize("order", ["n", "auto", "grid"])
 @pytest.mark.parametrize("tile", [21, 43, 53, 58, 72, 76])
 def test_tile_order_does_not_change_results(tile, order):
     """clora_set_option("tile_order"): which XCD computes which tile is a permutation -- bit-identical GEMM / conv outputs"""
