@@ -19,7 +19,7 @@ def main():
     from controllora_amd.train import ControlLoRATrainer
     from oracle import cases, unet_ref
     with use_emulator():
-        unet, clora, _ = E.build_product_case("v1", "cpu")
+        unet, clora, _ = E.build_product_case(os.environ.get("CLORA_DIST_CASE", "v1"), "cpu")
         if rank >= 1:                      # perturb the other ranks: the trainer must broadcast rank 0's adapters
             with torch.no_grad():
                 for p in clora.parameters():
