@@ -171,6 +171,22 @@ def test_groupnorm(B, HW, C, G, silu, train):
     KC.case_groupnorm("cpu", B, HW, C, G, silu, train_params=train)
 
 
+def test_groupnorm_random_shapes():
+    """seeded sweep over group sizes 1..80 channels, 1..513 rows, 1..32 groups: whichever plan a shape gets (one launch, two launches,
+    channel slabs, two column chunks per thread) agrees with torch, with the other plan and with itself (case_groupnorm)"""
+    import random
+    rng = random.Random(7)
+    n = 0
+    while n < 48:
+        G = rng.choice([1, 2, 4, 8, 16, 32, 32, 32])
+        C = G * rng.choice([1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 20, 40, 60, 80])
+        HW, B = rng.choice([1, 2, 7, 16, 37, 64, 100, 130, 256, 300, 513]), rng.choice([1, 2, 3])
+        if C % 8 or C > 2560 or B * HW * C > 600000:
+            continue
+        n += 1
+        KC.case_groupnorm("cpu", B, HW, C, G, rng.random() < 0.5, seed=n)
+
+
 @pytest.mark.parametrize("M,C", [(37, 320), (9, 1280), (5, 64)])
 def test_layernorm(M, C):
     KC.case_layernorm("cpu", M, C)
