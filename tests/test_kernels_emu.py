@@ -70,6 +70,38 @@ def test_control_terms_in_rank_space(kw):
     print(KC.case_rank_control("cpu", **kw))
 
 
+def test_tile_order_grid_random_shapes():
+    """seeded sweep of tile shape x grid size x split-K (whole and ragged edges): the rectangle assignment of clora_set_option
+    "tile_order" = 3 covers every (split, tile) exactly once -- outputs bit-identical to the m-major order and equal to fp32 matmul"""
+    import math
+    import random
+    import torch
+    from controllora_amd import kernels as K
+    rng = random.Random(3)
+    dims = {43: (64, 64), 21: (128, 128), 22: (128, 64), 53: (128, 256), 58: (256, 256), 54: (128, 320)}
+    n = 0
+    try:
+        while n < 24:
+            tile = rng.choice(sorted(dims))
+            tm, tn, sk = rng.choice([2, 4, 8, 16]), rng.choice([1, 2, 4, 8]), rng.choice([1, 2, 4])
+            M, N = tm * dims[tile][0] - rng.choice([0, 0, 8]), tn * dims[tile][1] - rng.choice([0, 0, 16])
+            Kd = 64 * sk * rng.choice([1, 2])
+            if M * N > 700000:
+                continue
+            n += 1
+            g = torch.Generator().manual_seed(n)
+            A = torch.randn(M, Kd, generator=g).half()
+            B = (torch.randn(N, Kd, generator=g) / math.sqrt(Kd)).half()
+            K.set_tile_order("m")
+            base = K.gemm(A, B, M, N, Kd, split_k=sk, tile_cfg=tile)
+            K.set_tile_order("grid")
+            other = K.gemm(A, B, M, N, Kd, split_k=sk, tile_cfg=tile)
+            assert torch.equal(base, other), (tile, M, N, Kd, sk)
+            assert float((base.float() - A.float() @ B.float().T).abs().max()) < 0.05
+    finally:
+        K.set_tile_order(K.DEFAULT_TILE_ORDER)
+
+
 @pytest.mark.parametrize("order", ["n", "auto", "grid"])
 @pytest.mark.parametrize("tile", [21, 43, 53, 72, 76])
 def test_tile_order_does_not_change_results(tile, order):
