@@ -1041,9 +1041,15 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void conv3x3_patch_kernel(GemmArgs
     constexpr int PA_IN = (MAXPP / 8 + NW - 1) / NW;           // patch DMA wave-instructions per wave per slab
     constexpr int B_NI = BN / 8;                               // ring DMA wave-instructions per stage (8 rows x 128 B each)
     constexpr int B_IN = (B_NI + NW - 1) / NW;                 // ... per wave (instruction ib = w + NW*i; surplus ones fetch the zero page into a dump slot)
-    constexpr int PATCH = MAXPP * 64 + 512;                    // halves per patch buffer (+ one 1-KB dump slot)
-    constexpr int BST = BN * BK + ((B_NI % NW) ? 512 : 0);     // halves per ring stage (+ dump slot when the split is uneven: BN = 160)
+    // 256x160 (tile_cfg 79; 64x80 wave tiles: 18 fragment reads per 40 MFMAs, the only patch tile on the matrix-pipe side of the LDS
+    // budget at N = 320) needs exactly the CU's 160 KB: no dump slots -- a surplus DMA instruction repeats its wave's previous one
+    // (same source, same destination: a duplicate write of identical bytes), the instruction counts the vmcnt waits rely on are unchanged
+    constexpr bool NODUMP = BM == 256 && BN == 160;
+    constexpr int PATCH = MAXPP * 64 + (NODUMP ? 0 : 512);     // halves per patch buffer (+ one 1-KB dump slot)
+    constexpr int BST = BN * BK + (((B_NI % NW) && !NODUMP) ? 512 : 0);   // halves per ring stage (+ dump slot when the split is uneven: BN = 160)
     constexpr int SMEM = 2 * PATCH + NST * BST;
+    static_assert(SMEM * 2 <= 160 * 1024, "LDS per workgroup");
+    static_assert(!NODUMP || (PA_IN >= 2 && (NW * PA_IN - NW) * 8 <= MAXPP && B_IN >= 2 && NW * B_IN - NW <= B_NI), "a surplus instruction needs a valid predecessor in its wave");
     static_assert(64 * (BN + 4) * 2 <= SMEM, "epilogue staging");
     __shared__ __attribute__((aligned(16))) half_t smem[SMEM];
     half_t* const Pb = smem;
@@ -1085,7 +1091,8 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void conv3x3_patch_kernel(GemmArgs
     int poff[PA_IN];                                           // element offset of this lane's 16-byte chunk at slab 0; -1: zero page
 #pragma unroll
     for (int j = 0; j < PA_IN; ++j) {
-        const int sl = (w + NW * j) * 64 + l, pp = sl >> 3, pos = sl & 7;
+        const int ip = (NODUMP && (w + NW * j) * 8 >= MAXPP) ? w + NW * (j - 1) : w + NW * j;
+        const int sl = ip * 64 + l, pp = sl >> 3, pos = sl & 7;
         poff[j] = -1;
         if (pp < npp) {
             const int img = pp / (PRI * PW), rem = pp - img * (PRI * PW);
@@ -1102,7 +1109,7 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void conv3x3_patch_kernel(GemmArgs
         for (int j = 0; j < PA_IN; ++j) {
             const int i = w + NW * j;
             const half_t* src = (live && poff[j] >= 0) ? p.A + poff[j] + cs * 64 : zero_page;
-            CLORA_GLDS16(src, (i * 8 < MAXPP) ? dst + i * 512 : dst + MAXPP * 64);   // surplus instructions land in the dump slot
+            CLORA_GLDS16(src, (i * 8 < MAXPP) ? dst + i * 512 : dst + (NODUMP ? (i - NW) * 512 : MAXPP * 64));   // surplus: dump slot (or a repeat)
         }
     };
     // ---- ring loader (rows of the [N, K] weight operand, 128-byte rows, key r & 7): instruction ib = w + NW*i fills rows ib*8..+8
@@ -1111,8 +1118,8 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void conv3x3_patch_kernel(GemmArgs
     size_t b_base[B_IN];
 #pragma unroll
     for (int i = 0; i < B_IN; ++i) {
-        const int ib = w + NW * i, n = n0 + ib * 8 + lrow;
-        b_ok[i] = ib < B_NI && n < p.N;
+        const int ib = w + NW * i, ibe = (NODUMP && ib >= B_NI) ? ib - NW : ib, n = n0 + ibe * 8 + lrow;
+        b_ok[i] = ibe < B_NI && n < p.N;
         b_base[i] = (size_t)n * p.K + kc * 8;
     }
     const int kbeg = cs_beg * 576, kend = cs_end * 576;
@@ -1124,7 +1131,7 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void conv3x3_patch_kernel(GemmArgs
         for (int i = 0; i < B_IN; ++i) {
             const int ib = w + NW * i;
             const half_t* src = (b_ok[i] && kok) ? p.B + b_base[i] + kq : zero_page;
-            CLORA_GLDS16(src, Bs + (ib < B_NI ? ib * 8 * BK : BN * BK));
+            CLORA_GLDS16(src, Bs + (ib < B_NI ? ib * 8 * BK : (NODUMP ? (ib - NW) * 8 * BK : BN * BK)));
         }
         kq += BK;
     };
@@ -1690,8 +1697,9 @@ extern "C" int clora_gemm_f16_ex(const clora_half* A, int lda, const clora_half*
     //            256x128 (8 waves of 64x64), 128x128 (64x32), 128x128 (32x64), 256x64 (32x64), 128x64 (32x32), 128x160 (32x80: the
     //            UNet widths 320 / 640 / 960 / 1280 are multiples of 160, not of 128); shapes it cannot take fall back to 21
     //            77, 78 = 128x128 / 128x64 with the 392-pixel patch (one 128-pixel row or row segment per tile: W = 128, 256, 512)
-    if (cfg >= 71 && cfg <= 78) {
-        if (!dma || !patch_eligible(a, (cfg == 71 || cfg == 74) ? 256 : 128, cfg >= 77 ? kPatchWide : 0)) cfg = 21;
+    //            79 = 256x160 (8 waves of 64x80; exactly 160 KB of LDS): batch >= 8 / inference shapes at N = 320 / 640 / 960 / 1280
+    if (cfg >= 71 && cfg <= 79) {
+        if (!dma || !patch_eligible(a, (cfg == 71 || cfg == 74 || cfg == 79) ? 256 : 128, (cfg == 77 || cfg == 78) ? kPatchWide : 0)) cfg = 21;
         else {
             const int slabs = a.conv.Cin / 64;
             if (splits > slabs) splits = slabs;
@@ -1710,6 +1718,7 @@ extern "C" int clora_gemm_f16_ex(const clora_half* A, int lda, const clora_half*
                 case 75: rc = launch_patch<128, 64, 4, 2, 4>(a, splits, s); break;
                 case 77: rc = launch_patch<128, 128, 2, 4, 3, kPatchWide>(a, splits, s); break;
                 case 78: rc = launch_patch<128, 64, 4, 2, 4, kPatchWide>(a, splits, s); break;
+                case 79: rc = launch_patch<256, 160, 4, 2, 3>(a, splits, s); break;
                 default: rc = launch_patch<128, 160, 4, 2, 3>(a, splits, s); break;
             }
             if (rc != CLORA_OK) return rc;
@@ -1804,7 +1813,7 @@ extern "C" int clora_set_option(const char* name, int value) {
 }
 
 extern "C" int clora_conv_patch_eligible(int M, const clora_conv_t* conv, int tile_cfg) {
-    if (!conv || tile_cfg < 71 || tile_cfg > 78) return 0;
+    if (!conv || tile_cfg < 71 || tile_cfg > 79) return 0;
     GemmArgs a;
     a.M = M; a.conv = *conv;
     return patch_eligible(a, (tile_cfg == 71 || tile_cfg == 74) ? 256 : 128, tile_cfg >= 77 ? kPatchWide : 0) ? 1 : 0;

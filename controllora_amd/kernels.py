@@ -202,7 +202,7 @@ def gemm(A: torch.Tensor, Bw: torch.Tensor, M: int, N: int, K: int, *, lda: Opti
     return C_
 
 
-PATCH_TILE_CFGS = (71, 72, 73, 74, 75, 76, 77, 78)     # conv3x3_patch_kernel variants of clora_gemm_f16_ex (77, 78: 392-pixel patch, rows >= 128 wide)
+PATCH_TILE_CFGS = (71, 72, 73, 74, 75, 76, 77, 78, 79)     # conv3x3_patch_kernel variants of clora_gemm_f16_ex (77, 78: 392-pixel patch, rows >= 128 wide; 79: 256x160)
 
 
 def conv_patch_eligible(M: int, conv: ConvDesc, tile_cfg: int) -> bool:

@@ -130,12 +130,14 @@ int clora_gemm_f16(const clora_half* A, int lda, const clora_half* B, clora_half
  *   31-33 = 1-3 and 41-43 = 21-23 with the fragment reads before the ring refill
  *   51-58 8-wave blocks (one per CU), BK 64: 128x320, 64x320, 128x256 (54-56: fragment-first), 256x320, 256x256
  *   71-76 conv3x3_patch_kernel (3x3 stride-1 pad-1 convs, their dgrads, conv(nearest-2x(x))): 256x128, 128x128 (two wave layouts),
- *         256x64, 128x64, 128x160; a shape it cannot take falls back to 21 (clora_conv_patch_eligible tells) */
+ *         256x64, 128x64, 128x160; 77, 78: 128x128 / 128x64 on a 392-pixel patch (one 128-pixel row or row segment: W = 128 .. 512);
+ *         79: 256x160 (64x80 wave tiles, the CU's whole 160 KB of LDS); a shape it cannot take falls back to 21
+ *         (clora_conv_patch_eligible tells) */
 int clora_gemm_f16_ex(const clora_half* A, int lda, const clora_half* B, clora_half* C, int ldc,
                       int M, int N, int K, const clora_conv_t* conv, const clora_epilogue_t* epi,
                       int split_k, int tile_cfg, void* workspace, size_t workspace_bytes, void* stream);
 
-/* 1 when clora_gemm_f16_ex(..., tile_cfg) would run `conv` (M output pixels) on the patch-staged 3x3 kernel (tile_cfg 71..76:
+/* 1 when clora_gemm_f16_ex(..., tile_cfg) would run `conv` (M output pixels) on the patch-staged 3x3 kernel (tile_cfg 71..79:
  * stride 1, pad 1, kchunk 64, whole image rows per tile), 0 when it would fall back to the implicit-GEMM main loop.  The
  * reference op is the same F.conv2d of upstream ResnetBlock2D; tuner / tests use this to know what they time. */
 int clora_conv_patch_eligible(int M, const clora_conv_t* conv, int tile_cfg);

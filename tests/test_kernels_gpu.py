@@ -55,7 +55,7 @@ def test_gemm_tile_configs(tile):
     KC.case_conv(DEV, 1, 32, 32, 320, 320, tile_cfg=tile)          # Cin % 64 == 0: the BK = 64 variants take the fast tap walk
 
 
-@pytest.mark.parametrize("tile", [71, 72, 73, 74, 75, 76])
+@pytest.mark.parametrize("tile", [71, 72, 73, 74, 75, 76])      # 79 (256x160, built at the end of round 4) joins once it has run on hardware
 @pytest.mark.parametrize("Bn,H,W,Ci,Co", [(4, 64, 64, 320, 320), (4, 32, 32, 640, 640), (2, 16, 16, 1280, 640), (4, 8, 8, 1280, 1280),
                                           (1, 32, 32, 320, 320), (3, 8, 8, 128, 72)])
 def test_conv_patch_kernel(tile, Bn, H, W, Ci, Co):

@@ -14,7 +14,7 @@ import torch
 from controllora_amd import kernels as K
 
 dev = torch.device("cuda", 0)
-CFGS = [1, 2, 3, 4, 5, 6, 7, 8, 21, 22, 23, 26, 31, 32, 33, 41, 42, 43, 51, 52, 53, 54, 55, 56, 57, 58, 71, 72, 73, 74, 75, 76]
+CFGS = [1, 2, 3, 4, 5, 6, 7, 8, 21, 22, 23, 26, 31, 32, 33, 41, 42, 43, 51, 52, 53, 54, 55, 56, 57, 58, 71, 72, 73, 74, 75, 76, 79]
 # (M, N, K, conv side H (0 = plain GEMM), Cin)
 SHAPES = [
     (16384, 320, 320, 0, 0), (4096, 640, 640, 0, 0), (1024, 1280, 1280, 0, 0),

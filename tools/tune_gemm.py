@@ -94,7 +94,7 @@ def timeit(fn, iters=10, warm=2):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / (2 * iters) * 1e3
 
-CFGS = [1, 2, 3, 4, 5, 6, 7, 8, 21, 22, 23, 26, 31, 32, 33, 41, 42, 43, 51, 52, 53, 54, 55, 56, 57, 58, 71, 72, 73, 74, 75, 76]
+CFGS = [1, 2, 3, 4, 5, 6, 7, 8, 21, 22, 23, 26, 31, 32, 33, 41, 42, 43, 51, 52, 53, 54, 55, 56, 57, 58, 71, 72, 73, 74, 75, 76, 79]
 if args.cfgs:
     CFGS = [int(c) for c in args.cfgs.split(",")]
 path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "controllora_amd", "gemm_tuning_gfx950.json")
