@@ -23,9 +23,14 @@ pytestmark = pytest.mark.gpu
 # full-size fixtures (512x512 = BASELINE's own sizes), measured on MI355X (profiles/r03_gputest_1.log): train step -- pred 1.59e-3, loss
 # 1.5e-5, flat gradient 3.7e-4 (norm 3.8e-5, worst per-parameter norm 2.5e-3), control maps 1.9-2.9e-3 (norms <= 3.6e-6); 50-step
 # DDIM -- first UNet evaluation 1.61e-3, latents 1.12e-3 after step 1, 1.97e-3 from step 20 to step 50.  Limits are <= 2x measured.
-FIX_TOL = dict(pred=3.2e-3, loss=1e-4, grads=8e-4, grads_norm=2e-4, control=5e-3, control_norm=5e-5, param_norm=5e-3,
-               eps=3.2e-3, latents=3.5e-3)
-TOL = dict(pred=3.5e-3, control=5e-3, loss=2e-4, grads=3e-3, grads_adapters=3e-3, grads_hint=9e-3)
+# Round 4: the forward is bit-stable run to run and box to box (`forward_bit_stable`; the figures of profiles/r04_gputest_final.log repeat
+# digit for digit on a second box), so the limits were pulled in from <= 2x to <= 1.3x the measured values of that log: train step at
+# 512x512 -- pred 1.58e-3 (v2 bs 8: 1.71e-3), gradient samples 3.6 / 4.1e-4 (v2: 4.8e-4), control maps <= 2.87e-3, per-parameter norm
+# 1.2e-3; UNet batch 32 -- first evaluation 1.63e-3 (worst sample 1.78e-3), latents 1.77e-3 after step 5; 50-step DDIM -- 1.94e-3.
+FIX_TOL = dict(pred=2.2e-3, loss=1e-4, grads=5.5e-4, grads_norm=1.6e-4, control=3.7e-3, control_norm=3.5e-5, param_norm=2.5e-3,
+               eps=2.1e-3, latents=2.5e-3)
+# 256x256 bs 1 against the oracle run on the spot: pred 1.66-1.72e-3, control maps <= 3.04e-3, gradients 1.15-1.54e-3 (hint encoder 4.5e-3)
+TOL = dict(pred=2.3e-3, control=4e-3, loss=2e-4, grads=2e-3, grads_adapters=1.6e-3, grads_hint=6e-3)
 
 
 @pytest.mark.parametrize("config", ["fill50k.json", "mpii-pose-v2.json", "danbooru-sketch.json"])
@@ -128,8 +133,8 @@ def test_baseline_config3_v2_bs8_train_step_vs_committed_oracle_fixture():
     errs = F.train_step_vs_fixture("cuda", "full_train_512_bs8_v2.safetensors")
     print("FULL_SIZE_V2_BS8_TRAIN_STEP_VS_FIXTURE", {k: (f"{v:.3e}" if isinstance(v, float) else v) for k, v in errs.items()})
     assert errs["pred"] < FIX_TOL["pred"] and errs["loss"] < FIX_TOL["loss"], errs
-    assert errs["grads_sample"] < 2 * FIX_TOL["grads"] and errs["grads_sample2"] < 2 * FIX_TOL["grads"], errs
-    assert errs["grads_norm"] < 2 * FIX_TOL["grads_norm"], errs
+    assert errs["grads_sample"] < 1.2 * FIX_TOL["grads"] and errs["grads_sample2"] < 1.2 * FIX_TOL["grads"], errs
+    assert errs["grads_norm"] < FIX_TOL["grads_norm"], errs
     for i in range(4):
         assert errs[f"control_{i}"] < FIX_TOL["control"] and errs[f"control_{i}_s2"] < FIX_TOL["control"], errs
         assert errs[f"control_{i}_norm"] < FIX_TOL["control_norm"], errs
@@ -142,7 +147,7 @@ def test_baseline_inference_unet_batch32_vs_committed_oracle_fixture():
     errs = F.infer32_vs_fixture("cuda")
     print("FULL_SIZE_INFER_B32_VS_FIXTURE", {k: (f"{v:.3e}" if isinstance(v, float) else v) for k, v in errs.items()})
     assert errs["unet_batch"] == 32
-    assert errs["eps_step01"] < FIX_TOL["eps"] and errs["eps_step01_worst_sample"] < 1.5 * FIX_TOL["eps"], errs
+    assert errs["eps_step01"] < FIX_TOL["eps"] and errs["eps_step01_worst_sample"] < 1.15 * FIX_TOL["eps"], errs
     assert errs["latents_step01"] < FIX_TOL["latents"] and errs["latents_step05"] < FIX_TOL["latents"], errs
 
 
@@ -150,7 +155,8 @@ def test_vae_512_vs_committed_oracle_fixture():
     """VAE at the reference's own resolution (train...:753-754): 512x512, batch 1, SD-1.5 widths; limits = the 256x256 test's"""
     errs = F.vae_512_vs_fixture("cuda")
     print("FULL_SIZE_VAE_512_VS_FIXTURE", {k: f"{v:.3e}" for k, v in errs.items()})
-    assert max(errs["mean"], errs["logvar"], errs["sample"], errs["decode"], errs["decode_s2"]) < 6e-3 and errs["decode_norm"] < 1e-3, errs
+    # measured (r04_gputest_final.log): mean 8.4e-4, logvar 1.04e-3, sample 2.1e-4, decode 1.52e-3 (both strides), decode norm 1.8e-6
+    assert max(errs["mean"], errs["logvar"], errs["sample"], errs["decode"], errs["decode_s2"]) < 2e-3 and errs["decode_norm"] < 1e-5, errs
 
 
 def test_baseline_inference_ddim50_512_vs_committed_oracle_fixture():
@@ -160,8 +166,8 @@ def test_baseline_inference_ddim50_512_vs_committed_oracle_fixture():
     north_star states "denoised latents within 1e-3 rel fp16".  The error budget at this exact configuration
     (tools/error_budget.py, profiles/r03_error_budget.json): the ORACLE ITSELF in the reference's fp16 arithmetic (stock torch
     ops, fp16 weights / activations) sits 2.85e-3 from its fp32 run, with an fp32 residual trunk 2.62e-3; the product sits
-    1.96e-3 away.  1e-3 is below what fp16 storage of the branch activations allows any implementation at 50 steps, so the test
-    pins (a) <= 2x the measured product error and (b) product error < the error of the reference's own fp16 arithmetic,
+    1.94e-3 away.  1e-3 is below what fp16 storage of the branch activations allows any implementation at 50 steps, so the test
+    pins (a) <= 1.3x the measured product error and (b) product error < the error of the reference's own fp16 arithmetic,
     re-measured here on the same inputs."""
     errs = F.ddim_vs_fixture("cuda", graph=True)
     print("FULL_SIZE_DDIM50_VS_FIXTURE", {k: (f"{v:.3e}" if isinstance(v, float) else v) for k, v in errs.items()})
