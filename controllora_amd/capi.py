@@ -16,6 +16,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CLORA_LIB_PATH") or os.path.join(_HERE, "_build", "libclora.so")   # override: A/B of kernel builds
 
+ABI_VERSION = 2                          # CLORA_ABI_VERSION of include/clora.h
 OK, ERR_ARG, ERR_LAUNCH, ERR_WORKSPACE = 0, -1, -2, -3
 _ERR = {ERR_ARG: "bad argument", ERR_LAUNCH: "kernel launch failed", ERR_WORKSPACE: "workspace too small"}
 
@@ -109,6 +110,7 @@ _PROTOS = {
     "clora_lora_wgrad_f16": [_P, _I, _P, _I, _I, _P, _I, _I, _I, _I, _I, _F, _I, _P, _Z, _P],
     "clora_comm_unique_id": [_P],
     "clora_comm_init": [_P, _I, _I],
+    "clora_comm_library": [C.c_char_p, _Z],
     "clora_comm_world": [],
     "clora_comm_rank": [],
     "clora_allreduce_flat_f32": [_P, _Z, _P],
@@ -127,6 +129,7 @@ _PROTOS = {
     "clora_optim_prep_f32": [_P, _F, _F, _F, _I, _F, _F, _I, _P],
     "clora_adamw_flat_f32": [_P, _P, _P, _P, _Z, _P, _F, _F, _F, _F, _F, _P],
     "clora_abi_version": [],
+    "clora_clock_probe": [_P, _I, _I, _P],
     "clora_groupnorm_workspace_bytes": [_I, _I, _I, _I, _I, _I],
     "clora_lora_wgrad_workspace_bytes": [_I, _I, _I],
     "clora_rank_gram_ws_bytes": [_I, _I],
@@ -144,7 +147,15 @@ class Lib:
         self.path = path
         self.require_device = require_device
         self.cdll = C.CDLL(path)
+        # struct layouts are part of the ABI: a library of another version would read fields this binding does not send
+        got = self.cdll.clora_abi_version() if hasattr(self.cdll, "clora_abi_version") else -1
+        if got != ABI_VERSION and os.environ.get("CLORA_ABI_ANY", "") != "1":
+            raise CloraError(f"{path} reports ABI {got}, this binding is written for ABI {ABI_VERSION} (include/clora.h); rebuild with "
+                             "`python -m controllora_amd.build` (CLORA_ABI_ANY=1 overrides for A/B runs of older builds whose "
+                             "struct layouts are known to match)")
         for name, argtypes in _PROTOS.items():
+            if not hasattr(self.cdll, name) and os.environ.get("CLORA_ABI_ANY", "") == "1":
+                continue                             # an older A/B build may lack the newest entry points
             fn = getattr(self.cdll, name)          # AttributeError (loud) if a symbol is missing
             fn.argtypes = argtypes
             fn.restype = C.c_int

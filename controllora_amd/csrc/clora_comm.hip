@@ -13,6 +13,7 @@
 // librccl is opened lazily with dlopen: libclora.so carries no link-time dependency on it, single-GPU users never load it, and
 // a host without RCCL gets CLORA_ERR_LAUNCH from the clora_comm_* calls instead of a loader error.
 #include <dlfcn.h>
+#include <link.h>
 #include <string.h>
 #include "clora_common.h"
 #include "../../include/clora.h"
@@ -37,9 +38,20 @@ struct Rccl {
 };
 Rccl g_rccl;
 
+// A librccl that the process has ALREADY mapped (a torch process: torch/lib/librccl.so, soname librccl.so.1) must be the one this
+// library binds -- two RCCL instances in one process would each own their own topology / IPC state.  dlopen by soname finds it
+// only if it was loaded under that soname; walking the loaded objects finds it under any path.
+int find_mapped_rccl(struct dl_phdr_info* info, size_t, void* out) {
+    if (info->dlpi_name && strstr(info->dlpi_name, "librccl.so")) { strncpy((char*)out, info->dlpi_name, 1023); return 1; }
+    return 0;
+}
+
 bool rccl_load() {
     if (g_rccl.handle) return true;
-    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    void* h = nullptr;
+    char mapped[1024] = {0};
+    if (dl_iterate_phdr(find_mapped_rccl, mapped) && mapped[0]) h = dlopen(mapped, RTLD_NOW | RTLD_NOLOAD);
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
     if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
     if (!h) return false;
     g_rccl.get_uid = (get_uid_fn)dlsym(h, "ncclGetUniqueId");
@@ -72,6 +84,19 @@ extern "C" int clora_comm_init(const void* id128, int rank, int world) {
     nccl_comm_t c = nullptr;
     if (g_rccl.init_rank(&c, world, id, rank) != 0 || !c) return CLORA_ERR_LAUNCH;     // collective: every rank calls it
     g_rccl.comm = c; g_rccl.world = world; g_rccl.rank = rank;
+    return CLORA_OK;
+}
+
+// which librccl the exchange is bound to (path of the object that defines the ncclAllReduce this library calls): a scaling record
+// can then show that the C-ABI path and torch.distributed ran the same RCCL
+extern "C" int clora_comm_library(char* path, size_t n) {
+    if (!path || n == 0) return CLORA_ERR_ARG;
+    path[0] = 0;
+    if (!rccl_load()) return CLORA_ERR_LAUNCH;
+    Dl_info di;
+    if (!dladdr((void*)g_rccl.all_reduce, &di) || !di.dli_fname) return CLORA_ERR_LAUNCH;
+    strncpy(path, di.dli_fname, n - 1);
+    path[n - 1] = 0;
     return CLORA_OK;
 }
 

@@ -67,6 +67,13 @@ __device__ __forceinline__ half4v clora_ds_read_tr16(const half_t* lptr) {
 // acc += a * b as ONE v_fma_f32 the compiler cannot merge into a packed v_pk_fma_f32 (see hoisted_rank4 in clora_gemm.hip: the
 // packed form of that block produced sporadic wrong low-half results on MI355X when several workgroups shared a CU)
 #define CLORA_FMA_F32(acc, a, b) asm("v_fma_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b))
+// shader-cycle counter (s_memtime) and the constant 100 MHz wall clock (s_memrealtime): clora_clock_probe
+#define CLORA_CYCLES() ((unsigned long long)__builtin_readcyclecounter())
+#define CLORA_WALL_TICKS() ((unsigned long long)wall_clock64())
+// schedule pins of the 8-phase GEMM main loop (gemm_8p_kernel): LDS-read counter wait, issue priority, "nothing crosses this line"
+#define CLORA_WAIT_LGKMCNT(n) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(n) : "memory")
+#define CLORA_SETPRIO(n) __builtin_amdgcn_s_setprio(n)
+#define CLORA_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
 #endif
 
 __device__ __forceinline__ floatx4 mfma16(half8 a, half8 b, floatx4 c) {

@@ -336,5 +336,42 @@ extern "C" int clora_adamw_flat_f32(float* p, const float* g, float* m, float* v
                        beta2, eps, weight_decay);
     return clora_check_launch();
 }
-extern "C" int clora_abi_version(void) { return 1; }
-extern "C" const char* clora_build_info(void) { return "libclora gfx950 (v_mfma_f32_16x16x32_f16), ABI 1"; }
+// Box calibration (bench.py): what clock does this chip hold under a dense MFMA stream?  One 256-thread block per CU-slot, every wave issues
+// `iters` x 8 independent v_mfma_f32_16x16x32_f16 on pseudo-random operands (zero operands clock higher: cdna_hip_programming.md
+// rule 25) and reports shader cycles (s_memtime) and 100 MHz wall ticks (s_memrealtime) around the loop: effective clock =
+// cycles / ticks x 100 MHz, sustained dense rate = blocks x 4 waves x iters x 8 x 16384 flop / wall time.  out[3b .. 3b+2] =
+// {cycles, ticks, checksum bits} of block b's wave 0.
+__global__ __launch_bounds__(256) void clock_probe_kernel(unsigned long long* out, int iters) {
+    const int l = threadIdx.x & 63;
+    half8 a, b;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        a[e] = (half_t)(((l * 37 + e * 11 + blockIdx.x) % 61) * (1.0f / 32.0f) - 0.95f);
+        b[e] = (half_t)(((l * 53 + e * 29 + threadIdx.x) % 59) * (1.0f / 32.0f) - 0.9f);
+    }
+    floatx4 acc[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) acc[q] = zero4f();
+    __syncthreads();
+    const unsigned long long c0 = CLORA_CYCLES(), w0 = CLORA_WALL_TICKS();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc[q] = mfma16(a, b, acc[q]);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) s += acc[q][0] + acc[q][1] + acc[q][2] + acc[q][3];
+    const unsigned long long c1 = CLORA_CYCLES(), w1 = CLORA_WALL_TICKS();
+    if (threadIdx.x == 0) {
+        out[3 * (size_t)blockIdx.x] = c1 - c0;
+        out[3 * (size_t)blockIdx.x + 1] = w1 - w0;
+        out[3 * (size_t)blockIdx.x + 2] = (unsigned long long)__float_as_uint(s);
+    }
+}
+extern "C" int clora_clock_probe(unsigned long long* out, int blocks, int iters, void* stream) {
+    if (!out || blocks <= 0 || iters <= 0) return CLORA_ERR_ARG;
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, out, iters);
+    return clora_check_launch();
+}
+extern "C" int clora_abi_version(void) { return 2; }   // 2: clora_epilogue_t / clora_lora_down_job_t grew (round 4)
+extern "C" const char* clora_build_info(void) { return "libclora gfx950 (v_mfma_f32_16x16x32_f16), ABI 2"; }

@@ -1454,8 +1454,9 @@ int conv_mode(const GemmArgs& a, int bk) {
 // 64x64 / 32x32 levels (activations 5-30 MB, weights 2-7 MB); at 16x16 / 8x8 the weights are 29-59 MB against 1-3 MB of
 // activations and n-major ranges (m fastest) are the cheaper assignment.  The model counts, per XCD and split, the distinct
 // panels of its range under either order.   "tile_order": 0 m-major always, 1 n-major always
-// (tests), 2 pick by the model.
-int g_opts[CLORA_OPT_COUNT] = {2, 1, 0, 0, 512, 1, 1, 0, 1, 1};    // tile_order, ln_rows, attn_fwd_waves (0 = auto), attn_bwd_waves (0 = auto), gn_blocks, epi_two_phase, lora_down_mode, gn_unroll, epi_hoist, gn_resident
+// (tests), 2 pick by the model, 3 (default since round 5: live PMC traffic 1.69x -> 1.59x of the algorithmic bytes, bit-identical
+// outputs) = 2 plus a per-XCD rectangle of tiles where whole divisors exist.
+int g_opts[CLORA_OPT_COUNT] = {3, 1, 0, 0, 512, 1, 1, 0, 1, 1};    // tile_order, ln_rows, attn_fwd_waves (0 = auto), attn_bwd_waves (0 = auto), gn_blocks, epi_two_phase, lora_down_mode, gn_unroll, epi_hoist, gn_resident
 int tile_order_mode() { return g_opts[CLORA_OPT_TILE_ORDER]; }
 
 double fabric_model_bytes(int tiles_m, int tiles_n, int splits, double a_panel, double b_panel, bool n_major) {
@@ -1816,7 +1817,7 @@ extern "C" int clora_conv_patch_eligible(int M, const clora_conv_t* conv, int ti
     if (!conv || tile_cfg < 71 || tile_cfg > 79) return 0;
     GemmArgs a;
     a.M = M; a.conv = *conv;
-    return patch_eligible(a, (tile_cfg == 71 || tile_cfg == 74) ? 256 : 128, tile_cfg >= 77 ? kPatchWide : 0) ? 1 : 0;
+    return patch_eligible(a, (tile_cfg == 71 || tile_cfg == 74 || tile_cfg == 79) ? 256 : 128, (tile_cfg == 77 || tile_cfg == 78) ? kPatchWide : 0) ? 1 : 0;   // same arguments as the launcher's switch
 }
 
 extern "C" int clora_gemm_f16(const clora_half* A, int lda, const clora_half* B, clora_half* C, int ldc, int M, int N,

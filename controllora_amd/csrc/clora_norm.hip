@@ -928,7 +928,9 @@ GnResident gn_resident_plan(GnArgs& a, bool bwd, bool params) {
     const int max_npt = bwd ? 8 : 16;
     for (int nt = 256; nt <= 512; nt *= 2) {
         const int nrl = nt / CH, npt = (a.HW + nrl - 1) / nrl;
-        if (npt <= max_npt && groups * 8 <= nt) {
+        // CS <= nt: stage 2 of gn_res_reduce maps one thread (group of `seg` threads) to one channel -- a slab with more channels than
+        // the block has threads would leave chs[] partly unreduced (C = 1280, G = 4)
+        if (npt <= max_npt && groups * 8 <= nt && CS <= nt) {
             a.nslab = a.G / groups; a.CS = CS; a.nchunk = 1; a.rows_per_chunk = a.HW;
             GnResident r = {nt, npt <= 4 ? 4 : (npt <= 8 ? 8 : 16)};
             return r;

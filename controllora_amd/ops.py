@@ -474,6 +474,7 @@ class _AdapterPacks:
         self.njobs = 0
         self.max_k = 0
         self.retired = []         # tables baked into captured graphs stay alive
+        self.epoch = 0            # bumped whenever a group is registered: a captured optimizer graph replays the job table of ITS epoch
 
     def _jobs_of(self, srcs, kmajor, scales, out, K):
         import ctypes as C
@@ -512,6 +513,7 @@ class _AdapterPacks:
             if self.table is not None:
                 self.retired.append(self.table)                 # a captured hipGraph may still replay a launch over the old table
             self.table = None                                   # rebuilt (with the new group) at the next repack
+            self.epoch += 1
         vers = tuple(D._version for D in live)
         if g["versions"] != vers:
             g["tab"] = self._launch(g["jobs"], g["K"], g["out"].device)    # first use / in-place update: this group alone
@@ -628,6 +630,8 @@ class _LoraProjFn(torch.autograd.Function):
                     f_in.append((s, xas[xis[1]], D.detach()))
             elif rs <= 16:                            # both inputs of a summed adapter input go through ONE job
                 x2 = xas[xis[1]] if len(xis) > 1 else None          # may hold fewer rows (control batch 1 broadcast, quirk C6)
+                if tin is not None:
+                    x2 = None                                       # t_pre IS the second input's share (c . D_q^T): count it once
                 dspecs.append(dict(X=xas[xis[0]], D=D.detach(), toff=s * r, R=rs, X2=x2, r2=0,
                                    x2_rows=x2.shape[0] if (x2 is not None and x2.shape[0] != M) else 0,
                                    T_in=tin, t_in_r=rs if tin is not None else 0))

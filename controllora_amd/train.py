@@ -94,15 +94,63 @@ class ControlLoRATrainer:
         # Exchange step: "torch" = torch.distributed.all_reduce on the process group (backend "nccl" IS RCCL on ROCm; gloo in
         # the CPU tests); "clora" = the C ABI's own RCCL communicator (clora_comm_init / clora_allreduce_flat_f32), created
         # from a unique id that rank 0 draws and the process group broadcasts.  Both enqueue the same ncclAllReduce on the
-        # current stream; "clora" is what a non-torch host would call.  Default "torch" (CLORA_COMM=clora switches).
+        # current stream; "clora" is what a non-torch host would call.  Default ("auto"): "clora" when there is something to
+        # exchange over RCCL (world > 1 on an "nccl" process group), "torch" otherwise; CLORA_COMM / comm= force either.  A
+        # requested "clora" that cannot be set up (no RCCL behind the group, communicator creation failed on ANY rank) falls
+        # back to "torch" LOUDLY: a warning on stderr and `comm_fallback` (reported in the bench line).
         import os as _os
-        self.comm = comm or _os.environ.get("CLORA_COMM", "torch")
-        if self.comm not in ("torch", "clora"):
-            raise ValueError(f"comm={self.comm!r}: expected 'torch' or 'clora'")
+        import sys as _sys
+        self.comm_requested = comm or _os.environ.get("CLORA_COMM", "auto")
+        if self.comm_requested not in ("auto", "torch", "clora"):
+            raise ValueError(f"comm={self.comm_requested!r}: expected 'auto', 'torch' or 'clora'")
+        backend = torch.distributed.get_backend(process_group) if world_size > 1 else None
+        self.comm_fallback = None
+        if self.comm_requested == "auto":
+            self.comm = "clora" if (world_size > 1 and backend == "nccl") else "torch"
+        else:
+            self.comm = self.comm_requested
+        if self.comm == "clora" and world_size > 1 and backend != "nccl":
+            self.comm_fallback = f'process group backend is {backend!r}: no RCCL behind it'
+            self.comm = "torch"
         if world_size > 1:
             torch.distributed.broadcast(self.flat.data, src=0, group=process_group)   # identical adapter init
         if self.comm == "clora":
-            self._init_clora_comm(process_group, world_size)
+            err = None
+            try:
+                self._init_clora_comm(process_group, world_size)
+            except Exception as e:                                   # noqa: BLE001 -- decided collectively below
+                err = repr(e)
+            bad = int(err is not None)
+            if world_size > 1:                                       # every rank must take the same exchange path
+                flag = torch.tensor([bad], dtype=torch.int32, device=dev)
+                torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX, group=process_group)
+                bad = int(flag.item())
+            if bad:
+                if self.comm_requested == "clora" and world_size <= 1:
+                    raise RuntimeError(f"comm='clora' requested but the C ABI communicator could not be created: {err}")
+                self.comm_fallback = f"clora_comm_init failed on at least one rank ({err})"
+                try:
+                    from . import capi
+                    capi.lib().call("clora_comm_destroy")
+                except Exception:                                    # noqa: BLE001
+                    pass
+                self.comm = "torch"
+        if self.comm_fallback:
+            print(f"[controllora_amd] WARNING: exchange path 'clora' unavailable, using torch.distributed instead: {self.comm_fallback}",
+                  file=_sys.stderr, flush=True)
+
+    def comm_library(self):
+        """path of the librccl whose ncclAllReduce the exchange step calls (C-ABI path: dladdr of the bound symbol)"""
+        if self.comm != "clora":
+            return None
+        import ctypes
+        from . import capi
+        buf = ctypes.create_string_buffer(1024)
+        try:
+            capi.lib().call("clora_comm_library", buf, 1024)
+        except Exception:                                            # noqa: BLE001
+            return None
+        return buf.value.decode(errors="replace")
 
     def _init_clora_comm(self, pg, world):
         """one RCCL communicator per process behind the C ABI: rank 0 draws the 128-byte unique id, the torch process group
@@ -226,6 +274,8 @@ class ControlLoRATrainer:
         self._g_opt = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._g_opt, pool=self._g_fb.pool()):
             self._optimizer_kernels()
+        from . import ops
+        self._pack_epoch = ops.ADAPTER_PACKS.epoch       # the captured repack launch covers the adapter groups registered so far
         return self
 
     def step_graphed(self, noisy_latents=None, timesteps=None, encoder_hidden_states=None, guide=None, target=None):
@@ -242,6 +292,11 @@ class ControlLoRATrainer:
             self.state[10:11].fill_(max(float(self.lr_lambda(self.global_step)), 1e-30))
         self.global_step += 1
         self._g_opt.replay()
+        from . import ops
+        if ops.ADAPTER_PACKS.epoch != self._pack_epoch:
+            # a group registered after the capture (e.g. run_validation at a batch size whose projections fuse differently): the
+            # captured repack launch does not know it and the flat AdamW does not bump its parameters' _version -- repack eagerly
+            ops.repack_adapters()
         return self._static_pred
 
     # -- checkpoint / resume (train...:713-735 `accelerator.save_state / load_state`: weights, optimizer moments,
@@ -261,6 +316,8 @@ class ControlLoRATrainer:
             self.state.copy_(sd["state"])
             self.state[11] = float(self.world)       # the divisor belongs to THIS run's world size, not the checkpoint's
         self.global_step, self._micro = int(sd["global_step"][0]), 0
+        from . import ops
+        ops.repack_adapters()        # the copies above do not bump the parameters' _version: refresh the fp16 operand packs now
 
     def save_state(self, directory: str) -> None:
         import os
@@ -333,9 +390,14 @@ class ControlLoRATrainer:
                 self.state[3] = float(sc.get("scale", 65536.0))
                 self.state[4] = float(sc.get("_growth_tracker", 0))
             self.state[11] = float(self.world)
+        # optimizer steps taken = the AdamW `step` (parsed above).  scheduler.bin is only a cross-check: accelerate's
+        # AcceleratedScheduler advances the wrapped scheduler num_processes times per optimizer step (train...:660-665 builds the
+        # schedule in those units), so a multi-GPU checkpoint holds last_epoch = world_of_the_saving_run x steps
         self.global_step = step
-        if os.path.exists(f("scheduler.bin")):
-            self.global_step = int(torch.load(f("scheduler.bin"), map_location="cpu").get("last_epoch", step))
+        self.resumed_scheduler_ratio = None
+        if os.path.exists(f("scheduler.bin")) and step > 0:
+            last = int(torch.load(f("scheduler.bin"), map_location="cpu").get("last_epoch", step))
+            self.resumed_scheduler_ratio = last / step       # = the saving run's process count (1 for a single-GPU run)
         self._micro = 0
         from . import ops
         ops.repack_adapters()
@@ -356,7 +418,8 @@ class ControlLoRATrainer:
         torch.save({"state": state, "param_groups": [group]}, os.path.join(directory, "optimizer.bin"))
         torch.save({"scale": float(self.state[3]), "growth_factor": 2.0, "backoff_factor": 0.5, "growth_interval": self.hp["interval"],
                     "_growth_tracker": int(self.state[4])}, os.path.join(directory, "scaler.pt"))
-        torch.save({"last_epoch": self.global_step, "_step_count": self.global_step + 1}, os.path.join(directory, "scheduler.bin"))
+        # accelerate's unit: the wrapped scheduler is stepped `num_processes` times per optimizer step
+        torch.save({"last_epoch": self.global_step * self.world, "_step_count": self.global_step * self.world + 1}, os.path.join(directory, "scheduler.bin"))
 
     # -- host-visible scalars (each forces a sync; call outside the timed region)
     def loss(self, numel) -> float:

@@ -152,8 +152,9 @@ int clora_conv_patch_eligible(int M, const clora_conv_t* conv, int tile_cfg);
  *   "tile_order"      how clora_gemm_f16[_ex] assigns output tiles -- and the attention kernels their (batch, head) blocks -- to
  *                     the eight XCDs.  0 = every XCD a contiguous range of tiles in m-major order, attention blocks in launch
  *                     order; 1 = n-major tile ranges; 2 = per launch the order that fetches fewer distinct A / B panels per XCD
- *                     (default: same-box A/B on MI355X 24.51 -> 24.35 ms/step); 3 = as 2, plus per launch an (split, m, n) RECTANGLE of tiles
- *                     per XCD where whole divisors exist and the same panel count model prefers it.  1, 2 and 3 also give every XCD whole
+ *                     (same-box A/B on MI355X 24.51 -> 24.35 ms/step); 3 (default) = as 2, plus per launch an (split, m, n) RECTANGLE of tiles
+ *                     per XCD where whole divisors exist and the same panel count model prefers it (fabric traffic of the GEMM
+ *                     family 1.69x -> 1.59x of its algorithmic bytes, outputs bit-identical to 2).  1, 2 and 3 also give every XCD whole
  *                     attention heads.
  *   "ln_rows"         1 = LayerNorm keeps several rows in flight per wave (default), 0 = one row per wave.
  *   "attn_fwd_waves"  0 = pick by grid size (default), 4 | 6 | 8 = waves per forward attention block (head dims <= 64).
@@ -344,6 +345,7 @@ int clora_lora_wgrad_f16(const clora_half* A, int lda, const float* T, int ldt, 
  *   clora_comm_destroy     releases the communicator */
 int clora_comm_unique_id(void* id128);
 int clora_comm_init(const void* id128, int rank, int world);
+int clora_comm_library(char* path, size_t n);   /* file that defines the ncclAllReduce the library is bound to (dladdr); loads librccl */
 int clora_comm_world(void);
 int clora_comm_rank(void);
 int clora_allreduce_flat_f32(float* buf, size_t n, void* stream);
@@ -384,7 +386,14 @@ int clora_optim_prep_f32(float* state, float max_norm, float beta1, float beta2,
 int clora_adamw_flat_f32(float* p, const float* g, float* m, float* v, size_t n, const float* state, float lr,
                          float beta1, float beta2, float eps, float weight_decay, void* stream);
 
-/* library info */
+/* Box calibration (bench.py "calibration"): `blocks` workgroups of 4 waves issue iters x 8 independent dense MFMAs each on
+ * pseudo-random operands; out[3b .. 3b+2] = {shader cycles, 100 MHz wall ticks, checksum} of block b.  No reference
+ * counterpart: it exists so that a bench line can be normalised by the clock the box actually held (DVFS). */
+int clora_clock_probe(unsigned long long* out, int blocks, int iters, void* stream);
+
+/* library info: clora_abi_version() changes whenever a struct of this header changes layout (2: round 4's clora_epilogue_t /
+ * clora_lora_down_job_t fields); a host built against another version must refuse the library */
+#define CLORA_ABI_VERSION 2
 int clora_abi_version(void);
 const char* clora_build_info(void);
 

@@ -114,11 +114,17 @@ static inline hipemu_half4 hipemu_tr16(const void* p) {
 #define CLORA_KEEP(x) ((void)0)
 #define CLORA_KEEP_PURE(x) ((void)0)
 #define CLORA_FMA_F32(acc, a, b) ((acc) = fmaf((a), (b), (acc)))
+#define CLORA_CYCLES() (0ull)
+#define CLORA_WALL_TICKS() (0ull)
+#define CLORA_WAIT_LGKMCNT(n) ((void)0)
+#define CLORA_SETPRIO(n) ((void)0)
+#define CLORA_SCHED_BARRIER() ((void)0)
 static inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }
 static inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v; return o; }
 static inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
 static inline unsigned atomicMax(unsigned* p, unsigned v) { unsigned o = *p; if (v > o) *p = v; return o; }
 static inline unsigned atomicOr(unsigned* p, unsigned v) { unsigned o = *p; *p = o | v; return o; }
+static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
 static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 static inline float __frcp_rn(float x) { return 1.0f / x; }
 

@@ -86,6 +86,46 @@ def test_resume_from_an_accelerate_format_checkpoint(tmp_path):
     st = opt2.state_dict()["state"]
     assert len(st) == len(params) and int(st[0]["step"]) == 4
     assert torch.allclose(st[0]["exp_avg"], opt.state[params[0]]["exp_avg"], atol=1e-8)
+    # the step count comes from the optimizer state, scheduler.bin is in accelerate's unit (the wrapped scheduler is
+    # stepped num_processes times per optimizer step): a checkpoint of an 8-process run resumes at step 3, not 24
+    torch.save({"last_epoch": 24, "_step_count": 25}, d / "scheduler.bin")
+    tr.load_state(str(d))
+    assert tr.global_step == 3 and tr.resumed_scheduler_ratio == 8.0
+    tr.world = 4
+    tr.global_step = 5
+    tr.save_accelerate_state(str(tmp_path / "checkpoint-5"))
+    assert torch.load(tmp_path / "checkpoint-5" / "scheduler.bin")["last_epoch"] == 20
+
+
+def test_adapter_packs_are_refreshed_behind_flat_updates(monkeypatch):
+    """(a) a pack group registered after the optimizer graph was captured is unknown to the captured repack launch --
+    `_AdapterPacks.epoch` moves and step_graphed repacks eagerly; (b) ControlLoRATrainer.load_state_dict copies into the flat
+    buffer without bumping any parameter's _version, so it must repack itself."""
+    from controllora_amd import ops
+    from controllora_amd.train import ControlLoRATrainer
+    from tests.emu_fixture import use_emulator
+    unet, clora, _ = E.build_product_case("v1", "cpu")
+    with use_emulator():
+        packs = ops._AdapterPacks()
+        D1, D2 = torch.randn(4, 64), torch.randn(4, 64)
+        e0 = packs.epoch
+        a = packs.get([D1]).clone()
+        assert packs.epoch == e0 + 1
+        packs.get([D1])
+        assert packs.epoch == e0 + 1                      # same group: no new epoch
+        packs.get([D1, D2])
+        assert packs.epoch == e0 + 2
+        with torch.no_grad():
+            D1.data.mul_(2.0)                             # what the flat AdamW kernel does: the bytes change, _version does not
+        v = D1._version
+        assert torch.equal(packs.get([D1]), a) and D1._version == v     # stale until someone repacks ...
+        packs.repack_all()
+        assert torch.equal(packs.get([D1])[:4].float(), D1.half().float())         # ... rows 0..3 = fp16(D)
+        tr = ControlLoRATrainer(unet, clora, lr=1e-3)
+        calls = []
+        monkeypatch.setattr(ops, "repack_adapters", lambda: calls.append(1))
+        tr.load_state_dict(tr.state_dict())
+        assert calls, "load_state_dict must refresh the adapter operand packs"
 
 
 def test_vae_encode_decode_matches_oracle():
@@ -183,3 +223,83 @@ def test_pipeline_prompt_to_image_on_the_emulator():
     assert b.shape == a.shape and torch.equal(a[0], b[0]) and not torch.equal(a[1], b[1])   # image 0 sees the same guide both times
     with pytest.raises(ValueError):
         pipe("red circle", torch.rand(3, 3, 64, 64), num_samples=2, ddim_steps=2, seed=5)
+
+
+def test_pose_app_process_call_pattern_on_the_emulator():
+    """reference apps/gradio_pose2image.py:68-96 with the pose map supplied instead of detected (the OpenPose annotator is out of
+    scope): nearest-neighbour resize of the map to the generation size (line 77), BGR flip + /127.5 - 1 control tensor (line 79),
+    the reference's return convention [detected_map] + images, the 30-step DPM-Solver++ default of the app; a different pose map
+    gives a different image, the same one the same image."""
+    import importlib.util
+    import os
+    import numpy as np
+    from controllora_amd import models as M
+    from controllora_amd.pipeline import ControlLoRAPipeline
+    from oracle import cases
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("pose2image", os.path.join(root, "apps", "pose2image.py"))
+    app = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(app)
+    # nearest resize == cv2.INTER_NEAREST's index rule on an up- and a down-scale
+    src = np.arange(6 * 4 * 3, dtype=np.uint8).reshape(6, 4, 3)
+    up = app.nearest_resize(src, 8, 12)
+    assert up.shape == (12, 8, 3) and np.array_equal(up[::2, ::2], src) and np.array_equal(up[1::2, 1::2], src)
+    assert np.array_equal(app.nearest_resize(src, 2, 3), src[::2, ::2])
+    torch.manual_seed(0)
+    clora = M.ControlLoRA(**cases.SMALL_CLORA_V1)
+    with torch.no_grad():
+        for n, p_ in clora.named_parameters():
+            if n.endswith(".up.weight"):
+                p_.normal_(0.0, 0.2)
+    pipe = ControlLoRAPipeline.from_pretrained("random:small", clora, "cpu")
+    rng = np.random.default_rng(0)
+    pose = (rng.random((32, 32, 3)) > 0.8).astype(np.uint8) * 255            # a small "skeleton" map, resized to 64 x 64 by process()
+    photo = np.zeros((128, 128, 3), np.uint8)
+    seen = {}
+    orig = pipe.__class__.__call__
+
+    def spy(self, prompt, control, **kw):
+        seen.update(control=control.clone(), kw=kw)
+        return orig(self, prompt, control, **kw)
+    pipe.__class__.__call__ = spy
+    try:
+        out = app.process(pipe, photo, "a man", "best quality", "lowres", 1, 64, 64, 2, 5.0, 7, 0.0, pose_map=pose)
+    finally:
+        pipe.__class__.__call__ = orig
+    assert len(out) == 2 and out[0].shape == (64, 64, 3) and out[1].shape == (64, 64, 3) and out[1].dtype == np.uint8
+    assert np.array_equal(out[0], app.nearest_resize(pose, 64, 64))                      # [detected_map] first, un-inverted (pose app)
+    want = torch.from_numpy(out[0][..., ::-1].copy().transpose(2, 0, 1)).float()[None] / 127.5 - 1.0
+    assert torch.equal(seen["control"], want) and seen["kw"]["sampler"] == "dpm" and seen["kw"]["ddim_steps"] == 2
+    again = app.process(pipe, photo, "a man", "best quality", "lowres", 1, 64, 64, 2, 5.0, 7, 0.0, pose_map=pose)
+    other = app.process(pipe, photo, "a man", "best quality", "lowres", 1, 64, 64, 2, 5.0, 7, 0.0, pose_map=255 - pose)
+    assert np.array_equal(out[1], again[1]) and not np.array_equal(out[1], other[1])
+
+
+@pytest.mark.parametrize("M,fuse", [(128, "0"), (96, "1")])
+def test_lora_proj_counts_a_precomputed_second_input_once(M, fuse, monkeypatch):
+    """on the NON-fused path `_LoraProjFn.forward` handed the down-projection job both the materialised second input
+    (X2 = c) and its precomputed share (T_in = t_pre = c . D^T), so T = (h + c) . D^T + c . D^T.  With a t_pre the job must read h
+    alone; the result equals the call without t_pre (which evaluates L(h + c) = L(h) + L(c) itself).  M = 128 / 96, N = K = 320
+    have no fused plan (too few blocks / down-projection fusion switched off)."""
+    from controllora_amd import ops
+    from tests.emu_fixture import use_emulator
+    monkeypatch.setattr(ops, "FUSE_DOWN", fuse == "1")
+    g = torch.Generator().manual_seed(3)
+    Kd = N = 320
+    x = (torch.randn(M, Kd, generator=g) * 0.5).half()
+    c = (torch.randn(M, Kd, generator=g) * 0.5).half()
+    W = torch.randn(N, Kd, generator=g) / Kd ** 0.5
+    D = torch.randn(4, Kd, generator=g) / Kd ** 0.5
+    U = torch.randn(N, 4, generator=g) * 0.3
+    pack = ops.LinearPack(W, torch.zeros(N))
+    with use_emulator():
+        assert ops._fuse_plan(M, N, Kd, N) is None or fuse == "1"
+        if ops._fusable(pack, ((((0, 1)), 1.0),), [4], N, M) is not None:
+            pytest.skip("shape became fusable: the test needs the non-fused path")
+        ref = ops.lora_proj(x, pack, [((x, c), D, U, 1.0)])
+        t_pre = c.float() @ D.t()
+        got = ops.lora_proj(x, pack, [((x, c), D, U, 1.0)], t_pre=t_pre.contiguous())
+    want = (x.float() @ W.t().half().float()) + ((x.float() + c.float()) @ D.t()) @ U.t()
+    rel = lambda a, b: float((a.float() - b).norm() / b.norm())
+    assert rel(ref, want) < 2e-3
+    assert rel(got, want) < 2e-3, rel(got, want)                       # 0.35 with the double count

@@ -219,6 +219,14 @@ def test_groupnorm_random_shapes():
         KC.case_groupnorm("cpu", B, HW, C, G, rng.random() < 0.5, seed=n)
 
 
+@pytest.mark.parametrize("B,HW,C,G", [(1, 64, 1280, 4), (2, 16, 2048, 1), (1, 37, 512, 4), (1, 16, 1024, 8), (2, 9, 2560, 8), (1, 64, 640, 5)])
+def test_groupnorm_wide_groups(B, HW, C, G):
+    """groups wider than a block has threads (cpg 128 .. 2048; ADVICE r04: the one-launch plan reduced only the first NT / seg
+    channels of a slab and read the rest of chs[] uninitialised -- C = 1280, G = 4, HW = 64 gave rel err 0.12): such shapes must
+    not take the one-launch plan, and whatever plan they take agrees with torch and with the other plan (case_groupnorm)"""
+    KC.case_groupnorm("cpu", B, HW, C, G, True, seed=B + HW)
+
+
 @pytest.mark.parametrize("M,C", [(37, 320), (9, 1280), (5, 64)])
 def test_layernorm(M, C):
     KC.case_layernorm("cpu", M, C)
