@@ -40,15 +40,21 @@ def build(force: bool = False, verbose: bool = True) -> str:
 def _build_locked(force: bool, verbose: bool) -> str:
     deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(os.path.dirname(HERE), "include", "clora.h")]
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    objs = []
+    objs, jobs = [], []
     for src in sources():
         obj = os.path.join(OUT_DIR, os.path.basename(src)[:-4] + ".o")
         if force or _stale(obj, deps):
-            cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", obj]
+            jobs.append([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", obj])
+        objs.append(obj)
+    if jobs:                                     # independent translation units: compile them side by side (clora_gemm.hip alone takes ~2 min)
+        from concurrent.futures import ThreadPoolExecutor
+
+        def run(cmd):
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)
-        objs.append(obj)
+        with ThreadPoolExecutor(max_workers=min(len(jobs), max(1, (os.cpu_count() or 2) // 2))) as ex:
+            list(ex.map(run, jobs))
     if force or _stale(LIB, objs):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB]
         if verbose:

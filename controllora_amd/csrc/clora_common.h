@@ -70,6 +70,10 @@ __device__ __forceinline__ half4v clora_ds_read_tr16(const half_t* lptr) {
 // shader-cycle counter (s_memtime) and the constant 100 MHz wall clock (s_memrealtime): clora_clock_probe
 #define CLORA_CYCLES() ((unsigned long long)__builtin_readcyclecounter())
 #define CLORA_WALL_TICKS() ((unsigned long long)wall_clock64())
+// acc = a . b + acc as ONE instruction on a register quad the compiler cannot re-number (the probe loop written with the builtin
+// compiled to 40 v_accvgpr moves per 8 MFMAs: 28 cycles per MFMA instead of 16)
+#define CLORA_MFMA_INPLACE(acc, a, b) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b))
+#define CLORA_MFMA_DRAIN() asm volatile("s_nop 15\n\ts_nop 15" ::: "memory")   // before compiler code reads what an asm MFMA wrote
 // schedule pins of the 8-phase GEMM main loop (gemm_8p_kernel): LDS-read counter wait, issue priority, "nothing crosses this line"
 #define CLORA_WAIT_LGKMCNT(n) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(n) : "memory")
 #define CLORA_SETPRIO(n) __builtin_amdgcn_s_setprio(n)

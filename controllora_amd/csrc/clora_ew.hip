@@ -356,8 +356,9 @@ __global__ __launch_bounds__(256) void clock_probe_kernel(unsigned long long* ou
     const unsigned long long c0 = CLORA_CYCLES(), w0 = CLORA_WALL_TICKS();
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) acc[q] = mfma16(a, b, acc[q]);
+        for (int q = 0; q < 8; ++q) CLORA_MFMA_INPLACE(acc[q], a, b);
     }
+    CLORA_MFMA_DRAIN();                                        // the last MFMAs' results are read below (hipcc pads nothing after an asm statement)
     float s = 0.f;
 #pragma unroll
     for (int q = 0; q < 8; ++q) s += acc[q][0] + acc[q][1] + acc[q][2] + acc[q][3];

@@ -1008,6 +1008,198 @@ __global__ __launch_bounds__(WM * WN * 64, (DmaOcc<BM, BN, NST, BK, WM * WN>::v)
 }
 
 // ------------------------------------------------------------------------------------------------
+// gemm_8p_kernel (tile_cfg 59): the plain GEMM on a 256 x 256 tile with the eight-phase ping-pong schedule of the CDNA4 guide
+// (cdna_hip_programming.md section 5, "The 256^2 8-phase template"), for the launches with M >= 16384 and wide N (FeedForward
+// projections, q|k|v at batch 32, the 8192^3 calibration GEMM).  What differs from gemm_dma_kernel's one-barrier-per-stage loop:
+//   * 8 waves = 2 (M) x 4 (N), wave tile 128 x 64 (FM = 8, FN = 4: 12 fragment reads per 64 MFMAs of a BK = 64 step instead of
+//     the 32x128 / 64x64 wave tiles' 20 / 16: the LDS fragment traffic was what kept the other tiles at 23 % MFMA busy);
+//   * a K-tile is FOUR phases of 16 MFMAs, one quadrant (64 rows x 32 columns) of the wave tile each: (A0,B0) (A0,B1) (A1,B1) (A1,B0);
+//     phase 0 reads the A0 and B0 fragments, phase 1 B1, phase 2 A1, phase 3 nothing (B0 stays in registers): every fragment is read
+//     from LDS exactly once per K-tile;
+//   * the two wave rows run ONE BARRIER APART (the wr == 1 waves pass an extra barrier before the loop, the wr == 0 waves one after
+//     it): between two barriers one wave of every SIMD issues its fragment reads and LDS-DMA while the other one owns the matrix
+//     pipe (s_setprio 1 around the MFMA cluster) -- the roles swap at every barrier;
+//   * operands arrive as 16-KB HALF-TILES by LDS-DMA (128 rows x 128 B; A-half h = the rows with (row % 128) / 64 == h of both wave
+//     rows, B-half h = the columns with (col % 64) / 32 == h of all four wave columns: exactly what the phases consume), one half-tile
+//     = 2 DMA instructions per thread per phase, SEVEN half-tiles ahead, in an 8-slot ring (2 K-tiles x {A0, B0, B1, A1} = 128 KB).
+//     Counted wait ONCE per K-tile: s_waitcnt vmcnt(6) in phase 3 (three half-tiles stay in flight across the barriers) retires the
+//     whole next K-tile; it sits before the phase's first barrier, so every wave -- of either wave row -- reads the buffer only after
+//     a barrier that all issuing waves passed behind their wait.
+//   * write-after-read: half-tile G + 7 lands in the slot of half-tile G - 1, whose last fragment read was issued one phase (A0) or
+//     two phases earlier and RETIRED (s_waitcnt lgkmcnt(0)) before the first barrier of its phase by both wave rows.
+// Rows past M / N are clamped to the last valid row (they feed accumulator rows / columns the epilogue never stores), k past the end
+// of the split fetches the zero page (the tail K-tile of K % 64 != 0, and the trailing prefetches that keep the wait a constant).
+// LDS rows are 128 B, key r & 7 on the source side as in gemm_dma_kernel (BK = 64): conflict-free ds_read_b128.
+template <int CONV>
+__global__ __launch_bounds__(512) void gemm_8p_kernel(GemmArgs p) {
+    static_assert(CONV == 0, "plain GEMM rows only");
+    constexpr int BM = 256, BN = 256, BK = 64, WM = 2, WN = 4, NT = 512;
+    constexpr int FM = 8, FN = 4;
+    constexpr int HT = 128 * BK;                             // halves per half-tile (16 KB)
+    constexpr int kInFlight8p = 6;                           // DMA instructions of the three half-tiles that stay in flight across the K-tile's wait
+    constexpr int SMEM = 8 * HT;                             // 128 KB
+    static_assert(64 * (BN + 4) * 2 <= SMEM, "epilogue staging");
+    __shared__ __attribute__((aligned(16))) half_t smem[SMEM];
+
+    const int t = threadIdx.x;
+    const int tiles = gridDim.x, nwg = gridDim.x * gridDim.y;  // XCD-aware block order, as in gemm_dma_kernel
+    const int lin = blockIdx.y * gridDim.x + blockIdx.x;
+    const int xq = nwg >> 3, xr = nwg & 7, xcd = lin & 7;
+    const int logical = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (lin >> 3);
+    int split = logical / tiles, tile = logical - split * tiles;
+    int tile_m = p.n_major ? tile % p.tiles_m : tile / p.tiles_n, tile_n = p.n_major ? tile / p.tiles_m : tile % p.tiles_n;
+    if (p.xg_m) {
+        const int rn = p.tiles_n / p.xg_n, rm = p.tiles_m / p.xg_m, rs = (int)gridDim.y / p.xg_s, idx = lin >> 3;
+        const int sl = idx / (rm * rn), r = idx - sl * (rm * rn);
+        split = (xcd / (p.xg_m * p.xg_n)) * rs + sl;
+        tile_m = ((xcd / p.xg_n) % p.xg_m) * rm + r / rn;
+        tile_n = (xcd % p.xg_n) * rn + r % rn;
+    }
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int kbeg = split * p.k_per_split;
+    const int kend = (kbeg + p.k_per_split < p.K) ? kbeg + p.k_per_split : p.K;
+    const int nk = (kend - kbeg + BK - 1) / BK;
+
+    const int w = t >> 6, l = t & 63, g = l >> 4, li = l & 15;
+    const int wr = w >> 2, wc = w & 3;                       // wave row / column: rows wr*128.., columns wc*64..
+    const half_t* zero_page = reinterpret_cast<const half_t*>(g_clora_zero16);
+
+    // ---- loader: per half-tile a thread issues two DMA instructions; instruction i of wave w fills local rows (w*2 + i)*8 .. +8,
+    // lane -> (row l >> 3, slot l & 7) and fetches logical k-chunk kc = slot ^ (row & 7)
+    const int lrow8 = l >> 3, kc = (l & 7) ^ (lrow8 & 7);
+    const half_t* srcA[2][2];                                // [half][instruction]: row pointer + lane chunk, K-tile 0 of the split
+    const half_t* srcB[2][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int lr = (w * 2 + i) * 8 + lrow8;          // local row of the half-tile, 0..127
+            int m = m0 + (lr >> 6) * 128 + h * 64 + (lr & 63);
+            int n = n0 + (lr >> 5) * 64 + h * 32 + (lr & 31);
+            m = m < p.M ? m : p.M - 1;
+            n = n < p.N ? n : p.N - 1;
+            srcA[h][i] = p.A + (size_t)m * p.lda + kbeg + kc * 8;
+            srcB[h][i] = p.B + (size_t)n * p.K + kbeg + kc * 8;
+        }
+    const int klane = kbeg + kc * 8;
+    // stage half-tile `slot` (0: A0, 1: B0, 2: B1, 3: A1) of K-tile ts of this split into ring buffer ts & 1
+    auto stage = [&](int ts, int slot) {
+        half_t* dst = smem + ((ts & 1) * 4 + slot) * HT + w * 2 * 512;
+        const bool kok = klane + ts * BK < kend;
+        const size_t ko = (size_t)ts * BK;
+        const half_t* s0 = slot == 0 ? srcA[0][0] : slot == 1 ? srcB[0][0] : slot == 2 ? srcB[1][0] : srcA[1][0];
+        const half_t* s1 = slot == 0 ? srcA[0][1] : slot == 1 ? srcB[0][1] : slot == 2 ? srcB[1][1] : srcA[1][1];
+        CLORA_GLDS16(kok ? s0 + ko : zero_page, dst);
+        CLORA_GLDS16(kok ? s1 + ko : zero_page, dst + 512);
+    };
+
+    // ---- fragment addressing: A fragment i (rows wr*128 + i*16 + li) lives in A-half i / 4 at local row wr*64 + (i % 4)*16 + li;
+    // B fragment j (columns wc*64 + j*16 + li) in B-half j / 2 at local row wc*32 + (j % 2)*16 + li; 16-byte slot (ks*4 + g) ^ (li & 7)
+    int fsw[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) fsw[ks] = ((ks * 4 + g) ^ (li & 7)) * 8;
+    const int a_row = (wr * 64 + li) * BK, b_row = (wc * 32 + li) * BK;
+
+    floatx4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = zero4f();
+
+    // prologue: half-tiles 0..6 (K-tile 0 complete, K-tile 1 without its A1), then K-tile 0 landed and published
+    stage(0, 0); stage(0, 1); stage(0, 2); stage(0, 3);
+    stage(1, 0); stage(1, 1); stage(1, 2);
+    CLORA_WAIT_VMCNT(6);
+    CLORA_RAW_BARRIER();
+    if (wr == 1) CLORA_RAW_BARRIER();                        // the second wave row runs one barrier behind the first
+
+    half8 a0[2][4], a1[2][4], b0[2][2], b1[2][2];
+    for (int kt = 0; kt < nk; ++kt) {
+        const half_t* buf = smem + (kt & 1) * 4 * HT;
+        // ---- phase 0: A0, B0 fragments; quadrant (rows 0..63, columns 0..31) of the wave tile; stages A1 of K-tile kt + 1
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b0[ks][j] = ld8(buf + 1 * HT + b_row + j * 16 * BK + fsw[ks]);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a0[ks][i] = ld8(buf + 0 * HT + a_row + i * 16 * BK + fsw[ks]);
+        stage(kt + 1, 3);
+        CLORA_WAIT_LGKMCNT(0);
+        CLORA_RAW_BARRIER();
+        CLORA_SCHED_BARRIER();
+        CLORA_SETPRIO(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = mfma16(a0[ks][i], b0[ks][j], acc[i][j]);
+        CLORA_SETPRIO(0);
+        CLORA_SCHED_BARRIER();
+        CLORA_RAW_BARRIER();
+        // ---- phase 1: B1 fragments; quadrant (rows 0..63, columns 32..63); stages A0 of K-tile kt + 2 (A0 of kt was read a phase ago)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b1[ks][j] = ld8(buf + 2 * HT + b_row + j * 16 * BK + fsw[ks]);
+        stage(kt + 2, 0);
+        CLORA_WAIT_LGKMCNT(0);
+        CLORA_RAW_BARRIER();
+        CLORA_SCHED_BARRIER();
+        CLORA_SETPRIO(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][2 + j] = mfma16(a0[ks][i], b1[ks][j], acc[i][2 + j]);
+        CLORA_SETPRIO(0);
+        CLORA_SCHED_BARRIER();
+        CLORA_RAW_BARRIER();
+        // ---- phase 2: A1 fragments; quadrant (rows 64..127, columns 32..63); stages B0 of K-tile kt + 2
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a1[ks][i] = ld8(buf + 3 * HT + a_row + i * 16 * BK + fsw[ks]);
+        stage(kt + 2, 1);
+        CLORA_WAIT_LGKMCNT(0);
+        CLORA_RAW_BARRIER();
+        CLORA_SCHED_BARRIER();
+        CLORA_SETPRIO(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[4 + i][2 + j] = mfma16(a1[ks][i], b1[ks][j], acc[4 + i][2 + j]);
+        CLORA_SETPRIO(0);
+        CLORA_SCHED_BARRIER();
+        CLORA_RAW_BARRIER();
+        // ---- phase 3: no fragment reads (B0 is still in registers); quadrant (rows 64..127, columns 0..31); stages B1 of K-tile kt + 2;
+        // the K-tile's one counted wait: everything but the three newest half-tiles has landed = all of K-tile kt + 1
+        stage(kt + 2, 2);
+        CLORA_WAIT_VMCNT(kInFlight8p);
+        CLORA_RAW_BARRIER();
+        CLORA_SCHED_BARRIER();
+        CLORA_SETPRIO(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[4 + i][j] = mfma16(a1[ks][i], b0[ks][j], acc[4 + i][j]);
+        CLORA_SETPRIO(0);
+        CLORA_SCHED_BARRIER();
+        CLORA_RAW_BARRIER();
+    }
+    if (wr == 0) CLORA_RAW_BARRIER();                        // re-join the two wave rows
+    CLORA_WAIT_VMCNT(0);                                     // trailing zero-page prefetches: LDS is reused below
+    dma_epilogue<BM, BN, WM, WN, NT, SMEM, true>(p, acc, m0, n0, split, smem, t);
+}
+
+// ------------------------------------------------------------------------------------------------
 // 3x3 / stride-1 / pad-1 convolution and its dgrad with the input staged ONCE per channel slab as a spatial patch in LDS.
 //
 // The implicit GEMM above fetches every input pixel nine times from L2 (once per filter tap); with its operand DMAs
@@ -1537,6 +1729,14 @@ int launch_gemm(GemmArgs& a, int splits, hipStream_t s, bool dma) {
     return clora_check_launch();
 }
 
+int launch_gemm_8p(GemmArgs& a, int splits, hipStream_t s) {
+    a.tiles_n = clora_cdiv(a.N, 256);
+    pick_tile_order(a, 256, 256, splits, false);
+    const dim3 grid(clora_cdiv(a.M, 256) * a.tiles_n, splits);
+    hipLaunchKernelGGL((gemm_8p_kernel<0>), grid, dim3(512), 0, s, a);
+    return clora_check_launch();
+}
+
 // conv3x3_patch_kernel: what it can take (everything else stays on gemm_dma_kernel)
 bool patch_eligible(const GemmArgs& a, int bm, int maxpp = 0) {
     const clora_conv_t& c = a.conv;
@@ -1691,7 +1891,7 @@ extern "C" int clora_gemm_f16_ex(const clora_half* A, int lda, const clora_half*
     }
     if (a.epi.geglu) {
         if (!dma) return CLORA_ERR_ARG;
-        const bool wide = cfg == 1 || cfg == 4 || cfg == 7 || cfg == 8 || cfg == 9 || cfg == 21 || cfg == 31 || cfg == 41 || cfg == 53 || cfg == 56 || cfg == 58;
+        const bool wide = cfg == 1 || cfg == 4 || cfg == 7 || cfg == 8 || cfg == 9 || cfg == 21 || cfg == 31 || cfg == 41 || cfg == 53 || cfg == 56 || cfg == 58 || cfg == 59;
         if (a.epi.geglu == 1 && !wide) { if (tile_cfg > 0) return CLORA_ERR_ARG; cfg = 1; }
     }
     //   71..76 = conv3x3_patch_kernel (3x3 stride-1 pad-1 convs and their dgrads, input patch staged once per 64-channel slab):
@@ -1733,7 +1933,9 @@ extern "C" int clora_gemm_f16_ex(const clora_half* A, int lda, const clora_half*
             return rc;
         }
     }
-    const int bk = ((cfg >= 21 && cfg <= 26) || (cfg >= 41 && cfg <= 43) || (cfg >= 51 && cfg <= 58) || (cfg >= 91 && cfg <= 96)) ? 64 : 32;
+    //   59 = gemm_8p_kernel: 256x256, 8 waves of 128x64, eight-phase ping-pong (plain GEMM rows only; convs fall back to 58)
+    if (cfg == 59 && (a.conv.enabled || !dma)) cfg = 58;
+    const int bk = ((cfg >= 21 && cfg <= 26) || (cfg >= 41 && cfg <= 43) || (cfg >= 51 && cfg <= 59) || (cfg >= 91 && cfg <= 96)) ? 64 : 32;
     a.k_per_split = clora_cdiv(clora_cdiv(K, bk), splits) * bk;
     splits = clora_cdiv(K, a.k_per_split);
     if (splits > 1) {
@@ -1763,6 +1965,7 @@ extern "C" int clora_gemm_f16_ex(const clora_half* A, int lda, const clora_half*
         case 53: rc = launch_gemm<128, 256, 4, 2, 3, 64, 0>(a, splits, s, true); break;
         case 57: rc = launch_gemm<256, 320, 4, 2, 2, 64, 1>(a, splits, s, true); break;    // M >= 32768 (batch-32 inference): 142 flop per operand byte
         case 58: rc = launch_gemm<256, 256, 4, 2, 2, 64, 1>(a, splits, s, true); break;
+        case 59: rc = launch_gemm_8p(a, splits, s); break;
         case 54: rc = launch_gemm<128, 320, 4, 2, 2, 64, 1>(a, splits, s, true); break;
         case 55: rc = launch_gemm<64, 320, 2, 4, 3, 64, 1>(a, splits, s, true); break;
         case 56: rc = launch_gemm<128, 256, 4, 2, 3, 64, 1>(a, splits, s, true); break;

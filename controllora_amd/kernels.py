@@ -102,7 +102,7 @@ def workspace(nbytes: int, device) -> torch.Tensor:
 
 
 _ws_retired = []
-WIDE_TILE_CFGS = (1, 4, 7, 8, 9, 21, 31, 41, 53, 56, 58)      # tile_cfg values whose tiles are >= 128 columns wide (GEGLU-forward epilogue)
+WIDE_TILE_CFGS = (1, 4, 7, 8, 9, 21, 31, 41, 53, 56, 58, 59)      # tile_cfg values whose tiles are >= 128 columns wide (GEGLU-forward epilogue)
 GEMM_WS_BYTES = 256 << 20   # split-K slab budget handed to the library's launch planner
 
 # Autotuned launch configurations (tools/tune_gemm.py on an MI355X): exact-shape lookups for the GEMMs of the

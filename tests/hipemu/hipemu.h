@@ -116,6 +116,8 @@ static inline hipemu_half4 hipemu_tr16(const void* p) {
 #define CLORA_FMA_F32(acc, a, b) ((acc) = fmaf((a), (b), (acc)))
 #define CLORA_CYCLES() (0ull)
 #define CLORA_WALL_TICKS() (0ull)
+#define CLORA_MFMA_INPLACE(acc, a, b) ((acc) = __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (acc), 0, 0, 0))
+#define CLORA_MFMA_DRAIN() ((void)0)
 #define CLORA_WAIT_LGKMCNT(n) ((void)0)
 #define CLORA_SETPRIO(n) ((void)0)
 #define CLORA_SCHED_BARRIER() ((void)0)

@@ -18,10 +18,13 @@ EDITS = [
     ("CLORA_WAIT_VMCNT((NST - 2) * (A_IN + B_IN));", "CLORA_WAIT_VMCNT((NST - 1) * (A_IN + B_IN));"),
     # patch conv: the weight ring's steady-state wait one stage short
     ("else CLORA_WAIT_VMCNT((NST - 2) * B_IN);", "else CLORA_WAIT_VMCNT((NST - 1) * B_IN);"),
+    # eight-phase GEMM: the K-tile's one counted wait leaves four half-tiles in flight instead of three -> A1 of the next K-tile is read early
+    ("CLORA_WAIT_VMCNT(kInFlight8p);", "CLORA_WAIT_VMCNT(kInFlight8p + 2);"),
 ]
 CASES = {
     "gemm_ring": lambda: KC.case_gemm_plain("cpu", 150, 72, 104, 1, tile_cfg=21),
     "patch_weights": lambda: KC.case_conv_patch("cpu", 2, 8, 8, 128, 64, 72),
+    "gemm_8phase": lambda: KC.case_gemm_plain("cpu", 150, 72, 424, 1, tile_cfg=59),
 }
 
 

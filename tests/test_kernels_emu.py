@@ -33,7 +33,7 @@ def test_conv_small_channels():
     KC.case_conv("cpu", 1, 16, 16, 8, 32)       # hint-encoder conv_in shape class (3 -> padded 8 channels)
 
 
-ALL_TILE_CFGS = [1, 2, 3, 4, 5, 6, 7, 8, 9, 21, 22, 23, 26, 31, 32, 33, 41, 42, 43, 51, 52, 53, 54, 55, 56, 57, 58]
+ALL_TILE_CFGS = [1, 2, 3, 4, 5, 6, 7, 8, 9, 21, 22, 23, 26, 31, 32, 33, 41, 42, 43, 51, 52, 53, 54, 55, 56, 57, 58, 59]
 
 
 @pytest.mark.parametrize("tile", ALL_TILE_CFGS)
@@ -45,7 +45,14 @@ def test_gemm_tile_configs(tile):
     KC.case_conv("cpu", 1, 8, 8, 16, 24, tile_cfg=tile)
 
 
-@pytest.mark.parametrize("tile", [1, 3, 4, 5, 6, 7, 21, 23, 43, 51, 52, 53, 54, 55, 56, 57, 58])
+@pytest.mark.parametrize("M,N,K,split", [(300, 520, 1096, 1), (513, 256, 640, 2), (256, 264, 64, 1), (40, 1288, 72, 1)])
+def test_gemm_eight_phase_tile(M, N, K, split, zero_latency_dma_param):
+    """tile_cfg 59 (gemm_8p_kernel, 256x256, two wave rows one barrier apart): several tiles, many K-tiles, a ragged K tail,
+    split-K, under both ends of the emulator's DMA latency range"""
+    KC.case_gemm_plain("cpu", M, N, K, split, tile_cfg=59)
+
+
+@pytest.mark.parametrize("tile", [1, 3, 4, 5, 6, 7, 21, 23, 43, 51, 52, 53, 54, 55, 56, 57, 58, 59])
 def test_gemm_epilogue_without_rowadd(tile):
     """projection epilogues (adapter / bias / residual, no row add): the two-phase chunk loop of the 8-wave tiles, ragged M and N"""
     KC.case_gemm_epilogue_no_rowadd("cpu", M=300, N=320, K_=128, tile_cfg=tile)
@@ -146,6 +153,14 @@ def test_attention(B, H, Nq, Nk, D, fused):
     KC.case_attention("cpu", B, H, Nq, Nk, D, fused_qkv=fused)
 
 
+@pytest.fixture(params=[0, 1], ids=["late_dma", "eager_dma"])
+def zero_latency_dma_param(request):
+    from tests.emu_fixture import emu_lib
+    emu_lib().cdll.hipemu_set_dma_eager(request.param)
+    yield
+    emu_lib().cdll.hipemu_set_dma_eager(0)
+
+
 @pytest.fixture
 def zero_latency_dma():
     """LDS-DMA copies land at issue instead of at the covering wait (tests/hipemu/hipemu.cpp): the other end of the latency
@@ -156,7 +171,7 @@ def zero_latency_dma():
     emu_lib().cdll.hipemu_set_dma_eager(0)
 
 
-@pytest.mark.parametrize("tile", [21, 33, 43, 53, 57])
+@pytest.mark.parametrize("tile", [21, 33, 43, 53, 57, 59])
 def test_gemm_rings_zero_latency_dma(tile, zero_latency_dma):
     KC.case_gemm_plain("cpu", 70, 136, 424, 3, tile_cfg=tile)
     KC.case_gemm_epilogue("cpu", split_k=1, tile_cfg=tile)

@@ -42,7 +42,7 @@ def test_conv_small_channels():
     KC.case_conv(DEV, 1, 64, 64, 8, 32)
 
 
-ALL_TILE_CFGS = [1, 2, 3, 4, 5, 6, 7, 8, 9, 21, 22, 23, 26, 31, 32, 33, 41, 42, 43, 51, 52, 53, 54, 55, 56, 57, 58]
+ALL_TILE_CFGS = [1, 2, 3, 4, 5, 6, 7, 8, 9, 21, 22, 23, 26, 31, 32, 33, 41, 42, 43, 51, 52, 53, 54, 55, 56, 57, 58, 59]
 
 
 @pytest.mark.parametrize("tile", ALL_TILE_CFGS)
@@ -55,7 +55,28 @@ def test_gemm_tile_configs(tile):
     KC.case_conv(DEV, 1, 32, 32, 320, 320, tile_cfg=tile)          # Cin % 64 == 0: the BK = 64 variants take the fast tap walk
 
 
-@pytest.mark.parametrize("tile", [71, 72, 73, 74, 75, 76])      # 79 (256x160, built at the end of round 4) joins once it has run on hardware
+@pytest.mark.parametrize("M,N,K,split", [(4096, 2560, 320, 1), (1000, 520, 1096, 2), (16384, 1280, 320, 1), (513, 264, 8200, 1), (2048, 2048, 2048, 1)])
+def test_gemm_eight_phase_tile(M, N, K, split):
+    """tile_cfg 59 (gemm_8p_kernel: 256x256 tile, two wave rows one barrier apart, half-tile LDS-DMA seven ahead): the level-0
+    FeedForward shapes, ragged M / N / K tail, split-K, a long K; elementwise outlier guard and repeat-launch bit equality inside
+    the case (a rare early read of a staged buffer would show as a few wrong tiles)"""
+    import math
+    import torch
+    from controllora_amd import kernels as K_
+    g = torch.Generator().manual_seed(M + K)
+    A, B = KC.rnd((M, K), DEV, g), KC.rnd((N, K), DEV, g, 1 / math.sqrt(K))
+    ref = A.float() @ B.float().T
+    first = None
+    for _ in range(4):
+        out = K_.gemm(A, B, M, N, K, split_k=split, tile_cfg=59, _tuned=False)
+        assert KC.rel(out, ref) < 6e-4
+        KC.no_outliers(out, ref)
+        if first is None:
+            first = out.clone()
+        assert torch.equal(out, first)
+
+
+@pytest.mark.parametrize("tile", [71, 72, 73, 74, 75, 76, 79])  # 79 = 256x160 (64x80 wave tiles, all 160 KB of LDS): first hardware run in round 5
 @pytest.mark.parametrize("Bn,H,W,Ci,Co", [(4, 64, 64, 320, 320), (4, 32, 32, 640, 640), (2, 16, 16, 1280, 640), (4, 8, 8, 1280, 1280),
                                           (1, 32, 32, 320, 320), (3, 8, 8, 128, 72)])
 def test_conv_patch_kernel(tile, Bn, H, W, Ci, Co):

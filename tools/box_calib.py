@@ -9,6 +9,7 @@ import torch
 import gemm_pilot as GP
 from controllora_amd import kernels as K
 
+K.set_tile_order("auto")          # the order every earlier calibration file was taken under (the library default is "grid" since round 5)
 A, Bw, out, res, cd = GP.operands(8192, 8192, 8192, 0, 0)
 us = GP.timeit(lambda: K.gemm(A, Bw, 8192, 8192, 8192, out=out, split_k=1, tile_cfg=1, _tuned=False), iters=4)
 x = torch.empty(128 << 20, dtype=torch.float16, device="cuda")
