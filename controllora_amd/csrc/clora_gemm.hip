@@ -1933,6 +1933,9 @@ extern "C" int clora_gemm_f16_ex(const clora_half* A, int lda, const clora_half*
             return rc;
         }
     }
+    // (round 5, measured and removed: conv3x3_patch_kernel with its two wave halves one barrier apart -- the ping-pong schedule of
+    // gemm_8p_kernel, cfgs 84 / 86 / 89 at the time: parity green on hardware, 128x160 +0.5..1.5 % (noise level), the 256-row tiles
+    // 25-60 % slower (spills); the lockstep tap loop is NOT what holds the patch convs at 43 % MFMA busy: profiles/r05_patch_pingpong_ab.txt)
     //   59 = gemm_8p_kernel: 256x256, 8 waves of 128x64, eight-phase ping-pong (plain GEMM rows only; convs fall back to 58)
     if (cfg == 59 && (a.conv.enabled || !dma)) cfg = 58;
     const int bk = ((cfg >= 21 && cfg <= 26) || (cfg >= 41 && cfg <= 43) || (cfg >= 51 && cfg <= 59) || (cfg >= 91 && cfg <= 96)) ? 64 : 32;

@@ -25,7 +25,12 @@ def main():
                 for p in clora.parameters():
                     p.add_(0.01 * rank)
         trainer = ControlLoRATrainer(unet, clora, init_scale=128.0, dynamic_scale=False, process_group=dist.group.WORLD,
-                                     world_size=world)
+                                     world_size=world, comm=os.environ.get("CLORA_DIST_COMM") or None)
+        # the default ("auto") picks torch.distributed on a gloo group without comment; a REQUESTED "clora" cannot run here (no RCCL
+        # behind gloo) and must say so instead of silently switching
+        want = os.environ.get("CLORA_DIST_COMM") or "auto"
+        assert trainer.comm == "torch" and trainer.comm_requested == want
+        assert (trainer.comm_fallback is not None) == (want == "clora"), trainer.comm_fallback
         full = cases.seeded_inputs(batch=world)
         sl = slice(rank, rank + 1)           # rank r gets sample r of the global batch of `world`
         noisy = unet_ref.DDPMSchedule().add_noise(full["latents"], full["noise"], full["timesteps"])

@@ -19,7 +19,9 @@ def _run(extra, env_extra=None):
     assert r.returncode == 0, out
     lines = [l for l in out.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out                  # ONE line, from rank 0
-    return json.loads(lines[0])
+    line = json.loads(lines[0])
+    line["_output"] = out
+    return line
 
 
 def test_gpus_flag_spawns_that_many_ranks():
@@ -31,3 +33,14 @@ def test_gpus_flag_spawns_that_many_ranks():
 def test_single_rank_does_not_spawn():
     line = _run(["--gpus", "1"])
     assert line["n_gpus"] == 1
+
+
+def test_requested_clora_exchange_falls_back_loudly_without_rccl():
+    """`--comm clora` on a process group with no RCCL behind it (gloo) must not be silently replaced: the
+    line says which path ran, which was asked for and why, and a warning goes to stderr"""
+    line = _run(["--gpus", "2", "--comm", "clora"])
+    assert line["n_gpus"] == 2 and line["allreduce_ok"] is True
+    assert line["comm"] == "torch" and line["comm_requested"] == "clora" and "no RCCL" in line["comm_fallback"]
+    assert "WARNING" in line["_output"] and "clora" in line["_output"]
+    quiet = _run(["--gpus", "2"])
+    assert quiet["comm_requested"] == "auto" and quiet["comm_fallback"] is None and "WARNING" not in quiet["_output"]
