@@ -142,8 +142,44 @@ def oracle_ddim(o_unet, o_clora, guide, cond, uncond, steps, guidance_scale, lat
     return x, traj
 
 
+@torch.no_grad()
+def oracle_dpm(o_unet, o_clora, guide, cond, uncond, steps, guidance_scale, latents):
+    """The reference's validation-time / app sampling loop (train_text_to_image_control_lora.py:811-843, apps/gradio_*2image.py:
+    `DPMSolverMultistepScheduler.from_config`, 30 steps, CFG) restated independently of controllora_amd/schedulers.py: DPM-Solver++(2M)
+    in the PAPER's form (Lu et al. 2022, Algorithm 2): with lambda = log(alpha / sigma), h = lambda_t - lambda_s, r = h_prev / h,
+        x_t = (sigma_t / sigma_s) x_s - alpha_t (e^{-h} - 1) D,   D = (1 + 1/(2r)) x0_s - (1/(2r)) x0_prev   (first step: D = x0_s),
+    SD's scaled-linear betas, upstream's timestep grid (linspace(0, 999, n + 1) rounded, reversed, last dropped), the last step goes
+    to t = 0; `lower_order_final` (first order on the last step) only below 15 steps.  fp64 coefficients, fp32 state."""
+    betas = torch.linspace(0.00085 ** 0.5, 0.012 ** 0.5, 1000, dtype=torch.float64) ** 2
+    acp = torch.cumprod(1.0 - betas, 0)
+    alpha, sigma = acp.sqrt(), (1.0 - acp).sqrt()
+    lam = torch.log(alpha) - torch.log(sigma)
+    ts = [int(t) for t in torch.linspace(0, 999, steps + 1).round().long().flip(0)[:-1]]
+    o_clora(guide)
+    ehs = torch.cat([uncond, cond], 0)
+    x = latents.clone()
+    x0_prev, lam_prev = None, None
+    for i, t in enumerate(ts):
+        eps = o_unet(torch.cat([x, x], 0), t, ehs).sample
+        eu, ec = eps.chunk(2)
+        eps = eu + guidance_scale * (ec - eu)
+        t_next = ts[i + 1] if i + 1 < len(ts) else 0
+        x0 = (x - float(sigma[t]) * eps) / float(alpha[t])
+        h = float(lam[t_next] - lam[t])
+        first = x0_prev is None or (steps < 15 and i == len(ts) - 1)
+        if first:
+            D = x0
+        else:
+            r = float(lam[t] - lam_prev) / h
+            D = (1.0 + 0.5 / r) * x0 - (0.5 / r) * x0_prev
+        import math
+        x = float(sigma[t_next] / sigma[t]) * x - float(alpha[t_next]) * math.expm1(-h) * D
+        x0_prev, lam_prev = x0, lam[t]
+    return x, None
+
+
 def ddim_parity(o_unet, o_clora, p_unet, p_clora, dev, res, steps, guidance_scale=9.0, nb=1, ctx_dim=768, ctx_len=77, seed=5,
-                graph=False, fp16_floor=False):
+                graph=False, fp16_floor=False, sampler="ddim"):
     """denoised-latent parity: product `pipeline.ddim_sample` vs the oracle loop; rel-L2 of the final latents (the
     quantity north_star states 1e-3 for) and of the per-step trajectory."""
     from controllora_amd.pipeline import ddim_sample
@@ -153,17 +189,18 @@ def ddim_parity(o_unet, o_clora, p_unet, p_clora, dev, res, steps, guidance_scal
     cond = torch.randn(nb, ctx_len, ctx_dim, generator=g).half().float()
     uncond = torch.randn(nb, ctx_len, ctx_dim, generator=g).half().float()
     lat0 = torch.randn(nb, 4, L, L, generator=g).half().float()
-    ref, traj = oracle_ddim(o_unet, o_clora, guide, cond, uncond, steps, guidance_scale, lat0)
+    loop = oracle_ddim if sampler == "ddim" else oracle_dpm
+    ref, traj = loop(o_unet, o_clora, guide, cond, uncond, steps, guidance_scale, lat0)
     floor = None
     if fp16_floor:
-        floor = fp16_oracle_floor(o_unet, o_clora, guide, cond, uncond, steps, guidance_scale, lat0, ref)
+        floor = fp16_oracle_floor(o_unet, o_clora, guide, cond, uncond, steps, guidance_scale, lat0, ref, loop=loop)
     kw = dict(graph=True) if graph else {}
     out = ddim_sample(p_unet, p_clora, guide.to(dev).half(), cond.to(dev).half(), uncond.to(dev).half(), steps=steps,
-                      guidance_scale=guidance_scale, latents=lat0.to(dev).half(), **kw)
+                      guidance_scale=guidance_scale, latents=lat0.to(dev).half(), sampler=sampler, **kw)
     return {"latents": rel(out, ref), "steps": steps, "latent_norm": float(ref.norm()), "fp16_oracle_vs_fp32_oracle": floor}
 
 
-def fp16_oracle_floor(o_unet, o_clora, guide, cond, uncond, steps, guidance_scale, lat0, ref):
+def fp16_oracle_floor(o_unet, o_clora, guide, cond, uncond, steps, guidance_scale, lat0, ref, loop=None):
     """What "fp16" costs ANY implementation: the same oracle loop with every module and tensor in fp16 (the arithmetic
     regime of the reference's own fp16 pipeline: fp16 storage of weights / activations / latents) against the fp32 oracle.
     north_star's "within 1e-3 rel fp16" is read against this floor (SURVEY.md section 8c "Tolerance reading")."""
@@ -171,7 +208,7 @@ def fp16_oracle_floor(o_unet, o_clora, guide, cond, uncond, steps, guidance_scal
     from oracle.controllora_ref import map_processors_to_unet as omap
     h_unet, h_clora = copy.deepcopy(o_unet).half(), copy.deepcopy(o_clora).half()
     h_unet.set_attn_processor(omap(h_unet, h_clora))
-    out, _ = oracle_ddim(h_unet, h_clora, guide.half(), cond.half(), uncond.half(), steps, guidance_scale, lat0.half())
+    out, _ = (loop or oracle_ddim)(h_unet, h_clora, guide.half(), cond.half(), uncond.half(), steps, guidance_scale, lat0.half())
     return rel(out, ref)
 
 

@@ -303,3 +303,24 @@ def test_lora_proj_counts_a_precomputed_second_input_once(M, fuse, monkeypatch):
     rel = lambda a, b: float((a.float() - b).norm() / b.norm())
     assert rel(ref, want) < 2e-3
     assert rel(got, want) < 2e-3, rel(got, want)                       # 0.35 with the double count
+
+
+@pytest.mark.parametrize("steps", [4, 16])
+def test_dpm_solver_sampling_loop_matches_an_independent_restatement(steps):
+    """reference train_text_to_image_control_lora.py:811-843 / the apps' `DPMSolverMultistepScheduler`: the product loop
+    (`ddim_sample(sampler="dpm")`: CFG batch, uncond first, scheduler state in fp32) against tests/full_cases.oracle_dpm -- the
+    DPM-Solver++(2M) update restated from the paper's form around the fp32 oracle UNet.  4 steps: first-order start, one
+    second-order step, `lower_order_final`; 16 steps: second order to the end.  Kernels emulated."""
+    from oracle import cases
+    from tests import full_cases as F
+    from tests.emu_fixture import use_emulator
+    o_unet, _, o_clora = cases.build_oracle_case("v1")
+    p_unet, _, p_clora = E.build_product_case("v1", "cpu")
+    with torch.no_grad():
+        for p in o_unet.parameters():
+            p.copy_(p.half().float())
+    with use_emulator():
+        r = F.ddim_parity(o_unet, o_clora, p_unet, p_clora, "cpu", res=64, steps=steps, guidance_scale=7.5, nb=1, ctx_dim=64, ctx_len=7,
+                          sampler="dpm")
+    print("DPM_LOOP_PARITY emu", steps, r)
+    assert r["latents"] < 6e-3, r

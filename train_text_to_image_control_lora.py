@@ -286,7 +286,9 @@ def main(argv=None):
 
 @torch.no_grad()
 def run_validation(args, unet, control_lora, vae, text_encoder, tokenizer, dataset, dev, global_step):
-    """sampling with the current adapters (reference :806-860): DDIM 30 steps, CFG 7.5, [sample | target | guide] strips"""
+    """sampling with the current adapters (reference :811-860): DPM-Solver++(2M) like the reference's
+    `DPMSolverMultistepScheduler.from_config(...)` (:824), 30 steps (:842), the pipeline's default guidance 7.5,
+    [sample | target | guide] strips (`dataset_cls.cat_input`, :843)"""
     from PIL import Image
     import numpy as np
     from controllora_amd.pipeline import ddim_sample
@@ -298,7 +300,7 @@ def run_validation(args, unet, control_lora, vae, text_encoder, tokenizer, datas
     for i in range(args.num_validation_images):
         ex = dataset[i % len(dataset)]
         guide = ex["guide_values"][None].to(dev).half()
-        lat = ddim_sample(unet, control_lora, guide, cond, uncond, steps=30, guidance_scale=7.5, generator=gen)
+        lat = ddim_sample(unet, control_lora, guide, cond, uncond, steps=30, guidance_scale=7.5, generator=gen, sampler="dpm")
         img = vae.decode(lat.half() / vae.scaling_factor).sample.float().clamp(-1, 1)
         strip = torch.cat([img[0].cpu(), ex["pixel_values"], ex["guide_values"]], dim=2)
         arr = ((strip.permute(1, 2, 0).numpy() + 1.0) * 127.5).round().astype(np.uint8)
