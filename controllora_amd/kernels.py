@@ -560,6 +560,23 @@ def lora_wgrad(A, T, toff, G, gs_n, gs_j, M, N, R, scale=1.0, a_rows=0, lda=None
     return G
 
 
+def wgrad_accumulate(dY: torch.Tensor, X: torch.Tensor, M: int, N: int, K: int, G: torch.Tensor):
+    """G[N, K] (fp32, contiguous) += dY[M, N]^T . X[M, K] on the MFMA weight-gradient kernel (clora_conv_wgrad_f16, plain rows): the
+    weight gradient of a WIDE-rank adapter (rank > 16: danbooru-sketch's 256), whose matrices are GEMM-sized"""
+    assert G.dtype == f32 and G.is_contiguous() and G.shape == (N, K) and dY.dtype == f16 and X.dtype == f16
+    assert dY.stride(1) == 1 and X.stride(1) == 1
+    _call("clora_conv_wgrad_f16", ptr(dY, f16), dY.stride(0), ptr(X, f16), X.stride(0), ptr(G), None, M, N, K, None, 0,
+          flops=2.0 * M * N * K)
+
+
+def to_f16(x: torch.Tensor) -> torch.Tensor:
+    """fp32 master weight -> the fp16 GEMM operand of this step"""
+    assert x.dtype == f32 and x.is_contiguous()
+    y = torch.empty(x.shape, dtype=f16, device=x.device)
+    _call("clora_cast_f32_to_f16", ptr(x), ptr(y), x.numel())
+    return y
+
+
 # ------------------------------------------------------------------ elementwise / movement
 def add(a, b):
     y = torch.empty_like(a)

@@ -868,7 +868,72 @@ class _ControlAddFn(torch.autograd.Function):
         return dh, dctrl, None, None, None, None, None
 
 
+class _ControlAddWideFn(torch.autograd.Function):
+    """_ControlAddFn for WIDE ranks (> 16: configs/danbooru-sketch.json trains rank-256 control adapters on cat(h, ctrl), reference
+    models.py:209-218): at that size `to_control` is two ordinary Linear layers ([M, C + Cc] x [C + Cc, 256] and [M, 256] x [256, C]),
+    so every contraction runs on the MFMA GEMM / weight-gradient kernels with fp16 operands cast from the fp32 master weights each
+    call (the rank-r kernels walk the rank 16 columns at a time: 528 us per expand and 96 weight-gradient launches per site at
+    level 0 -- 138.7 ms per train step under danbooru-sketch.json, profiles/r05_bench_sketch.json).  Arithmetic = the reference's
+    fp16 path: cat -> Linear (fp16 T) -> Linear -> x scale -> + h; the scale is folded into the up operand (exact for scale = 1)."""
+
+    @staticmethod
+    def forward(ctx, h, ctrl, D, U, scale, concat):
+        M, C_ = h.shape
+        Mc, Cc = ctrl.shape
+        R = D.shape[0]
+        cm = ctrl if Mc == M else ctrl.repeat(M // Mc, 1)                # control batch 1 broadcast over the batch (quirk C6)
+        X = K.concat_channels(h, cm) if concat else cm.contiguous()
+        Kin = X.shape[1]
+        D16 = K.to_f16(D.detach().contiguous())                           # [R, Kin]
+        Us = U.detach() if scale == 1.0 else U.detach() * scale
+        U16 = K.to_f16(Us.contiguous())                                   # [C, R]
+        T = K.gemm(X, D16, M, R, Kin)                                     # [M, R] fp16
+        y = K.gemm(T, U16, M, C_, R, residual=h)
+        ctx.save_for_backward(h, ctrl, T)
+        ctx.params, ctx.cfg = (D, U), (scale, concat)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        h, ctrl, T = ctx.saved_tensors
+        D, U = ctx.params
+        scale, concat = ctx.cfg
+        M, C_ = h.shape
+        Mc, Cc = ctrl.shape
+        R = D.shape[0]
+        Us = U.detach() if scale == 1.0 else U.detach() * scale
+        UsT16 = K.to_f16(Us.t().contiguous())                             # [R, C]: dT = dy . (s U)
+        dT = K.gemm(dy, UsT16, M, R, C_)                                  # [M, R] fp16
+        if U.requires_grad:
+            if scale == 1.0:
+                K.wgrad_accumulate(dy, T, M, C_, R, _grad_buffer(U))      # dU += dy^T . T
+            else:
+                g = torch.zeros_like(U, dtype=f32)
+                K.wgrad_accumulate(dy, T, M, C_, R, g)
+                _grad_buffer(U).add_(g, alpha=scale)
+        cm = ctrl if Mc == M else ctrl.repeat(M // Mc, 1)
+        X = K.concat_channels(h, cm) if concat else cm.contiguous()
+        Kin = X.shape[1]
+        if D.requires_grad:
+            K.wgrad_accumulate(dT, X, M, R, Kin, _grad_buffer(D))         # dD += dT^T . cat(h, ctrl)
+        Dt16 = K.to_f16(D.detach().t().contiguous())                      # [Kin, R]
+        dh, dctrl = dy, None
+        if concat:
+            dh = K.gemm(dT, Dt16[:C_], M, C_, R, residual=dy)             # dh = dy + dT . D[:, :C]
+        if ctx.needs_input_grad[1]:
+            dctrl = K.gemm(dT, Dt16[C_:] if concat else Dt16, M, Cc, R)
+            if Mc != M:
+                dctrl = dctrl.reshape(M // Mc, Mc, Cc).float().sum(0).to(f16)
+        return dh, dctrl, None, None, None, None
+
+
+WIDE_RANK = _os.environ.get("CLORA_WIDE_RANK", "1") != "0"      # "0": rank > 16 adapters stay on the rank-r kernels (A/B)
+
+
 def control_add(h, ctrl, D, U, scale, concat, t_ctrl=None):
+    if WIDE_RANK and D.shape[0] > 16 and t_ctrl is None and D.shape[0] % 8 == 0 and D.shape[1] % 8 == 0 and h.shape[0] % ctrl.shape[0] == 0:
+        return _ControlAddWideFn.apply(h, ctrl, D, U, float(scale), bool(concat))
     return _ControlAddFn.apply(h, ctrl, D, U, float(scale), bool(concat), t_ctrl)
 
 

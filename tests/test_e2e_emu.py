@@ -324,3 +324,48 @@ def test_dpm_solver_sampling_loop_matches_an_independent_restatement(steps):
                           sampler="dpm")
     print("DPM_LOOP_PARITY emu", steps, r)
     assert r["latents"] < 6e-3, r
+
+
+@pytest.mark.parametrize("concat,Mc,scale", [(True, 96, 1.0), (True, 48, 1.0), (False, 96, 0.5)])
+def test_wide_rank_control_adapter_on_the_gemm_kernels(concat, Mc, scale, monkeypatch):
+    """configs/danbooru-sketch.json's rank-256 `to_control` (reference models.py:209-218) runs as two Linear layers on the MFMA GEMM /
+    weight-gradient kernels (ops._ControlAddWideFn) instead of the rank-r kernels: output, d(h), d(ctrl) and both weight gradients
+    against torch autograd of the reference formula in fp32, and against the rank-r path (ops._ControlAddFn) -- rank 32, with and
+    without cat(h, ctrl), control batch broadcast (Mc < M), scale != 1."""
+    from controllora_amd import ops
+    from tests.emu_fixture import use_emulator
+    g = torch.Generator().manual_seed(11)
+    M, C_, Cc, R = 96, 64, 32, 32
+    h = (torch.randn(M, C_, generator=g) * 0.5).half()
+    ctrl = (torch.randn(Mc, Cc, generator=g) * 0.5).half()
+    Kin = C_ + Cc if concat else Cc
+    dy = (torch.randn(M, C_, generator=g) * 0.1).half()
+
+    def run(wide):
+        monkeypatch.setattr(ops, "WIDE_RANK", wide)
+        D = torch.nn.Parameter(torch.randn(R, Kin, generator=torch.Generator().manual_seed(1)) / Kin ** 0.5)
+        U = torch.nn.Parameter(torch.randn(C_, R, generator=torch.Generator().manual_seed(2)) * 0.2)
+        hh, cc = h.clone().requires_grad_(True), ctrl.clone().requires_grad_(True)
+        with use_emulator():
+            y = ops.control_add(hh, cc, D, U, scale, concat)
+            y.backward(dy)
+        return y.detach().float(), hh.grad.float(), cc.grad.float(), D.grad.clone(), U.grad.clone()
+
+    D = torch.randn(R, Kin, generator=torch.Generator().manual_seed(1)) / Kin ** 0.5
+    U = torch.randn(C_, R, generator=torch.Generator().manual_seed(2)) * 0.2
+    D.requires_grad_(True); U.requires_grad_(True)
+    hf, cf = h.float().requires_grad_(True), ctrl.float().requires_grad_(True)
+    cm = cf.repeat(M // Mc, 1)
+    x = torch.cat([hf, cm], 1) if concat else cm
+    yref = hf + scale * ((x @ D.t()) @ U.t())
+    yref.backward(dy.float())
+    ref = (yref.detach(), hf.grad, cf.grad, D.grad, U.grad)
+    rel = lambda a, b: float((a - b).norm() / b.norm())
+    wide, narrow = run(True), run(False)
+    names = ("y", "dh", "dctrl", "dD", "dU")
+    errs_w = {n: rel(a, b) for n, a, b in zip(names, wide, ref)}
+    errs_n = {n: rel(a, b) for n, a, b in zip(names, narrow, ref)}
+    print("WIDE_RANK", errs_w, "rank-r path", errs_n)
+    for n in names:
+        assert errs_w[n] < 1e-3, (n, errs_w)                 # fp16 T / dT between the two GEMMs, as in the reference's fp16 path
+        assert errs_n[n] < 1e-3, (n, errs_n)
