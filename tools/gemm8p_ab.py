@@ -7,6 +7,19 @@ import torch
 from controllora_amd import kernels as K
 dev = torch.device("cuda", 0)
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+if "--pmc" in sys.argv:
+    # counter collection (rocprofv3 --pmc ... -- python tools/gemm8p_ab.py 1 --pmc): a few eager launches of the calibration GEMM per tile
+    import math as _m
+    for n in (8192, 4096):
+        g_ = torch.Generator(device=dev).manual_seed(1)
+        A = (torch.rand(n, n, device=dev, generator=g_) - 0.5).half()
+        Bw = ((torch.rand(n, n, device=dev, generator=g_) - 0.5) * (2.0 / _m.sqrt(n))).half()
+        out = torch.empty(n, n, device=dev, dtype=torch.float16)
+        for c in (1, 56, 58, 59):
+            for _ in range(3):
+                K.gemm(A, Bw, n, n, n, out=out, split_k=1, tile_cfg=c, _tuned=False)
+        torch.cuda.synchronize()
+    sys.exit(0)
 
 def graph_of(fn, iters):
     for _ in range(2): fn()
