@@ -176,7 +176,7 @@ def box_calibration(dev):
     (the driver's box ran every kernel 5-28 % slower than the builder's and nothing in the line said why):
       * gemm8192_cfg1_us -- the 8192^3 fp16 GEMM on tile_cfg 1 (128x128 BK32: a kernel whose code has not changed since round 1;
         tools/box_calib.py and every profiles/r0N_box_calib*.txt use the same one) under tile_order "auto", random operands,
-        best of 3 pairs of launches
+        best of 3 pairs of launches; gemm8192_cfg59_* -- the same GEMM on the eight-phase tile (gemm_8p_kernel)
       * copy256MB_GBps -- a 256 MB device copy (read + write bytes)
       * mfma_clock_MHz / mfma_probe_TFLOPs -- clora_clock_probe: shader cycles vs the 100 MHz wall clock around a dense MFMA stream on
         pseudo-random operands: the clock the chip holds under matrix load (DVFS), and the dense rate that goes with it
@@ -192,16 +192,29 @@ def box_calibration(dev):
         C_ = torch.empty(n, n, device=dev, dtype=torch.float16)
         run = lambda: K.gemm(A, B, n, n, n, out=C_, split_k=1, tile_cfg=1, _tuned=False)
         K.set_tile_order("auto")               # the order every profiles/r0N_box_calib*.txt was taken under (the library's default, "grid",
-        run(); torch.cuda.synchronize()        # runs this very GEMM 6 % faster: 1515 vs 1615 us on one box, profiles/r05_ab_lib_382a909_vs_head.txt)
-        best = None
-        for _ in range(3):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(); run(); run(); e1.record(); torch.cuda.synchronize()
-            us = e0.elapsed_time(e1) * 1e3 / 2
-            best = us if best is None else min(best, us)
-        K.set_tile_order(K.DEFAULT_TILE_ORDER)
+        try:                                   # runs this very GEMM 6 % faster: 1515 vs 1615 us on one box, profiles/r05_ab_lib_382a909_vs_head.txt)
+            run(); torch.cuda.synchronize()
+            best = None
+            for _ in range(3):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(); run(); run(); e1.record(); torch.cuda.synchronize()
+                us = e0.elapsed_time(e1) * 1e3 / 2
+                best = us if best is None else min(best, us)
+        finally:
+            K.set_tile_order(K.DEFAULT_TILE_ORDER)
         out["gemm8192_cfg1_us"] = round(best, 1)
         out["gemm8192_cfg1_TFLOPs"] = round(2 * n ** 3 / best / 1e6, 1)
+        # the same GEMM on the eight-phase 256x256 tile (tile_cfg 59, default tile order): what the GEMM core reaches on this box
+        run59 = lambda: K.gemm(A, B, n, n, n, out=C_, split_k=1, tile_cfg=59, _tuned=False)
+        run59(); torch.cuda.synchronize()
+        best59 = None
+        for _ in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); run59(); run59(); e1.record(); torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 1e3 / 2
+            best59 = us if best59 is None else min(best59, us)
+        out["gemm8192_cfg59_us"] = round(best59, 1)
+        out["gemm8192_cfg59_TFLOPs"] = round(2 * n ** 3 / best59 / 1e6, 1)
         del A, B, C_
         x = torch.empty(128 << 20, dtype=torch.float16, device=dev)
         y = torch.empty_like(x)

@@ -115,11 +115,20 @@ class ControlLoRATrainer:
         if world_size > 1:
             torch.distributed.broadcast(self.flat.data, src=0, group=process_group)   # identical adapter init
         if self.comm == "clora":
-            err = None
-            try:
-                self._init_clora_comm(process_group, world_size)
-            except Exception as e:                                   # noqa: BLE001 -- decided collectively below
-                err = repr(e)
+            # (1) can EVERY rank load librccl through the C ABI?  ncclCommInitRank is a collective: a rank that cannot even open the
+            # library must be found BEFORE the others enter it, or they would wait for it forever
+            err = None if self.comm_library(force=True) else "librccl could not be opened through the C ABI (clora_comm_library)"
+            if world_size > 1:
+                flag = torch.tensor([int(err is not None)], dtype=torch.int32, device=dev)
+                torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX, group=process_group)
+                if int(flag.item()) and err is None:
+                    err = "another rank could not open librccl through the C ABI"
+            # (2) the collective communicator creation, (3) agreed on by all ranks below
+            if err is None:
+                try:
+                    self._init_clora_comm(process_group, world_size)
+                except Exception as e:                               # noqa: BLE001 -- decided collectively below
+                    err = repr(e)
             bad = int(err is not None)
             if world_size > 1:                                       # every rank must take the same exchange path
                 flag = torch.tensor([bad], dtype=torch.int32, device=dev)
@@ -139,9 +148,9 @@ class ControlLoRATrainer:
             print(f"[controllora_amd] WARNING: exchange path 'clora' unavailable, using torch.distributed instead: {self.comm_fallback}",
                   file=_sys.stderr, flush=True)
 
-    def comm_library(self):
+    def comm_library(self, force=False):
         """path of the librccl whose ncclAllReduce the exchange step calls (C-ABI path: dladdr of the bound symbol)"""
-        if self.comm != "clora":
+        if self.comm != "clora" and not force:
             return None
         import ctypes
         from . import capi
