@@ -170,3 +170,32 @@ def test_canny_annotator_and_app_helpers():
     assert app.canny(weak, 100, 200).sum() == 0
     assert app.resize_image(np.zeros((100, 150, 3), np.uint8), 128).shape == (128, 192, 3)
     assert app.hwc3(np.zeros((4, 4), np.uint8)).shape == (4, 4, 3)
+
+
+@pytest.mark.gpu
+def test_validation_after_graph_replayed_steps_sees_the_current_adapters(tmp_path):
+    """ADVICE r04 (stale adapter packs), end to end through the entry point: `run_validation` (reference train...:811-843, 30-step
+    DPM-Solver++) samples at the CFG batch, whose projections register NEW fused-adapter pack groups after the train step's
+    optimizer graph was captured; the flat AdamW of the following replayed steps changes the weights without bumping a parameter
+    version, so the next validation would mix stale down matrices with fresh up matrices unless step_graphed repacks.  The hipGraph
+    run and the eager run (which repacks every group every step) must paint the same validation strips at both checkpoints."""
+    import numpy as np
+    from PIL import Image
+    from oracle import cases
+    cfg = tmp_path / "small.json"
+    cfg.write_text(json.dumps({k: (list(v) if isinstance(v, tuple) else v) for k, v in cases.SMALL_CLORA_V1.items()}))
+    imgs = {}
+    for mode, extra in (("graph", []), ("eager", ["--no_hipgraph"])):
+        out = tmp_path / mode
+        args = ["--pretrained_model_name_or_path", "random:small", "--dataset_name", "synthetic:fill50k", "--control_lora_config", str(cfg),
+                "--output_dir", str(out), "--resolution", "64", "--train_batch_size", "2", "--max_train_samples", "16", "--seed", "3",
+                "--mixed_precision", "fp16", "--checkpointing_steps", "3", "--learning_rate", "1e-2", "--max_train_steps", "6",
+                "--validation_prompt", "red circle with blue background", "--num_validation_images", "1"] + extra
+        assert T.main(args) == 6
+        files = sorted(os.listdir(out / "validation"))
+        assert len(files) == 2, files
+        imgs[mode] = [np.asarray(Image.open(out / "validation" / f)).astype(np.int32) for f in files]
+    for a, b in zip(imgs["graph"], imgs["eager"]):
+        assert a.shape == b.shape
+        assert np.abs(a - b).max() <= 2, int(np.abs(a - b).max())          # uint8 strips: identical up to a rounding of the fp16 path
+    assert np.abs(imgs["graph"][0] - imgs["graph"][1]).max() > 2           # and the adapters DID move between the two checkpoints
