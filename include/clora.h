@@ -129,6 +129,8 @@ int clora_gemm_f16(const clora_half* A, int lda, const clora_half* B, clora_half
  *   21, 22, 23, 26  BK 64 (128-byte LDS rows): 128x128 x2 stages, 128x64 x3, 64x64 x3, 128x64 x2
  *   31-33 = 1-3 and 41-43 = 21-23 with the fragment reads before the ring refill
  *   51-58 8-wave blocks (one per CU), BK 64: 128x320, 64x320, 128x256 (54-56: fragment-first), 256x320, 256x256
+ *   59    gemm_8p_kernel: 256x256, 8 waves of 128x64, eight-phase ping-pong schedule (the two wave rows one barrier apart, 16-KB
+ *         half-tiles by LDS-DMA seven ahead, one counted wait per K-tile); plain GEMM rows only -- a conv falls back to 58
  *   71-76 conv3x3_patch_kernel (3x3 stride-1 pad-1 convs, their dgrads, conv(nearest-2x(x))): 256x128, 128x128 (two wave layouts),
  *         256x64, 128x64, 128x160; 77, 78: 128x128 / 128x64 on a 392-pixel patch (one 128-pixel row or row segment: W = 128 .. 512);
  *         79: 256x160 (64x80 wave tiles, the CU's whole 160 KB of LDS); a shape it cannot take falls back to 21
