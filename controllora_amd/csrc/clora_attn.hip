@@ -154,7 +154,7 @@ constexpr float kRebase = 8.0f;
 // CAUSAL (clora_attn_fwd_causal_f16: the CLIP text encoder's masked self-attention, 77 tokens): key j is visible to query i
 // iff j <= i.  A separate instantiation, so the unmasked kernels of the UNet keep their exact code.
 template <int DP, int DT, bool ONES, int NWV, bool CAUSAL = false>
-__global__ __launch_bounds__(NWV * 64, (DP <= 64 ? (NWV == 4 ? 3 : 2) : 1)) void attn_fwd_kernel(AttnArgs p) {
+__global__ __launch_bounds__(NWV * 64, (DP <= 64 ? (NWV == 16 ? 4 : (NWV == 4 ? 3 : 2)) : 1)) void attn_fwd_kernel(AttnArgs p) {
     constexpr int BKV = 64, LDK = DP + 16, DV = DT * 16, LDV = DV + ((DV % 32) == 16 ? 0 : 16), KS = DP / 32;
     constexpr int TILE = BKV * LDK + BKV * LDV;           // one K tile + one V tile; two of them: double buffer
     __shared__ __attribute__((aligned(16))) half_t smem[2 * TILE];
@@ -662,11 +662,15 @@ __global__ __launch_bounds__(256) void attn_dkv_convert_kernel(AttnArgs p) {
     }
 }
 
+constexpr bool kAttnFwd16 = false;      // the automatic choice of the 16-wave forward block: off until it has been measured
 template <int DP, int DT>
 int launch_fwd(const AttnArgs& a, hipStream_t s) {
     // wider blocks when there are enough queries to keep the grid full (A/B: clora_set_option("attn_fwd_waves", 4 | 6 | 8))
     const int forced = clora_option(CLORA_OPT_ATTN_FWD_WAVES);
     int nw = forced ? forced : ((DP <= 64 && (long)clora_cdiv(a.Nq, 256) * a.B * a.H >= 512) ? 8 : 4);   // measured: 6 waves lose, 8 win 10-18 %
+    // 16 waves = 512 queries per block (half the K/V tile stream per flop again) once even those blocks fill the chip twice over: the
+    // batch-32 sampler's level-0 self-attention (2,048 blocks); "attn_fwd_waves" = 16 forces it (A/B)
+    if (!forced && DP <= 64 && a.Nk >= 1024 && (long)clora_cdiv(a.Nq, 512) * a.B * a.H >= 1024) nw = kAttnFwd16 ? 16 : nw;
     if (DP > 64 && nw != 4) nw = 4;                         // larger head dims keep the 4-wave block (LDS / registers)
     const bool ones = a.D == DT * 16 - 8;
     const dim3 grid(clora_cdiv(a.Nq, nw * 32), a.B * a.H);
@@ -676,7 +680,8 @@ int launch_fwd(const AttnArgs& a, hipStream_t s) {
         else hipLaunchKernelGGL((attn_fwd_kernel<DP, DT, false, NWV>), grid, dim3(NWV * 64), 0, s, a);                \
     } while (0)
     if constexpr (DP <= 64) {
-        if (nw == 8) CLORA_FWD_LAUNCH(8);
+        if (nw == 16) CLORA_FWD_LAUNCH(16);
+        else if (nw == 8) CLORA_FWD_LAUNCH(8);
         else if (nw == 6) CLORA_FWD_LAUNCH(6);
         else CLORA_FWD_LAUNCH(4);
     } else {

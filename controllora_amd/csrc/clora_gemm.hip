@@ -2007,14 +2007,14 @@ extern "C" int clora_set_option(const char* name, int value) {
     if (!name) return CLORA_ERR_ARG;
     struct Opt { const char* name; int id, lo, hi; };
     static const Opt kOpts[] = {{"tile_order", CLORA_OPT_TILE_ORDER, 0, 3}, {"ln_rows", CLORA_OPT_LN_ROWS, 0, 1},
-                                {"attn_fwd_waves", CLORA_OPT_ATTN_FWD_WAVES, 0, 8}, {"attn_bwd_waves", CLORA_OPT_ATTN_BWD_WAVES, 0, 8},
+                                {"attn_fwd_waves", CLORA_OPT_ATTN_FWD_WAVES, 0, 16}, {"attn_bwd_waves", CLORA_OPT_ATTN_BWD_WAVES, 0, 8},
                                 {"gn_blocks", CLORA_OPT_GN_BLOCKS, 64, 1 << 16}, {"epi_two_phase", CLORA_OPT_EPI_TWO_PHASE, 0, 1},
                                 {"lora_down_mode", CLORA_OPT_LORA_DOWN_MODE, 0, 2}, {"gn_unroll", CLORA_OPT_GN_UNROLL, 0, 1},
                                 {"epi_hoist", CLORA_OPT_EPI_HOIST, 0, 1}, {"gn_resident", CLORA_OPT_GN_RESIDENT, 0, 1}};
     for (const Opt& o : kOpts)
         if (!strcmp(name, o.name)) {
             if (value < o.lo || value > o.hi) return CLORA_ERR_ARG;
-            if ((o.id == CLORA_OPT_ATTN_FWD_WAVES && value != 0 && value != 4 && value != 6 && value != 8) ||
+            if ((o.id == CLORA_OPT_ATTN_FWD_WAVES && value != 0 && value != 4 && value != 6 && value != 8 && value != 16) ||
                 (o.id == CLORA_OPT_ATTN_BWD_WAVES && value != 0 && value != 4 && value != 8)) return CLORA_ERR_ARG;
             g_opts[o.id] = value;
             return CLORA_OK;

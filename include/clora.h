@@ -159,7 +159,7 @@ int clora_conv_patch_eligible(int M, const clora_conv_t* conv, int tile_cfg);
  *                     family 1.69x -> 1.59x of its algorithmic bytes, outputs bit-identical to 2).  1, 2 and 3 also give every XCD whole
  *                     attention heads.
  *   "ln_rows"         1 = LayerNorm keeps several rows in flight per wave (default), 0 = one row per wave.
- *   "attn_fwd_waves"  0 = pick by grid size (default), 4 | 6 | 8 = waves per forward attention block (head dims <= 64).
+ *   "attn_fwd_waves"  0 = pick by grid size (default), 4 | 6 | 8 | 16 = waves per forward attention block (head dims <= 64).
  *   "attn_bwd_waves"  0 = pick by grid size (default), 4 | 8 = waves per backward attention block (head dims <= 64).
  *   "gn_blocks"       target number of GroupNorm row-chunk blocks in flight (default 512, >= 64).
  *   "epi_two_phase"   1 = the 8-wave GEMM tiles request every T row / residual chunk of a thread before using the first (default),

@@ -67,7 +67,7 @@ def test_options_are_the_only_global_state_and_no_getenv_in_the_library(monkeypa
     L = capi.Lib(build.build(verbose=False), require_device=False)            # forwards the two variables
     so = L.cdll.clora_set_option
     assert so(b"tile_order", 0) == 0 and so(b"tile_order", 3) == 0 and so(b"tile_order", 4) == capi.ERR_ARG and so(b"tile_order", 2) == 0
-    assert so(b"attn_fwd_waves", 6) == 0 and so(b"attn_fwd_waves", 5) == capi.ERR_ARG and so(b"attn_fwd_waves", 0) == 0
+    assert so(b"attn_fwd_waves", 6) == 0 and so(b"attn_fwd_waves", 16) == 0 and so(b"attn_fwd_waves", 5) == capi.ERR_ARG and so(b"attn_fwd_waves", 0) == 0
     assert so(b"attn_bwd_waves", 6) == capi.ERR_ARG and so(b"gn_blocks", 8) == capi.ERR_ARG and so(b"gn_blocks", 512) == 0
     assert so(b"no_such_knob", 1) == capi.ERR_ARG and so(None, 1) == capi.ERR_ARG
     monkeypatch.setenv("CLORA_TILE_ORDER", "sideways")

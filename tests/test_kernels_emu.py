@@ -315,3 +315,16 @@ def test_kernels_are_bit_stable_run_to_run(family):
         TG.test_kernels_are_bit_stable_run_to_run(family)
     finally:
         TG.DEV = old
+
+
+@pytest.mark.parametrize("waves", [4, 8, 16])
+@pytest.mark.parametrize("B,H,Nq,Nk,D", [(1, 2, 600, 300, 40), (2, 1, 513, 64, 40), (1, 1, 100, 1100, 64)])
+def test_attention_forward_block_widths(waves, B, H, Nq, Nk, D):
+    """clora_set_option("attn_fwd_waves"): 4 / 8 / 16 waves = 128 / 256 / 512 queries per forward block (the 16-wave block halves the
+    K/V tile stream per flop once more: the batch-32 sampler's level-0 self-attention); same results, ragged query counts included"""
+    from controllora_amd import kernels as K_
+    K_.set_option("attn_fwd_waves", waves)
+    try:
+        KC.case_attention("cpu", B, H, Nq, Nk, D)
+    finally:
+        K_.set_option("attn_fwd_waves", 0)
