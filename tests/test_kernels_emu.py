@@ -328,3 +328,17 @@ def test_attention_forward_block_widths(waves, B, H, Nq, Nk, D):
         KC.case_attention("cpu", B, H, Nq, Nk, D)
     finally:
         K_.set_option("attn_fwd_waves", 0)
+
+
+def test_gemm_eight_phase_random_shapes(zero_latency_dma_param):
+    """seeded sweep of tile_cfg 59 over ragged M / N / K (K tails that are not whole 64-deep K-tiles, fewer K-tiles than the seven
+    half-tiles the prologue runs ahead, several tiles in both directions, split-K): every shape against an fp32 matmul, under the
+    late- and the eager-landing DMA model"""
+    import random
+    rng = random.Random(59)
+    for _ in range(10):
+        M = rng.choice([1, 17, 64, 255, 256, 257, 300, 520])
+        N = rng.choice([8, 24, 72, 256, 264, 520])
+        Kd = rng.choice([8, 40, 64, 72, 128, 136, 320, 456, 1032])
+        split = rng.choice([1, 1, 2, 3]) if Kd >= 256 else 1
+        KC.case_gemm_plain("cpu", M, N, Kd, split, seed=M + N + Kd, tile_cfg=59)
