@@ -201,7 +201,10 @@ def box_calibration(dev):
                 us = e0.elapsed_time(e1) * 1e3 / 2
                 best = us if best is None else min(best, us)
         finally:
-            K.set_tile_order(K.DEFAULT_TILE_ORDER)
+            # back to the order in force before the calibration: an A/B run started with CLORA_TILE_ORDER=auto|m|n (forwarded to the
+            # library at load, capi._ENV_OPTIONS) must keep that order for the timed windows
+            env_order = {"a": "auto", "g": "grid"}.get(os.environ.get("CLORA_TILE_ORDER", ""), os.environ.get("CLORA_TILE_ORDER", ""))
+            K.set_tile_order(env_order if env_order in K.TILE_ORDERS else K.DEFAULT_TILE_ORDER)
         out["gemm8192_cfg1_us"] = round(best, 1)
         out["gemm8192_cfg1_TFLOPs"] = round(2 * n ** 3 / best / 1e6, 1)
         # the same GEMM on the eight-phase 256x256 tile (tile_cfg 59, default tile order): what the GEMM core reaches on this box

@@ -78,7 +78,20 @@ class LoraWgradJob(C.Structure):
                 ("a_rows", C.c_int), ("A2", C.c_void_p), ("lda2", C.c_int)]
 
 
+class ConvPackJob(C.Structure):
+    """mirror of clora_conv_pack_job_t"""
+    _fields_ = [("w", C.c_void_p), ("fwd", C.c_void_p), ("dgrad", C.c_void_p), ("Co", C.c_int), ("Ci", C.c_int), ("ksize", C.c_int),
+                ("Cip", C.c_int), ("Cop", C.c_int), ("pad_", C.c_int)]
+
+
+class ConvUnpackJob(C.Structure):
+    """mirror of clora_conv_unpack_job_t"""
+    _fields_ = [("stage", C.c_void_p), ("stage_b", C.c_void_p), ("grad_w", C.c_void_p), ("grad_b", C.c_void_p), ("Co", C.c_int),
+                ("Ci", C.c_int), ("ksize", C.c_int), ("Cip", C.c_int)]
+
+
 LORA_MAX_JOBS = 16
+CONV_MAX_JOBS = 32
 _P, _I, _Z, _F = C.c_void_p, C.c_int, C.c_size_t, C.c_float
 _PROTOS = {
     "clora_gemm_f16": [_P, _I, _P, _P, _I, _I, _I, _I, C.POINTER(ConvDesc), C.POINTER(Epilogue), _I, _P, _Z, _P],
@@ -88,6 +101,8 @@ _PROTOS = {
     "clora_conv_wgrad_f16": [_P, _I, _P, _I, _P, _P, _I, _I, _I, C.POINTER(ConvDesc), _I, _P],
     "clora_conv_weight_pack_f32": [_P, _I, _I, _I, _I, _I, _P, _P, _P],
     "clora_conv_wgrad_unpack_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "clora_conv_weight_pack_multi_f32": [C.POINTER(ConvPackJob), _I, _P],
+    "clora_conv_wgrad_unpack_multi_f32": [C.POINTER(ConvUnpackJob), _I, _P],
     "clora_attn_fwd_f16": [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _F, _P],
     "clora_attn_fwd_causal_f16": [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _F, _P],
     "clora_attn_bwd_f16": [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _F, _P, _Z, _P],

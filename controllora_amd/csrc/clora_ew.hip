@@ -376,3 +376,87 @@ extern "C" int clora_clock_probe(unsigned long long* out, int blocks, int iters,
 }
 extern "C" int clora_abi_version(void) { return 2; }   // 2: clora_epilogue_t / clora_lora_down_job_t grew (round 4)
 extern "C" const char* clora_build_info(void) { return "libclora gfx950 (v_mfma_f32_16x16x32_f16), ABI 2"; }
+
+// ------------------------------------------------------------------------------------------------
+// Multi-job forms of clora_conv_weight_pack_f32 / clora_conv_wgrad_unpack_f32 (clora_gemm.hip): every trainable convolution of the
+// hint encoder in one launch (grid.y = job).  Same per-element arithmetic as the single-job kernels.
+namespace {
+struct ConvPackJobs { clora_conv_pack_job_t j[CLORA_CONV_MAX_JOBS]; };
+struct ConvUnpackJobs { clora_conv_unpack_job_t j[CLORA_CONV_MAX_JOBS]; };
+
+__global__ __launch_bounds__(256) void conv_weight_pack_multi_kernel(ConvPackJobs jobs) {
+    const clora_conv_pack_job_t& p = jobs.j[blockIdx.y];
+    const int taps = p.ksize * p.ksize, Co = p.Co, Ci = p.Ci, Cip = p.Cip, Cop = p.Cop;
+    const float* w = p.w;
+    half_t* fwd = (half_t*)p.fwd;
+    half_t* dgrad = (half_t*)p.dgrad;
+    const int nf = Co * taps * Cip, nd = dgrad ? Cip * taps * Cop : 0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < nf + nd; i += gridDim.x * 256) {
+        if (i < nf) {
+            const int ci = i % Cip, tap = (i / Cip) % taps, co = i / (Cip * taps);
+            fwd[i] = ci < Ci ? (half_t)w[((size_t)co * Ci + ci) * taps + tap] : (half_t)0.f;
+        } else {
+            const int q = i - nf;
+            const int co = q % Cop, tap = (q / Cop) % taps, ci = q / (Cop * taps);
+            dgrad[q] = (ci < Ci && co < Co) ? (half_t)w[((size_t)co * Ci + ci) * taps + tap] : (half_t)0.f;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void conv_wgrad_unpack_multi_kernel(ConvUnpackJobs jobs) {
+    const clora_conv_unpack_job_t& p = jobs.j[blockIdx.y];
+    const int taps = p.ksize * p.ksize, Co = p.Co, Ci = p.Ci, Cip = p.Cip;
+    const int nw = Co * taps * Cip;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < nw + (p.grad_b ? Co : 0); i += gridDim.x * 256) {
+        if (i < nw) {
+            const int ci = i % Cip, tap = (i / Cip) % taps, co = i / (Cip * taps);
+            const float v = p.stage[i];
+            p.stage[i] = 0.f;
+            if (ci < Ci) p.grad_w[((size_t)co * Ci + ci) * taps + tap] += v;
+        } else {
+            const int co = i - nw;
+            p.grad_b[co] += p.stage_b[co];
+            p.stage_b[co] = 0.f;
+        }
+    }
+}
+}  // namespace
+
+extern "C" int clora_conv_weight_pack_multi_f32(const clora_conv_pack_job_t* jobs, int njobs, void* stream) {
+    if (!jobs || njobs <= 0 || njobs > CLORA_CONV_MAX_JOBS) return CLORA_ERR_ARG;
+    ConvPackJobs cj;
+    long most = 0;
+    for (int i = 0; i < njobs; ++i) {
+        const clora_conv_pack_job_t& j = jobs[i];
+        if (!j.w || !j.fwd || j.Co <= 0 || j.Ci <= 0 || (j.ksize != 1 && j.ksize != 3) || j.Cip < j.Ci || (j.Cip & 7) ||
+            (j.dgrad && (j.Cop < j.Co || (j.Cop & 7))))
+            return CLORA_ERR_ARG;
+        const int taps = j.ksize * j.ksize;
+        const long total = (long)j.Co * taps * j.Cip + (j.dgrad ? (long)j.Cip * taps * j.Cop : 0);
+        if (total > most) most = total;
+        cj.j[i] = j;
+    }
+    int blocks = clora_cdiv(most, 256 * 4);                     // ~4 elements per thread of the largest job
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(conv_weight_pack_multi_kernel, dim3(blocks, njobs), dim3(256), 0, (hipStream_t)stream, cj);
+    return clora_check_launch();
+}
+
+extern "C" int clora_conv_wgrad_unpack_multi_f32(const clora_conv_unpack_job_t* jobs, int njobs, void* stream) {
+    if (!jobs || njobs <= 0 || njobs > CLORA_CONV_MAX_JOBS) return CLORA_ERR_ARG;
+    ConvUnpackJobs cj;
+    long most = 0;
+    for (int i = 0; i < njobs; ++i) {
+        const clora_conv_unpack_job_t& j = jobs[i];
+        if (!j.stage || !j.grad_w || j.Co <= 0 || j.Ci <= 0 || j.Cip < j.Ci || (j.ksize != 1 && j.ksize != 3) ||
+            ((j.grad_b == nullptr) != (j.stage_b == nullptr)))
+            return CLORA_ERR_ARG;
+        const long total = (long)j.Co * j.ksize * j.ksize * j.Cip + (j.grad_b ? j.Co : 0);
+        if (total > most) most = total;
+        cj.j[i] = j;
+    }
+    int blocks = clora_cdiv(most, 256 * 4);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(conv_wgrad_unpack_multi_kernel, dim3(blocks, njobs), dim3(256), 0, (hipStream_t)stream, cj);
+    return clora_check_launch();
+}

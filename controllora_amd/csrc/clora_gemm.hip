@@ -1899,7 +1899,7 @@ extern "C" int clora_gemm_f16_ex(const clora_half* A, int lda, const clora_half*
     //            UNet widths 320 / 640 / 960 / 1280 are multiples of 160, not of 128); shapes it cannot take fall back to 21
     //            77, 78 = 128x128 / 128x64 with the 392-pixel patch (one 128-pixel row or row segment per tile: W = 128, 256, 512)
     //            79 = 256x160 (8 waves of 64x80; exactly 160 KB of LDS): batch >= 8 / inference shapes at N = 320 / 640 / 960 / 1280
-    if (cfg >= 71 && cfg <= 82 && cfg != 80) {
+    if (cfg >= 71 && cfg <= 79) {
         if (!dma || !patch_eligible(a, (cfg == 71 || cfg == 74 || cfg == 79) ? 256 : 128, (cfg == 77 || cfg == 78) ? kPatchWide : 0)) cfg = 21;
         else {
             const int slabs = a.conv.Cin / 64;
@@ -2023,7 +2023,7 @@ extern "C" int clora_set_option(const char* name, int value) {
 }
 
 extern "C" int clora_conv_patch_eligible(int M, const clora_conv_t* conv, int tile_cfg) {
-    if (!conv || tile_cfg < 71 || tile_cfg > 82 || tile_cfg == 80) return 0;
+    if (!conv || tile_cfg < 71 || tile_cfg > 79) return 0;
     GemmArgs a;
     a.M = M; a.conv = *conv;
     return patch_eligible(a, (tile_cfg == 71 || tile_cfg == 74 || tile_cfg == 79) ? 256 : 128, (tile_cfg == 77 || tile_cfg == 78) ? kPatchWide : 0) ? 1 : 0;   // same arguments as the launcher's switch

@@ -245,11 +245,14 @@ def conv_wgrad_into(dY: torch.Tensor, X: torch.Tensor, M: int, N: int, K: int, c
 
 def conv_wgrad_staged(dY, X, M, N, K, conv, stage: torch.Tensor, weight_grad: torch.Tensor, bias_grad: Optional[torch.Tensor], Cip: int):
     """3x3 trainable conv: coalesced atomics into the persistent, gather-ordered staging buffer `stage` (fp32
-    [N*K + N], zero on entry and left zero), then one unpack launch adds it into the OIHW weight / bias gradients."""
+    [N*K + N], zero on entry and left zero), then the unpack adds it into the OIHW weight / bias gradients -- inside a backward
+    pass as ONE multi-job launch for all convolutions at the end of the pass (conv_unpack_defer), else right away."""
     assert stage.dtype == f32 and stage.numel() == N * K + N and weight_grad.dtype == f32 and weight_grad.is_contiguous()
     sw, sb = stage[:N * K], stage[N * K:]
     _call("clora_conv_wgrad_f16", ptr(dY, f16), N, ptr(X, f16), K, ptr(sw), ptr(sb), M, N, K,
           C.byref(conv) if conv is not None else None, 0, flops=2.0 * M * N * K)
+    if bias_grad is not None and conv_unpack_defer(conv_unpack_job(stage, weight_grad, bias_grad, Cip), stage, weight_grad, bias_grad):
+        return
     Co, Ci, k, _ = weight_grad.shape
     _call("clora_conv_wgrad_unpack_f32", ptr(sw), ptr(sb) if bias_grad is not None else None, ptr(weight_grad),
           ptr(bias_grad, f32) if bias_grad is not None else None, Co, Ci, k, Cip)
@@ -257,14 +260,50 @@ def conv_wgrad_staged(dY, X, M, N, K, conv, stage: torch.Tensor, weight_grad: to
         sb.zero_()
 
 
-def conv_weight_pack(weight: torch.Tensor, Cip: int, need_dgrad: bool):
-    """fp32 [Co,Ci,k,k] -> fp16 forward operand [Co, k*k*Cip] and (optionally) dgrad operand [Cip, k*k*Cop], one launch"""
+def conv_weight_pack(weight: torch.Tensor, Cip: int, need_dgrad: bool, out=None):
+    """fp32 [Co,Ci,k,k] -> fp16 forward operand [Co, k*k*Cip] and (optionally) dgrad operand [Cip, k*k*Cop], one launch;
+    out = (fwd, dgrad) reuses persistent operand buffers (ops.TRAIN_CONV_PACKS)"""
     Co, Ci, k, _ = weight.shape
     Cop = (Co + 7) // 8 * 8
-    fwd = torch.empty((Co, k * k * Cip), dtype=f16, device=weight.device)
-    dgrad = torch.empty((Cip, k * k * Cop), dtype=f16, device=weight.device) if need_dgrad else None
+    if out is not None:
+        fwd, dgrad = out
+    else:
+        fwd = torch.empty((Co, k * k * Cip), dtype=f16, device=weight.device)
+        dgrad = torch.empty((Cip, k * k * Cop), dtype=f16, device=weight.device) if need_dgrad else None
     _call("clora_conv_weight_pack_f32", ptr(weight, f32), Co, Ci, k, Cip, Cop, ptr(fwd), ptr(dgrad) if dgrad is not None else None)
     return fwd, dgrad
+
+
+def conv_pack_job(weight: torch.Tensor, Cip: int, fwd: torch.Tensor, dgrad: Optional[torch.Tensor]):
+    """one problem of conv_weight_pack_multi (clora_conv_pack_job_t)"""
+    Co, Ci, k, _ = weight.shape
+    assert weight.dtype == f32 and weight.is_contiguous() and fwd.dtype == f16 and fwd.numel() == Co * k * k * Cip
+    return capi.ConvPackJob(ptr(weight, f32), ptr(fwd), ptr(dgrad) if dgrad is not None else None, Co, Ci, k, Cip, (Co + 7) // 8 * 8, 0)
+
+
+def conv_weight_pack_multi(jobs):
+    """the fp16 operands of every trainable convolution in one launch per 32 jobs (clora_conv_weight_pack_multi_f32)"""
+    for i in range(0, len(jobs), capi.CONV_MAX_JOBS):
+        chunk = jobs[i:i + capi.CONV_MAX_JOBS]
+        arr = (capi.ConvPackJob * len(chunk))(*chunk)
+        _call("clora_conv_weight_pack_multi_f32", arr, len(chunk))
+
+
+def conv_unpack_job(stage: torch.Tensor, weight_grad: torch.Tensor, bias_grad: Optional[torch.Tensor], Cip: int):
+    """one problem of conv_wgrad_unpack_multi: `stage` = the persistent fp32 [Co * k*k*Cip + Co] staging buffer of conv_wgrad_staged"""
+    Co, Ci, k, _ = weight_grad.shape
+    nw = Co * k * k * Cip
+    assert stage.dtype == f32 and stage.numel() == nw + Co and weight_grad.dtype == f32 and weight_grad.is_contiguous()
+    sw, sb = stage[:nw], stage[nw:]
+    return capi.ConvUnpackJob(ptr(sw), ptr(sb) if bias_grad is not None else None, ptr(weight_grad),
+                              ptr(bias_grad, f32) if bias_grad is not None else None, Co, Ci, k, Cip)
+
+
+def conv_wgrad_unpack_multi(jobs):
+    for i in range(0, len(jobs), capi.CONV_MAX_JOBS):
+        chunk = jobs[i:i + capi.CONV_MAX_JOBS]
+        arr = (capi.ConvUnpackJob * len(chunk))(*chunk)
+        _call("clora_conv_wgrad_unpack_multi_f32", arr, len(chunk))
 
 
 # ------------------------------------------------------------------ attention
@@ -489,7 +528,8 @@ def lora_wgrad_multi(jobs, device):
 # the autograd functions queue their reduction jobs instead of launching them one site at a time; the queue is flushed
 # ONCE at the end of the backward pass, 16 jobs per launch: ~110 small launch pairs per step become ~25 large ones.
 # Tensors the jobs read are kept alive until the flush.  Jobs that target the same gradient buffer never share a launch.
-_wgrad_queue = {"jobs": [], "refs": [], "task": None, "enabled": os.environ.get("CLORA_DEFER_WGRAD", "1") != "0"}
+_wgrad_queue = {"jobs": [], "refs": [], "task": None, "enabled": os.environ.get("CLORA_DEFER_WGRAD", "1") != "0", "unpack": []}
+DEFER_UNPACK = os.environ.get("CLORA_DEFER_UNPACK", "1") != "0"        # "0": one unpack launch per hint-encoder convolution (A/B runs)
 
 
 def _graph_task_id():
@@ -497,35 +537,55 @@ def _graph_task_id():
     return f() if f is not None else -1
 
 
-def lora_wgrad_defer(jobs, device, *keepalive):
+def _defer_open():
+    """inside a backward pass with deferral on: make sure THIS pass has its end-of-backward flush registered -> True"""
     if not _wgrad_queue["enabled"] or PROFILER is not None:
-        lora_wgrad_multi(jobs, device)
-        return
+        return False
     task = _graph_task_id()
     if task < 0:                   # not inside a backward pass: nothing to wait for
-        lora_wgrad_multi(jobs, device)
-        return
+        return False
     if _wgrad_queue["task"] != task:
         # first deferral of THIS backward pass.  Anything still queued belongs to an earlier pass that raised before
         # its end-of-backward callback ran: those jobs point at freed tensors -- drop them, never launch them.
         lora_wgrad_discard()
         _wgrad_queue["task"] = task
         torch.autograd.Variable._execution_engine.queue_callback(lora_wgrad_flush)   # runs when this pass ends
+    return True
+
+
+def lora_wgrad_defer(jobs, device, *keepalive):
+    if not _defer_open():
+        lora_wgrad_multi(jobs, device)
+        return
     _wgrad_queue["jobs"].extend(jobs)
     _wgrad_queue["refs"].extend(keepalive)
     _wgrad_queue["device"] = device
 
 
+def conv_unpack_defer(job, *keepalive) -> bool:
+    """queue the staging -> OIHW unpack of one hint-encoder convolution for the end-of-backward flush (one multi-job launch for all
+    of them; the gradients are leaves of the pass: only the optimizer reads them) -> False when there is no pass to wait for"""
+    if not DEFER_UNPACK or not _defer_open():
+        return False
+    _wgrad_queue["unpack"].append(job)
+    _wgrad_queue["refs"].extend(keepalive)
+    return True
+
+
 def lora_wgrad_discard():
     """drop queued jobs without running them (a backward pass that raised must not leak its jobs into the next step)"""
     _wgrad_queue["jobs"].clear()
+    _wgrad_queue["unpack"].clear()
     _wgrad_queue["refs"].clear()
     _wgrad_queue["task"] = None
 
 
 def lora_wgrad_flush():
     jobs, _wgrad_queue["jobs"] = _wgrad_queue["jobs"], []
+    unpack, _wgrad_queue["unpack"] = _wgrad_queue["unpack"], []
     _wgrad_queue["task"] = None
+    if unpack:
+        conv_wgrad_unpack_multi(unpack)
     if jobs:
         batches = []               # greedy packing: a batch never holds two jobs with the same destination
         for j in jobs:

@@ -140,6 +140,65 @@ class text_kv_cache:
         return False
 
 
+# ---- training: the text K|V projections of all cross-attention sites of one width as ONE launch (ops.TextKVGroup).  The UNet opens
+# `grouped_text_kv` around its forward; `_attend` below picks its site's column block up from `_TEXT_GROUPS`.
+_TEXT_GROUPS = None
+
+
+class grouped_text_kv:
+    """Context manager used by `unet.UNet2DConditionModel.forward`: with autograd on and a text embedding that needs no gradient
+    (the reference's frozen text encoder, train...:441-445, 766-768), evaluate k | v of every cross-attention site whose processor
+    runs the fused path -- grouped by hidden size -- before the first block runs.  Sites it does not cover run as before."""
+
+    def __init__(self, unet, ehs, kw):
+        self.unet, self.ehs, self.scale = unet, ehs, float((kw or {}).get("scale", 1.0))
+
+    def __enter__(self):
+        global _TEXT_GROUPS
+        self._prev = _TEXT_GROUPS
+        _TEXT_GROUPS = None
+        if not (ops.GROUP_TEXT_KV and torch.is_grad_enabled()) or self.ehs.requires_grad:
+            return self
+        sites = getattr(self.unet, "_cross_sites", None)
+        if sites is None:
+            sites = self.unet._cross_sites = [m for m in self.unet.modules() if getattr(m, "is_cross", False) and hasattr(m, "fused_packs")]
+        buckets = {}
+        for attn in sites:
+            p = attn.processor
+            if isinstance(p, LoRACrossAttnProcessor) and not p._needs_generic_path():
+                buckets.setdefault((attn.inner_dim, attn.to_k.weight.shape[1]), []).append(attn)
+        e2 = _flat2(self.ehs)
+        table = {}
+        for (C_, ctx_dim), group in buckets.items():
+            if len(group) < 2 or e2.shape[1] != ctx_dim:
+                continue
+            segs = []
+            for attn in group:
+                p = attn.processor
+                for name, skipped in (("to_k_lora", p.key_states_skipped), ("to_v_lora", p.value_states_skipped)):
+                    sg = p._seg(name, e2, self.scale, skipped)
+                    segs.append(None if sg is None else (sg[1], sg[2], float(sg[3])))
+            ranks = {sg[0].shape[0] for sg in segs if sg is not None}
+            if len(ranks) > 1 or any(r > 16 for r in ranks):
+                continue
+            key = tuple((a.to_k.weight.data_ptr(), a.to_k.weight._version, a.to_v.weight.data_ptr(), a.to_v.weight._version) for a in group)
+            cache = self.unet.__dict__.setdefault("_text_kv_packs", {})
+            hit = cache.get((C_, ctx_dim))
+            if hit is None or hit[0] != key:
+                w = torch.cat([w_ for a in group for w_ in (a.to_k.weight.detach(), a.to_v.weight.detach())], 0)
+                hit = cache[(C_, ctx_dim)] = (key, ops.LinearPack(w, None))
+            g = ops.TextKVGroup(e2, hit[1], C_, segs, len(group))
+            for i, attn in enumerate(group):
+                table[id(attn)] = (g, i, attn.processor, self.scale)
+        _TEXT_GROUPS = table or None
+        return self
+
+    def __exit__(self, *exc):
+        global _TEXT_GROUPS
+        _TEXT_GROUPS = self._prev
+        return False
+
+
 class LoRACrossAttnProcessor(nn.Module):
     fuses_residual = True
     version = 0
@@ -246,15 +305,20 @@ class LoRACrossAttnProcessor(nn.Module):
             t_pre = getattr(self, "_control_T", None)
         if attn.is_cross:
             q = ops.lora_proj(h2, packs[0], [self._seg("to_q_lora", q_in, scale)], t_pre=t_pre[:, :4] if t_pre is not None else None)
-            cache = _TEXT_KV if not torch.is_grad_enabled() else None
-            key = (id(self), id(attn), e2.data_ptr(), e2._version, tuple(e2.shape), float(scale)) if cache is not None else None
-            kv = cache.get(key) if cache is not None else None
-            if kv is None:
-                kv = ops.lora_proj(e2, packs[1], [self._seg("to_k_lora", e2, scale, self.key_states_skipped),
-                                                 self._seg("to_v_lora", e2, scale, self.value_states_skipped)])
-                if cache is not None:
-                    cache[key] = kv
-            a = attn.attend(q, kv, B, N, Nk)
+            grp = _TEXT_GROUPS.get(id(attn)) if (_TEXT_GROUPS is not None and torch.is_grad_enabled()) else None
+            if grp is not None and grp[2] is self and grp[3] == float(scale) and grp[0].e2.data_ptr() == e2.data_ptr():
+                # k | v of this site were evaluated with every other site of its width at the head of the UNet forward
+                a = ops.attention_cross_grouped(q, grp[0], grp[1], B, attn.heads, N, Nk, attn.dim_head, attn.scale)
+            else:
+                cache = _TEXT_KV if not torch.is_grad_enabled() else None
+                key = (id(self), id(attn), e2.data_ptr(), e2._version, tuple(e2.shape), float(scale)) if cache is not None else None
+                kv = cache.get(key) if cache is not None else None
+                if kv is None:
+                    kv = ops.lora_proj(e2, packs[1], [self._seg("to_k_lora", e2, scale, self.key_states_skipped),
+                                                     self._seg("to_v_lora", e2, scale, self.value_states_skipped)])
+                    if cache is not None:
+                        cache[key] = kv
+                a = attn.attend(q, kv, B, N, Nk)
         else:
             qkv = ops.lora_proj(h2, packs[0], [self._seg("to_q_lora", q_in, scale),
                                                self._seg("to_k_lora", h2, scale, self.key_states_skipped),

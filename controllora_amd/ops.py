@@ -370,6 +370,116 @@ def attention_cross(q, kv, B, H, N, Nk, D, scale):
     return _AttnCrossFn.apply(q, kv, B, H, N, Nk, D, scale)
 
 
+# ---- grouped text K|V projections ---------------------------------------------------------------------------------------------
+# The cross-attention sites' k = W_k e + s L_k(e), v = W_v e + s L_v(e) (reference models.py:128-136, 249-265) read ONLY the text
+# embedding: the 16 projections of a train step (M = B * 77 rows each) do not depend on anything the UNet computes.  All sites of one
+# width run as ONE GEMM over the row-concatenated [W_k1; W_v1; W_k2; ...] with one adapter per column segment (+ one multi-job
+# down-projection launch), at the head of the UNet forward; every site's attention reads its column block in place.  Backward: each
+# site's attention writes dK | dV into its block of one gradient buffer; when the last site of the group has run, dT of all adapters
+# is one multi-job launch and the weight gradients join the deferred queue (the text embedding itself needs no gradient: the text
+# encoder is frozen, reference train...:441-445).  16 GEMM + 16 down + 16 dT launches -> 3 + 3 + 3.
+GROUP_TEXT_KV = _os.environ.get("CLORA_GROUP_TEXT_KV", "1") != "0"        # "0": one projection per site (round-5 path, A/B runs)
+
+
+class TextKVGroup:
+    def __init__(self, e2: torch.Tensor, pack: LinearPack, seg_w: int, segs, n_sites: int):
+        """segs[s] = None or (down_weight [r, K], up_weight [seg_w, r], scale) for column segment s (site i owns 2i, 2i + 1)"""
+        M, S = e2.shape[0], len(segs)
+        assert pack.N == S * seg_w and S == 2 * n_sites
+        self.e2, self.pack, self.seg_w, self.segs, self.n_sites = e2, pack, seg_w, segs, n_sites
+        live = [sg for sg in segs if sg is not None]
+        self.r = live[0][0].shape[0] if live else 0
+        assert all(sg[0].shape[0] == self.r and sg[0].shape[1] == pack.K for sg in live) and self.r <= 16
+        self.T = None
+        if live:
+            r = self.r
+            self.T = (torch.empty if len(live) == S else torch.zeros)((M, S * r), dtype=f32, device=e2.device)
+            specs = [dict(X=e2, D=sg[0].detach(), toff=s * r, R=r, X2=None, r2=0) for s, sg in enumerate(segs) if sg is not None]
+            K.lora_down_multi([K.down_job(j["X"], j["D"], self.T, j["toff"], M, j["D"].shape[1], R=j["R"]) for j in _merge_down_jobs(specs)])
+            pieces = [_zero_const((seg_w, r), e2.device) if sg is None else (sg[1].detach() if sg[2] == 1.0 else sg[1].detach() * sg[2])
+                      for sg in segs]
+            self.out = K.gemm(e2, pack.w, M, pack.N, pack.K, bias=pack.bias, lora_t=self.T, lora_u=_stack_rows(pieces), lora_seg=seg_w,
+                              lora_scale=1.0)
+        else:
+            self.out = K.gemm(e2, pack.w, M, pack.N, pack.K, bias=pack.bias)
+        self.dout, self.pending, self.done = None, set(range(n_sites)), False
+
+    def site_kv(self, i):
+        w = self.seg_w
+        return self.out[:, 2 * i * w:(2 * i + 2) * w]
+
+    def sink(self, i):
+        """dK, dV views of site i inside the group's gradient buffer"""
+        if self.dout is None:
+            self.dout = torch.empty_like(self.out)
+            # safety net: a site whose output never reached the loss leaves the group open -- close it when the pass ends
+            torch.autograd.Variable._execution_engine.queue_callback(lambda: self.finalize(late=True))
+        w = self.seg_w
+        return self.dout[:, 2 * i * w:(2 * i + 1) * w], self.dout[:, (2 * i + 1) * w:(2 * i + 2) * w]
+
+    def site_done(self, i):
+        self.pending.discard(i)
+        if not self.pending:
+            self.finalize()
+
+    def finalize(self, late=False):
+        if self.done:
+            return
+        self.done = True
+        if self.T is None or self.dout is None:
+            return
+        M, r, w, N = self.e2.shape[0], self.r, self.seg_w, self.pack.N
+        written = [s for s, sg in enumerate(self.segs) if sg is not None and (s // 2) not in self.pending]
+        if not written:
+            return
+        dT = (torch.empty if len(written) == len(self.segs) else torch.zeros)((M, len(self.segs) * r), dtype=f32, device=self.e2.device)
+        djobs, wjobs = [], []
+        for s in written:
+            D, U, sc = self.segs[s]
+            dys = self.dout[:, s * w:(s + 1) * w]
+            djobs.append(K.down_job(dys, U.detach(), dT, s * r, M, w, ldx=N, kmajor=True, R=r, d_scale=sc))
+            if U.requires_grad:
+                wjobs.append(K.wgrad_job(dys, self.T, s * r, _grad_buffer(U), U.shape[1], 1, M, w, r, scale=sc, lda=N))
+            if D.requires_grad:
+                wjobs.append(K.wgrad_job(self.e2, dT, s * r, _grad_buffer(D), 1, D.shape[1], M, D.shape[1], r))
+        K.lora_down_multi(djobs)
+        if wjobs:
+            if late:                                     # the end-of-backward flush may already have run
+                K.lora_wgrad_multi(wjobs, self.e2.device)
+            else:
+                K.lora_wgrad_defer(wjobs, self.e2.device, self.dout, self.T, dT, self.e2)
+
+
+class _AttnCrossGroupedFn(torch.autograd.Function):
+    """_AttnCrossFn for a site of a TextKVGroup: k | v are the site's column block of the grouped projection, dK | dV go to the
+    group's gradient buffer (no autograd edge to the group: its backward is the group's own, run after its last site)"""
+
+    @staticmethod
+    def forward(ctx, q, group: TextKVGroup, i, B, H, N, Nk, D, scale):
+        C_ = H * D
+        kv = group.site_kv(i)
+        o, lse = K.attn_fwd(q, kv[:, :C_], kv[:, C_:], B, H, N, Nk, D, scale)
+        ctx.save_for_backward(q, o, lse)
+        ctx.cfg = (group, i, B, H, N, Nk, D, scale)
+        return o
+
+    @staticmethod
+    def backward(ctx, dO):
+        q, o, lse = ctx.saved_tensors
+        group, i, B, H, N, Nk, D, scale = ctx.cfg
+        C_ = H * D
+        kv = group.site_kv(i)
+        dk, dv = group.sink(i)
+        dq = torch.empty_like(q)
+        K.attn_bwd(q, kv[:, :C_], kv[:, C_:], o, dO.contiguous(), lse, B, H, N, Nk, D, scale, dq, dk, dv)
+        group.site_done(i)
+        return dq, None, None, None, None, None, None, None, None
+
+
+def attention_cross_grouped(q, group: TextKVGroup, i, B, H, N, Nk, D, scale):
+    return _AttnCrossGroupedFn.apply(q, group, i, B, H, N, Nk, D, scale)
+
+
 # ------------------------------------------------------------------------------------------------ adapters
 def _grad_buffer(p: torch.Tensor) -> torch.Tensor:
     """Adapter weight gradients are accumulated by the kernels straight into ``param.grad`` (fp32 atomics;
@@ -540,7 +650,68 @@ ADAPTER_PACKS = _AdapterPacks()
 
 
 def repack_adapters():
+    """refresh every fp16 operand derived from the trainable fp32 master weights after they changed behind torch's back (the flat
+    AdamW kernel, a flat-buffer checkpoint load): the adapters' in-GEMM operand blocks and the hint encoder's conv operands"""
     ADAPTER_PACKS.repack_all()
+    TRAIN_CONV_PACKS.repack_all()
+
+
+# ---- fp16 GEMM operands of the trainable hint-encoder convolutions (reference models.py:470, 529, 594-597, 684) ---------------
+# accelerate's autocast casts every conv weight once per forward; here the cast is fused with the layout change the implicit GEMM
+# wants (K.conv_weight_pack) and -- since round 6 -- done for ALL convolutions by one launch per optimizer step instead of one
+# launch per convolution per forward (18 launches of 5-10 us under fill50k.json): the operands are persistent buffers hung on the
+# parameter itself, refreshed (a) by `repack_adapters()` after the flat optimizer step / a flat checkpoint load, (b) at the point of
+# use when torch saw an in-place update (the parameter's _version moved: torch optimizers, load_state_dict, tests).
+PERSISTENT_CONV_PACKS = _os.environ.get("CLORA_PERSISTENT_CONV_PACKS", "1") != "0"     # "0": pack per call (round-5 path, A/B runs)
+
+
+class _TrainConvPacks:
+    def __init__(self):
+        self.live = []            # weakrefs of the parameters that carry a pack
+
+    def get(self, weight: torch.Tensor, Cip: int, need_dx: bool):
+        import weakref
+        key = (weight.data_ptr(), str(weight.device), int(Cip), bool(need_dx))
+        st = getattr(weight, "_clora_pack", None)
+        if st is None or st["key"] != key:
+            Co, Ci, k, _ = weight.shape
+            Cop = (Co + 7) // 8 * 8
+            fwd = torch.empty((Co, k * k * Cip), dtype=f16, device=weight.device)
+            dgrad = torch.empty((Cip, k * k * Cop), dtype=f16, device=weight.device) if need_dx else None
+            fresh = st is None
+            st = dict(key=key, fwd=fwd, dgrad=dgrad, Cip=int(Cip), version=None)
+            weight._clora_pack = st
+            if fresh:
+                self.live.append(weakref.ref(weight))
+            ADAPTER_PACKS.epoch += 1                       # a captured optimizer graph does not repack this one yet (train.step_graphed)
+        if st["version"] != weight._version:
+            K.conv_weight_pack(weight.detach(), st["Cip"], st["dgrad"] is not None, out=(st["fwd"], st["dgrad"]))
+            st["version"] = weight._version
+        return st["fwd"], st["dgrad"]
+
+    def repack_all(self):
+        jobs, alive = [], []
+        for ref in self.live:
+            w = ref()
+            st = getattr(w, "_clora_pack", None) if w is not None else None
+            if st is None:
+                continue
+            alive.append(ref)
+            if st["key"][0] != w.data_ptr() or not w.is_cuda and capi_requires_device():
+                continue                                   # moved since (module.to()): re-packed at its next use
+            jobs.append(K.conv_pack_job(w.detach(), st["Cip"], st["fwd"], st["dgrad"]))
+            st["version"] = w._version
+        self.live = alive
+        if jobs:
+            K.conv_weight_pack_multi(jobs)
+
+
+def capi_requires_device():
+    from . import capi
+    return capi.lib().require_device
+
+
+TRAIN_CONV_PACKS = _TrainConvPacks()
 
 
 FUSE_MIN_BLOCKS = int(_os.environ.get("CLORA_FUSE_MIN_BLOCKS", "192"))
@@ -1251,7 +1422,10 @@ class _TrainConvFn(torch.autograd.Function):
     def forward(ctx, x, weight, bias, B, H, W, stride, asym_pad, need_dx):
         Co, Ci, k, _ = weight.shape
         Cip = x.shape[1]
-        wp, wd = K.conv_weight_pack(weight.detach(), Cip, need_dx)
+        if PERSISTENT_CONV_PACKS:
+            wp, wd = TRAIN_CONV_PACKS.get(weight, Cip, need_dx)
+        else:
+            wp, wd = K.conv_weight_pack(weight.detach(), Cip, need_dx)
         if k == 3:
             cd, Ho, Wo = K.conv_fwd_desc(H, W, Cip, 3, stride, 0 if asym_pad else 1, False, asym_pad)
             y = K.gemm(x, wp, B * Ho * Wo, Co, 9 * Cip, conv=cd, bias=bias.detach())

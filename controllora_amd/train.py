@@ -89,8 +89,12 @@ class ControlLoRATrainer:
         # gradient accumulation (train...:174-178, `accelerator.accumulate`): micro-batch losses are divided by the
         # number of accumulation steps and the optimizer runs on the last micro-batch only
         self.accum, self._micro = max(1, int(gradient_accumulation_steps)), 0
-        # LR schedule (train...:660-665 get_scheduler): multiplier(step) written to state[10] before each optimizer step
+        # LR schedule (train...:660-665 get_scheduler): multiplier written to state[10] before each optimizer step.  Units are
+        # accelerate's: `accelerator.prepare(lr_scheduler)` steps the wrapped LambdaLR `num_processes` times per optimizer step, so
+        # the reference's multiplier at optimizer step s is lambda(s * world) -- with N GPUs it warms up and decays N times faster
+        # than the flag values read (the entry point builds lambda from warmup * accum / max_train_steps * accum like train...:675-680)
         self.lr_lambda, self.global_step = lr_lambda, 0
+        self.sched_epoch = 0          # `last_epoch` of the reference's wrapped LambdaLR: += world per optimizer step
         # Exchange step: "torch" = torch.distributed.all_reduce on the process group (backend "nccl" IS RCCL on ROCm; gloo in
         # the CPU tests); "clora" = the C ABI's own RCCL communicator (clora_comm_init / clora_allreduce_flat_f32), created
         # from a unique id that rank 0 draws and the process group broadcasts.  Both enqueue the same ncclAllReduce on the
@@ -239,8 +243,9 @@ class ControlLoRATrainer:
             return False
         self._micro = 0
         if self.lr_lambda is not None:
-            self.state[10:11].fill_(max(float(self.lr_lambda(self.global_step)), 1e-30))
+            self.state[10:11].fill_(max(float(self.lr_lambda(self.sched_epoch)), 1e-30))
         self.global_step += 1
+        self.sched_epoch += self.world
         if self.world > 1:
             self._all_reduce_grads()
             self._reduced = True
@@ -280,12 +285,16 @@ class ControlLoRATrainer:
         self._g_fb = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._g_fb):
             self._static_pred = self.forward_backward(*self._static)
+        self._capture_optimizer_graph()
+        return self
+
+    def _capture_optimizer_graph(self):
+        from . import ops
+        torch.cuda.synchronize()
         self._g_opt = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._g_opt, pool=self._g_fb.pool()):
             self._optimizer_kernels()
-        from . import ops
         self._pack_epoch = ops.ADAPTER_PACKS.epoch       # the captured repack launch covers the adapter groups registered so far
-        return self
 
     def step_graphed(self, noisy_latents=None, timesteps=None, encoder_hidden_states=None, guide=None, target=None):
         for dst, src in zip(self._static, (noisy_latents, timesteps, encoder_hidden_states, guide, target)):
@@ -298,14 +307,18 @@ class ControlLoRATrainer:
             self._all_reduce_grads()
             self._reduced = True
         if self.lr_lambda is not None:
-            self.state[10:11].fill_(max(float(self.lr_lambda(self.global_step)), 1e-30))
+            self.state[10:11].fill_(max(float(self.lr_lambda(self.sched_epoch)), 1e-30))
         self.global_step += 1
+        self.sched_epoch += self.world
         self._g_opt.replay()
         from . import ops
         if ops.ADAPTER_PACKS.epoch != self._pack_epoch:
             # a group registered after the capture (e.g. run_validation at a batch size whose projections fuse differently): the
             # captured repack launch does not know it and the flat AdamW does not bump its parameters' _version -- repack eagerly
+            # THIS step, then capture the optimizer graph again so that its repack launch covers the new table (once per new
+            # group, not an extra eager launch on every later step: ADVICE r05)
             ops.repack_adapters()
+            self._capture_optimizer_graph()
         return self._static_pred
 
     # -- checkpoint / resume (train...:713-735 `accelerator.save_state / load_state`: weights, optimizer moments,
@@ -313,7 +326,8 @@ class ControlLoRATrainer:
     def state_dict(self) -> Dict[str, torch.Tensor]:
         return {"params": self.flat.data.detach().cpu().clone(), "exp_avg": self.flat.exp_avg.cpu().clone(),
                 "exp_avg_sq": self.flat.exp_avg_sq.cpu().clone(), "state": self.state.cpu().clone(),
-                "global_step": torch.tensor([self.global_step], dtype=torch.int64)}
+                "global_step": torch.tensor([self.global_step], dtype=torch.int64),
+                "sched_epoch": torch.tensor([self.sched_epoch], dtype=torch.int64)}
 
     def load_state_dict(self, sd: Dict[str, torch.Tensor]) -> None:
         if sd["params"].numel() != self.flat.numel:
@@ -325,6 +339,7 @@ class ControlLoRATrainer:
             self.state.copy_(sd["state"])
             self.state[11] = float(self.world)       # the divisor belongs to THIS run's world size, not the checkpoint's
         self.global_step, self._micro = int(sd["global_step"][0]), 0
+        self.sched_epoch = int(sd["sched_epoch"][0]) if "sched_epoch" in sd else self.global_step * self.world
         from . import ops
         ops.repack_adapters()        # the copies above do not bump the parameters' _version: refresh the fp16 operand packs now
 
@@ -403,10 +418,13 @@ class ControlLoRATrainer:
         # AcceleratedScheduler advances the wrapped scheduler num_processes times per optimizer step (train...:660-665 builds the
         # schedule in those units), so a multi-GPU checkpoint holds last_epoch = world_of_the_saving_run x steps
         self.global_step = step
+        self.sched_epoch = step * self.world
         self.resumed_scheduler_ratio = None
-        if os.path.exists(f("scheduler.bin")) and step > 0:
-            last = int(torch.load(f("scheduler.bin"), map_location="cpu").get("last_epoch", step))
-            self.resumed_scheduler_ratio = last / step       # = the saving run's process count (1 for a single-GPU run)
+        if os.path.exists(f("scheduler.bin")):
+            last = int(torch.load(f("scheduler.bin"), map_location="cpu", weights_only=False).get("last_epoch", step))
+            self.sched_epoch = last                          # the schedule continues from the saved position, like accelerate.load_state
+            if step > 0:
+                self.resumed_scheduler_ratio = last / step   # = the saving run's process count (1 for a single-GPU run)
         self._micro = 0
         from . import ops
         ops.repack_adapters()
@@ -427,8 +445,17 @@ class ControlLoRATrainer:
         torch.save({"state": state, "param_groups": [group]}, os.path.join(directory, "optimizer.bin"))
         torch.save({"scale": float(self.state[3]), "growth_factor": 2.0, "backoff_factor": 0.5, "growth_interval": self.hp["interval"],
                     "_growth_tracker": int(self.state[4])}, os.path.join(directory, "scaler.pt"))
-        # accelerate's unit: the wrapped scheduler is stepped `num_processes` times per optimizer step
-        torch.save({"last_epoch": self.global_step * self.world, "_step_count": self.global_step * self.world + 1}, os.path.join(directory, "scheduler.bin"))
+        # accelerate's unit: the wrapped scheduler is stepped `num_processes` times per optimizer step.  The file is the state_dict of
+        # a real torch LambdaLR (every key `LambdaLR.load_state_dict` of the installed torch expects, `lr_lambdas` = [None] for a
+        # plain function as torch writes it), so `accelerator.load_state` of a reference run can take it
+        base_lr = self.hp["lr"] if lr is None else lr
+        last = self.sched_epoch
+        mult = float(self.lr_lambda(last)) if self.lr_lambda is not None else 1.0
+        dummy = torch.optim.SGD([torch.zeros(1, requires_grad=True)], lr=base_lr)
+        sched = torch.optim.lr_scheduler.LambdaLR(dummy, self.lr_lambda if self.lr_lambda is not None else (lambda _: 1.0))
+        sd = sched.state_dict()
+        sd.update(last_epoch=last, _step_count=last + 1, _last_lr=[base_lr * mult], base_lrs=[base_lr])
+        torch.save(sd, os.path.join(directory, "scheduler.bin"))
 
     # -- host-visible scalars (each forces a sync; call outside the timed region)
     def loss(self, numel) -> float:

@@ -476,8 +476,14 @@ class UNet2DConditionModel(nn.Module):
         dev = sample.device
         temb_act = self.time_embed(timestep, B, dev)
         tp = self._temb_projections(temb_act)
-        tproj = lambda r: tp[id(r.time_emb_proj)]
         ehs = encoder_hidden_states.to(f16).contiguous()
+        from . import models as _models                  # (models imports this module: resolved at call time)
+        with _models.grouped_text_kv(self, ehs, kw):     # training: the text K|V projections of all sites, one launch per width
+            return self._forward_blocks(sample, temb_act, tp, ehs, kw, return_dict)
+
+    def _forward_blocks(self, sample, temb_act, tp, ehs, kw, return_dict):
+        B, Cin, H, W = sample.shape
+        tproj = lambda r: tp[id(r.time_emb_proj)]
         x = sample.new_zeros((B, H, W, self.conv_in.pack().Cip), dtype=f16)
         x[..., :Cin] = sample.permute(0, 2, 3, 1)
         x = self.conv_in(x.reshape(B * H * W, -1), B, H, W).reshape(B, H * W, -1)

@@ -200,6 +200,27 @@ int clora_conv_wgrad_unpack_f32(float* stage, float* stage_b, float* grad_w, flo
 int clora_conv_weight_pack_f32(const float* w, int Co, int Ci, int ksize, int Cip, int Cop, clora_half* fwd,
                                clora_half* dgrad, void* stream);
 
+/* The two calls above for EVERY trainable convolution of the hint encoder in one launch each (reference models.py:684-808 builds
+ * 18 Conv2d layers under configs/fill50k.json: until round 6 the step issued 18 pack and 14 unpack launches of 5-10 us).
+ * `jobs` is a HOST array (copied into the kernel arguments, graph-capture safe), njobs <= CLORA_CONV_MAX_JOBS; per job the
+ * arguments and results are exactly those of the single-job calls. */
+#define CLORA_CONV_MAX_JOBS 32
+typedef struct {
+    const float* w;            /* fp32 master weight [Co][Ci][ks][ks] */
+    clora_half* fwd;           /* [Co][ks*ks][Cip] */
+    clora_half* dgrad;         /* [Cip][ks*ks][Cop] or NULL */
+    int Co, Ci, ksize, Cip, Cop, pad_;
+} clora_conv_pack_job_t;
+int clora_conv_weight_pack_multi_f32(const clora_conv_pack_job_t* jobs, int njobs, void* stream);
+typedef struct {
+    float* stage;              /* [Co][ks*ks*Cip] gather-ordered staging, reset to zero */
+    float* stage_b;            /* [Co] or NULL (together with grad_b) */
+    float* grad_w;             /* [Co][Ci][ks][ks] += */
+    float* grad_b;             /* [Co] += or NULL */
+    int Co, Ci, ksize, Cip;
+} clora_conv_unpack_job_t;
+int clora_conv_wgrad_unpack_multi_f32(const clora_conv_unpack_job_t* jobs, int njobs, void* stream);
+
 /* ---- attention core: O = softmax(Q K^T * scale) V per (batch, head), flash-style (never
  * materialises the [B*H, N, Nk] scores the reference builds at models.py:140-141, 270-271).
  * q: [B, Nq, H*D] with row stride ldq (elements), k/v: [B, Nk, H*D] strides ldk/ldv, o: ldo.

@@ -91,10 +91,21 @@ def test_resume_from_an_accelerate_format_checkpoint(tmp_path):
     torch.save({"last_epoch": 24, "_step_count": 25}, d / "scheduler.bin")
     tr.load_state(str(d))
     assert tr.global_step == 3 and tr.resumed_scheduler_ratio == 8.0
+    assert tr.sched_epoch == 24                    # the schedule continues where the saving run's wrapped LambdaLR stood
+    # the LR multiplier is evaluated in accelerate's units: `last_epoch` advances by the process count per optimizer step
+    seen = []
+    tr.lr_lambda = lambda e: (seen.append(e), 1.0)[1]
     tr.world = 4
-    tr.global_step = 5
+    tr._all_reduce_grads = lambda: None          # no process group in this test: only the schedule arithmetic is exercised
+    tr.optimizer_step()
+    assert seen == [24] and tr.sched_epoch == 28 and tr.global_step == 4
     tr.save_accelerate_state(str(tmp_path / "checkpoint-5"))
-    assert torch.load(tmp_path / "checkpoint-5" / "scheduler.bin")["last_epoch"] == 20
+    sd = torch.load(tmp_path / "checkpoint-5" / "scheduler.bin", weights_only=False)
+    assert sd["last_epoch"] == 28 and sd["_step_count"] == 29
+    # ... and the file is a complete LambdaLR state dict: torch's own scheduler loads it (what accelerate.load_state does)
+    sch = torch.optim.lr_scheduler.LambdaLR(torch.optim.SGD([torch.zeros(1, requires_grad=True)], lr=1e-3), lambda e: 1.0)
+    sch.load_state_dict(sd)
+    assert sch.last_epoch == 28
 
 
 def test_adapter_packs_are_refreshed_behind_flat_updates(monkeypatch):
@@ -126,6 +137,87 @@ def test_adapter_packs_are_refreshed_behind_flat_updates(monkeypatch):
         monkeypatch.setattr(ops, "repack_adapters", lambda: calls.append(1))
         tr.load_state_dict(tr.state_dict())
         assert calls, "load_state_dict must refresh the adapter operand packs"
+
+
+def test_hint_encoder_conv_operands_are_persistent_and_refreshed():
+    """Round 6: the fp16 GEMM operands of the trainable hint-encoder convolutions (reference models.py:470, 529, 594-597, 684) are
+    persistent buffers refreshed by ONE multi-job launch per optimizer step (ops.TRAIN_CONV_PACKS) instead of one launch per
+    convolution per forward, and the staging -> OIHW gradient unpack of all of them is ONE launch at the end of the backward.
+    (a) multi-job pack == single-job pack, bit for bit; (b) an in-place torch update (the _version moves) is caught at the point of
+    use; (c) a flat-buffer update (no _version change) is stale until repack_adapters(), which the trainer calls after AdamW;
+    (d) deferred multi-job unpack == immediate single-job unpack on the gradients of a whole hint-encoder backward."""
+    from controllora_amd import kernels as K
+    from controllora_amd import ops
+    from tests.emu_fixture import use_emulator
+    with use_emulator():
+        g = torch.Generator().manual_seed(3)
+        ws = [torch.nn.Parameter(torch.randn(16, 3, 3, 3, generator=g)), torch.nn.Parameter(torch.randn(24, 16, 3, 3, generator=g)),
+              torch.nn.Parameter(torch.randn(40, 24, 1, 1, generator=g))]
+        cips = [8, 16, 24]
+        single = [K.conv_weight_pack(w.detach(), cip, True) for w, cip in zip(ws, cips)]
+        packs = ops._TrainConvPacks()
+        got = [packs.get(w, cip, True) for w, cip in zip(ws, cips)]
+        for (f1, d1), (f2, d2) in zip(single, got):
+            assert torch.equal(f1, f2) and torch.equal(d1, d2)
+        ptrs = [f.data_ptr() for f, _ in got]
+        with torch.no_grad():
+            ws[0].mul_(2.0)                                   # torch-visible update: caught by the version check
+        f0, _ = packs.get(ws[0], cips[0], True)
+        assert f0.data_ptr() == ptrs[0] and torch.equal(f0, K.conv_weight_pack(ws[0].detach(), cips[0], True)[0])
+        with torch.no_grad():
+            ws[1].data.mul_(0.5)                              # what the flat AdamW kernel does: bytes change, _version does not
+            ws[2].data.add_(1.0)
+        stale, _ = packs.get(ws[1], cips[1], True)
+        assert torch.equal(stale, single[1][0])
+        packs.repack_all()                                    # ONE launch for all three
+        for w, cip, p0 in zip(ws, cips, ptrs):
+            f, d = packs.get(w, cip, True)
+            f1, d1 = K.conv_weight_pack(w.detach(), cip, True)
+            assert f.data_ptr() == p0 and torch.equal(f, f1) and torch.equal(d, d1)
+        # (d) the same hint-encoder backward with the deferred multi-job unpack and with one unpack per convolution
+        grads = {}
+        for defer in (True, False):
+            K.DEFER_UNPACK = defer
+            _, clora, _ = E.build_product_case("v1", "cpu")
+            from oracle import cases
+            outs = clora(cases.seeded_inputs()["guide"].half()).control_states
+            loss = sum((o.float() ** 2).sum() for o in outs)
+            loss.backward()
+            K.lora_wgrad_flush()
+            grads[defer] = [p.grad.clone() for n, p in clora.named_parameters() if p.grad is not None and p.ndim == 4]
+        K.DEFER_UNPACK = True
+        assert len(grads[True]) == len(grads[False]) >= 5
+        for a, b in zip(grads[True], grads[False]):
+            assert torch.allclose(a, b, rtol=1e-5, atol=1e-6 * float(b.abs().max()))      # fp32 atomics: order differs run to run
+
+
+@pytest.mark.parametrize("case", ["v1", "v2", "lora"])
+def test_grouped_text_kv_projection_equals_per_site(case):
+    """Round 6: in training the k | v projections of all cross-attention sites of one width run as ONE GEMM at the head of the UNet
+    forward (ops.TextKVGroup; reference models.py:128-136, 249-265 evaluates them site by site) and their adapters' backward as one
+    multi-job launch after the group's last site: same prediction and same gradients as the per-site path."""
+    from controllora_amd import ops
+    from tests.emu_fixture import use_emulator
+    res = {}
+    with use_emulator():
+        for grouped in (True, False):
+            ops.GROUP_TEXT_KV = grouped
+            calls = []
+            orig = ops.TextKVGroup.__init__
+
+            def spy(self, *a, **k):
+                calls.append(1)
+                return orig(self, *a, **k)
+            ops.TextKVGroup.__init__ = spy
+            try:
+                out, _ = E.run_product_step(case, "cpu")
+            finally:
+                ops.TextKVGroup.__init__ = orig
+                ops.GROUP_TEXT_KV = True
+            assert bool(calls) == grouped, (grouped, len(calls))
+            res[grouped] = out
+    assert E.rel(res[True]["pred"], res[False]["pred"]) < 1e-6
+    assert E.rel(res[True]["grads"], res[False]["grads"]) < 2e-5, E.rel(res[True]["grads"], res[False]["grads"])
 
 
 def test_vae_encode_decode_matches_oracle():

@@ -34,7 +34,10 @@ pytestmark = pytest.mark.gpu
 # different tile / split-K choice of the tuner or a compiler update moves a summation order and the last digits, not the regime.
 FIX_EXPECT = dict(pred=2.2e-3, loss=1e-4, grads=5.5e-4, grads_norm=1.6e-4, control=3.7e-3, control_norm=3.5e-5, param_norm=2.5e-3,
                   eps=2.1e-3, latents=2.5e-3)
-FIX_TOL = dict(pred=2.5e-3, loss=1e-4, grads=8e-4, grads_norm=2e-4, control=4.4e-3, control_norm=5e-5, param_norm=3.5e-3,
+# Round 6: only the three quantities with a cited regime bound (pred / eps: 2.50e-3, latents: 2.85e-3) are asserted against
+# it; gradients, control maps and per-parameter norms have no measured fp16-regime figure, so their ASSERTED limits stay at the round-4
+# values (1.3x the bit-stable measurements) -- a precision regression there fails instead of printing a NOTE.
+FIX_TOL = dict(pred=2.5e-3, loss=1e-4, grads=5.5e-4, grads_norm=1.6e-4, control=3.7e-3, control_norm=3.5e-5, param_norm=2.5e-3,
                eps=2.5e-3, latents=2.85e-3)
 
 

@@ -184,7 +184,9 @@ def main(argv=None):
         # precision normally comes from `accelerate launch --mixed_precision fp16`): a seed gradient of 2/n ~ 1e-5 is
         # subnormal in fp16, so loss scaling with the dynamic GradScaler is ALWAYS on for this path.
         init_scale=65536.0, dynamic_scale=True, gradient_accumulation_steps=args.gradient_accumulation_steps,
-        lr_lambda=data.lr_lambda(args.lr_scheduler, args.lr_warmup_steps, args.max_train_steps))
+        # schedule units as the reference builds them (train...:675-680); the trainer evaluates it at optimizer step x world
+        lr_lambda=data.lr_lambda(args.lr_scheduler, args.lr_warmup_steps * args.gradient_accumulation_steps,
+                                 args.max_train_steps * args.gradient_accumulation_steps))
 
     global_step, first_epoch, resume_step = 0, 0, 0
     if args.resume_from_checkpoint:
