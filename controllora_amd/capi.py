@@ -16,7 +16,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CLORA_LIB_PATH") or os.path.join(_HERE, "_build", "libclora.so")   # override: A/B of kernel builds
 
-ABI_VERSION = 2                          # CLORA_ABI_VERSION of include/clora.h
+ABI_VERSION = 3                          # CLORA_ABI_VERSION of include/clora.h
 OK, ERR_ARG, ERR_LAUNCH, ERR_WORKSPACE = 0, -1, -2, -3
 _ERR = {ERR_ARG: "bad argument", ERR_LAUNCH: "kernel launch failed", ERR_WORKSPACE: "workspace too small"}
 
@@ -39,7 +39,13 @@ class Epilogue(C.Structure):
                 ("lora_u", C.c_void_p), ("ldu", C.c_int), ("lora_u_tr", C.c_int), ("lora_r", C.c_int), ("lora_seg", C.c_int), ("lora_scale", C.c_float),
                 ("geglu", C.c_int), ("geglu_f", C.c_int), ("geglu_h", C.c_void_p), ("geglu_y", C.c_void_p),
                 ("lora_dpack", C.c_void_p), ("lora_t_in", C.c_void_p), ("ldt_in", C.c_int), ("lora_t_in_rows", C.c_int),
-                ("lora_t_in_mask", C.c_uint)]
+                ("lora_t_in_mask", C.c_uint), ("defer", C.c_void_p)]
+
+
+class Deferred(C.Structure):
+    """mirror of clora_deferred_t: a split-K GEMM whose finish pass is left to the consumer of its output"""
+    _fields_ = [("partial", C.c_void_p), ("splits", C.c_int), ("M", C.c_int), ("N", C.c_int), ("C", C.c_void_p), ("ldc", C.c_int),
+                ("epi", Epilogue)]
 
 
 class LoraPackJob(C.Structure):
@@ -108,6 +114,10 @@ _PROTOS = {
     "clora_attn_bwd_f16": [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _F, _P, _Z, _P],
     "clora_groupnorm_fwd_f16": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P, _Z, _P],
     "clora_groupnorm_bwd_f16": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _Z, _P],
+    "clora_groupnorm_fwd_f16_ex": [_P, _P, _I, C.POINTER(Deferred), _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P, _Z, _P],
+    "clora_groupnorm_bwd_f16_ex": [_P, _P, C.POINTER(Deferred), _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _Z, _P],
+    "clora_layernorm_bwd_f16_ex": [_P, _P, C.POINTER(Deferred), _P, _P, _P, _I, _I, _F, _P],
+    "clora_finish_deferred": [C.POINTER(Deferred), _P],
     "clora_layernorm_fwd_f16": [_P, _P, _P, _P, _I, _I, _F, _P],
     "clora_softmax_rows_f16": [_P, _P, _I, _I, _I, _F, _P],
     "clora_layernorm_bwd_f16": [_P, _P, _P, _P, _P, _I, _I, _F, _P],

@@ -17,6 +17,7 @@
 #include <string.h>
 #include "clora_common.h"
 #include "../../include/clora.h"
+#include "clora_epilogue.h"
 
 namespace {
 
@@ -35,151 +36,6 @@ struct GemmArgs {
     clora_conv_t conv;
     clora_epilogue_t epi;
 };
-
-// everything of the epilogue that happens BEFORE the fp16 rounding (scalar form: split-K finish, v1 kernel)
-__device__ __forceinline__ float epi_pre(float acc, int m, int n, const clora_epilogue_t& e) {
-    if (e.bias) acc += e.bias[n];
-    if (e.rowadd) acc += (float)((const half_t*)e.rowadd)[(size_t)(m / e.rows_per_batch) * e.ld_rowadd + n];
-    if (e.lora_t) {
-        const int r = e.lora_r;
-        const float* t = e.lora_t + (size_t)m * e.ldt + (n / e.lora_seg) * r;
-        float s = 0.f;
-        if (e.lora_u_tr) {
-            const float* u = e.lora_u + n;
-            for (int j = 0; j < r; ++j) s += t[j] * u[(size_t)j * e.ldu];
-        } else {
-            const float* u = e.lora_u + (size_t)n * e.ldu;
-            for (int j = 0; j < r; ++j) s += t[j] * u[j];
-        }
-        acc += e.lora_scale * s;
-    }
-    return acc;
-}
-
-// Row-chunk form: 8 consecutive columns n..n+7 of row m (n % 8 == 0, lora_seg % 16 == 0 so the chunk belongs to
-// one adapter).  Bias, U and the rank-r row of T are fetched with float4 loads -- instead of 2r scalar loads
-// per output element.  Used by the LDS-staged epilogue of the DMA kernel and by the split-K finish kernel.
-__device__ __forceinline__ void epi_chunk8(float (&v)[8], int m, int n, const clora_epilogue_t& e) {
-    if (e.bias) {
-        const floatx4 b0 = *reinterpret_cast<const floatx4*>(e.bias + n), b1 = *reinterpret_cast<const floatx4*>(e.bias + n + 4);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { v[q] += b0[q]; v[4 + q] += b1[q]; }
-    }
-    if (e.rowadd) {
-        const half8 ra = ld8((const half_t*)e.rowadd + (size_t)(m / e.rows_per_batch) * e.ld_rowadd + n);
-#pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] += (float)ra[q];
-    }
-    if (e.lora_t) {
-        const int R = e.lora_r;
-        const int toff = (n / e.lora_seg) * R;
-        const float* tp = e.lora_t + (size_t)m * e.ldt + toff;
-        const bool tvec = ((e.ldt | toff) & 3) == 0;
-        for (int j0 = 0; j0 < R; j0 += 4) {
-            floatx4 t = zero4f();
-            if (j0 + 4 <= R && tvec) t = *reinterpret_cast<const floatx4*>(tp + j0);
-            else {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) if (j0 + q < R) t[q] = tp[j0 + q];
-            }
-            t *= e.lora_scale;
-            if (e.lora_u_tr) {                       // u(n, j) = U[j*ldu + n]: contiguous along n
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if (j0 + q < R) {
-                        const float* up = e.lora_u + (size_t)(j0 + q) * e.ldu + n;
-#pragma unroll
-                        for (int c = 0; c < 8; ++c) v[c] += t[q] * up[c];
-                    }
-            } else if (j0 + 4 <= R && (e.ldu & 3) == 0) {
-#pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    const floatx4 u = *reinterpret_cast<const floatx4*>(e.lora_u + (size_t)(n + c) * e.ldu + j0);
-                    v[c] += t[0] * u[0] + t[1] * u[1] + t[2] * u[2] + t[3] * u[3];
-                }
-            } else {
-#pragma unroll
-                for (int c = 0; c < 8; ++c)
-                    for (int q = 0; q < 4; ++q)
-                        if (j0 + q < R) v[c] += t[q] * e.lora_u[(size_t)(n + c) * e.ldu + j0 + q];
-            }
-        }
-    }
-}
-
-// Split-K finish kernel only.  Inside epi_chunk8 every `if (e.bias) / if (e.rowadd) / if (e.lora_t)` is its own basic block with
-// load -> wait -> use, and the residual comes after all of them: four to five dependent L1 / L2 round trips per output chunk.
-// Here the operands that do not depend on the accumulators are requested together, before the slab values are touched.
-// (The tile epilogues keep epi_chunk8 exactly as it is: they are register-bound -- requesting the operands, or only the
-// residual, at the top of a chunk spilled accumulators in the occupancy-bounded kernels (64x64 BK32: 0 -> 60..84 B,
-// 128x128 BK32: 88 -> 184..216 B, patch 128x64: 116 -> 124..132 VGPRs), and even an unused extra parameter on epi_chunk8
-// changed their allocation.)
-struct EpiOps {
-    floatx4 b0, b1, t4;
-    half8 ra;
-    bool have;
-    bool have_t;        // t4 holds the first four T values of the row (rank >= 4, 16-byte aligned)
-};
-
-__device__ __forceinline__ void epi_issue(EpiOps& o, int m, int n, const clora_epilogue_t& e) {
-    o.have = true;
-    o.b0 = zero4f(); o.b1 = zero4f(); o.t4 = zero4f(); o.ra = zero8();
-    if (e.bias) { o.b0 = *reinterpret_cast<const floatx4*>(e.bias + n); o.b1 = *reinterpret_cast<const floatx4*>(e.bias + n + 4); }
-    if (e.rowadd) o.ra = ld8((const half_t*)e.rowadd + (size_t)(m / e.rows_per_batch) * e.ld_rowadd + n);
-    o.have_t = e.lora_t && e.lora_r >= 4 && (e.ldt & 3) == 0 && (e.lora_r & 3) == 0;       // uniform: toff is a multiple of 4 then
-    if (o.have_t) o.t4 = *reinterpret_cast<const floatx4*>(e.lora_t + (size_t)m * e.ldt + (n / e.lora_seg) * e.lora_r);
-}
-
-__device__ __forceinline__ void epi_chunk8_pre(float (&v)[8], int m, int n, const clora_epilogue_t& e, const EpiOps* pre) {
-    if (e.bias) {
-        floatx4 b0, b1;
-        if (pre) { b0 = pre->b0; b1 = pre->b1; }
-        else { b0 = *reinterpret_cast<const floatx4*>(e.bias + n); b1 = *reinterpret_cast<const floatx4*>(e.bias + n + 4); }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { v[q] += b0[q]; v[4 + q] += b1[q]; }
-    }
-    if (e.rowadd) {
-        const half8 ra = pre ? pre->ra : ld8((const half_t*)e.rowadd + (size_t)(m / e.rows_per_batch) * e.ld_rowadd + n);
-#pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] += (float)ra[q];
-    }
-    if (e.lora_t) {
-        const int R = e.lora_r;
-        const int toff = (n / e.lora_seg) * R;
-        const float* tp = e.lora_t + (size_t)m * e.ldt + toff;
-        const bool tvec = ((e.ldt | toff) & 3) == 0;
-        for (int j0 = 0; j0 < R; j0 += 4) {
-            floatx4 t = zero4f();
-            if (j0 == 0 && pre && pre->have_t) t = pre->t4;
-            else if (j0 + 4 <= R && tvec) t = *reinterpret_cast<const floatx4*>(tp + j0);
-            else {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) if (j0 + q < R) t[q] = tp[j0 + q];
-            }
-            t *= e.lora_scale;
-            if (e.lora_u_tr) {                       // u(n, j) = U[j*ldu + n]: contiguous along n
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if (j0 + q < R) {
-                        const float* up = e.lora_u + (size_t)(j0 + q) * e.ldu + n;
-#pragma unroll
-                        for (int c = 0; c < 8; ++c) v[c] += t[q] * up[c];
-                    }
-            } else if (j0 + 4 <= R && (e.ldu & 3) == 0) {
-#pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    const floatx4 u = *reinterpret_cast<const floatx4*>(e.lora_u + (size_t)(n + c) * e.ldu + j0);
-                    v[c] += t[0] * u[0] + t[1] * u[1] + t[2] * u[2] + t[3] * u[3];
-                }
-            } else {
-#pragma unroll
-                for (int c = 0; c < 8; ++c)
-                    for (int q = 0; q < 4; ++q)
-                        if (j0 + q < R) v[c] += t[q] * e.lora_u[(size_t)(n + c) * e.ldu + j0 + q];
-            }
-        }
-    }
-}
 
 template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
@@ -1398,45 +1254,7 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(GemmArgs p, int spli
     for (size_t c = (size_t)blockIdx.x * 256 + threadIdx.x; c < chunks; c += (size_t)gridDim.x * 256) {
         const int m = (int)(c / (p.N / 8));
         const int n = (int)(c - (size_t)m * (p.N / 8)) * 8;
-        float s[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) s[e] = 0.f;
-        const size_t zs = (size_t)p.M * p.N;                     // floats between consecutive slabs
-        const float* q0 = p.partial + (size_t)m * p.N + n;
-        // the chunk's epilogue operands and residual travel together with the first slab loads (they were four more dependent
-        // round trips after the fold)
-        EpiOps ops;
-        epi_issue(ops, m, n, p.epi);
-        half8 rr = zero8();
-        if (p.epi.residual) rr = ld8((const half_t*)p.epi.residual + (size_t)m * p.epi.ldr + n);
-        int z = 0;
-        for (; z + 4 <= splits; z += 4) {                        // four slabs' loads in flight (a load -> wait -> add loop paid one
-            floatx4 a[4], b[4];                                  // L2 / HBM round trip per slab: up to 12 per output chunk)
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                a[u] = *reinterpret_cast<const floatx4*>(q0 + (size_t)(z + u) * zs);
-                b[u] = *reinterpret_cast<const floatx4*>(q0 + (size_t)(z + u) * zs + 4);
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { s[e] += a[u][e]; s[4 + e] += b[u][e]; }
-        }
-        for (; z < splits; ++z) {
-            const floatx4 a = *reinterpret_cast<const floatx4*>(q0 + (size_t)z * zs);
-            const floatx4 b = *reinterpret_cast<const floatx4*>(q0 + (size_t)z * zs + 4);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { s[e] += a[e]; s[4 + e] += b[e]; }
-        }
-        epi_chunk8_pre(s, m, n, p.epi, &ops);
-        half8 v;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = (half_t)s[e];
-        if (p.epi.residual) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)rr[e]);
-        }
-        st8(p.C + (size_t)m * p.ldc + n, v);
+        st8(p.C + (size_t)m * p.ldc + n, finish_chunk8(p.partial, splits, p.M, p.N, p.epi, m, n));     // clora_epilogue.h
     }
 }
 
@@ -1765,6 +1583,21 @@ int launch_patch(GemmArgs& a, int splits, hipStream_t s) {
     return clora_check_launch();
 }
 
+// split-K launches: the finish pass (slabs -> epilogue -> C), or -- clora_epilogue_t.defer -- its description for the consumer of C
+int finish_or_defer(GemmArgs& a, int splits, clora_deferred_t* defer, hipStream_t s) {
+    if (defer) {
+        defer->partial = a.partial; defer->splits = splits; defer->M = a.M; defer->N = a.N; defer->C = (clora_half*)a.C; defer->ldc = a.ldc;
+        defer->epi = a.epi;
+        defer->epi.defer = nullptr;
+        return CLORA_OK;
+    }
+    const size_t chunks = (size_t)a.M * (a.N / 8);
+    int blocks = (int)((chunks + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(splitk_finish_kernel, dim3(blocks), dim3(256), 0, s, a, splits);
+    return clora_check_launch();
+}
+
 }  // namespace
 
 // ---- launch planning --------------------------------------------------------------------------------
@@ -1820,6 +1653,13 @@ extern "C" int clora_gemm_f16_ex(const clora_half* A, int lda, const clora_half*
         if (lda & 7) return CLORA_ERR_ARG;
     }
     if (epi) a.epi = *epi; else a.epi = clora_epilogue_t();
+    clora_deferred_t* const defer = a.epi.defer;             // host-side request: never travels in the kernel arguments
+    a.epi.defer = nullptr;
+    if (defer) {
+        if (a.epi.geglu) return CLORA_ERR_ARG;
+        defer->splits = 0;                                   // until a split-K launch below says otherwise
+        defer->partial = nullptr;
+    }
     if (a.epi.lora_t && (a.epi.lora_r <= 0 || a.epi.lora_seg <= 0 || (a.epi.lora_seg & 15))) return CLORA_ERR_ARG;
     if (a.epi.rowadd && a.epi.rows_per_batch <= 0) return CLORA_ERR_ARG;
     if (a.epi.residual && (a.epi.ldr & 7)) return CLORA_ERR_ARG;
@@ -1923,13 +1763,7 @@ extern "C" int clora_gemm_f16_ex(const clora_half* A, int lda, const clora_half*
                 default: rc = launch_patch<128, 160, 4, 2, 3>(a, splits, s); break;
             }
             if (rc != CLORA_OK) return rc;
-            if (splits > 1) {
-                const size_t chunks = (size_t)M * (N / 8);
-                int blocks = (int)((chunks + 255) / 256);
-                if (blocks > 2048) blocks = 2048;
-                hipLaunchKernelGGL(splitk_finish_kernel, dim3(blocks), dim3(256), 0, s, a, splits);
-                rc = clora_check_launch();
-            }
+            if (splits > 1) rc = finish_or_defer(a, splits, defer, s);
             return rc;
         }
     }
@@ -1991,14 +1825,16 @@ extern "C" int clora_gemm_f16_ex(const clora_half* A, int lda, const clora_half*
         default: return CLORA_ERR_ARG;
     }
     if (rc != CLORA_OK) return rc;
-    if (splits > 1) {
-        const size_t chunks = (size_t)M * (N / 8);
-        int blocks = (int)((chunks + 255) / 256);
-        if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(splitk_finish_kernel, dim3(blocks), dim3(256), 0, s, a, splits);
-        rc = clora_check_launch();
-    }
+    if (splits > 1) rc = finish_or_defer(a, splits, defer, s);
     return rc;
+}
+
+extern "C" int clora_finish_deferred(const clora_deferred_t* d, void* stream) {
+    if (!d || !d->partial || !d->C || d->splits <= 1 || d->M <= 0 || d->N <= 0 || (d->N & 7) || (d->ldc & 7)) return CLORA_ERR_ARG;
+    GemmArgs a = GemmArgs();
+    a.partial = const_cast<float*>(d->partial); a.C = (half_t*)d->C; a.ldc = d->ldc; a.M = d->M; a.N = d->N; a.epi = d->epi;
+    a.epi.defer = nullptr;
+    return finish_or_defer(a, d->splits, nullptr, (hipStream_t)stream);
 }
 
 int clora_option(int id) { return (id >= 0 && id < CLORA_OPT_COUNT) ? g_opts[id] : 0; }

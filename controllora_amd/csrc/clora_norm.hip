@@ -11,6 +11,7 @@
 #include <stdlib.h>
 #include "clora_common.h"
 #include "../../include/clora.h"
+#include "clora_epilogue.h"
 
 namespace {
 
@@ -34,7 +35,32 @@ struct GnArgs {
     int nslab, CS;  // channel slabs (whole groups, multiple of 8 channels) = blockIdx.y: fills the chip at low resolution
     float eps;
     int fuse_silu;
+    // round 6 (include/clora.h clora_groupnorm_*_ex)
+    const half_t* x2;     // fwd: channels [Ca, C) of the input live in x2 [B*HW, C - Ca], x is [B*HW, Ca] (nullptr: x is [B*HW, C])
+    int Ca;
+    half_t* xcopy;        // fwd, optional: the raw input as one contiguous [B*HW, C] tensor (concatenated / finished)
+    half_t* y2;           // bwd, optional: dx of channels [Ca, C) goes to y2 [B*HW, C - Ca], y holds [B*HW, Ca]
+    const float* fin_partial;   // deferred split-K producer of x (fwd) / dy (bwd): slabs [fin_splits][B*HW][C] + its epilogue
+    int fin_splits;
+    clora_epilogue_t fin_epi;
 };
+
+// where a thread's 8-channel chunk (first channel ch0, a multiple of 8; Ca % 8 == 0) of the input lives: base pointer at row 0 of batch
+// element 0 and the row pitch in halves -- one tensor, or the two halves of a channel concatenation
+struct GnCol { const half_t* p; int pitch; };
+__device__ __forceinline__ GnCol gn_in_col(const GnArgs& a, int ch0) {
+    GnCol c;
+    if (a.x2 && ch0 >= a.Ca) { c.p = a.x2 + (ch0 - a.Ca); c.pitch = a.C - a.Ca; }
+    else { c.p = a.x + ch0; c.pitch = a.x2 ? a.Ca : a.C; }
+    return c;
+}
+struct GnColW { half_t* p; int pitch; };
+__device__ __forceinline__ GnColW gn_dx_col(const GnArgs& a, int ch0) {
+    GnColW c;
+    if (a.y2 && ch0 >= a.Ca) { c.p = a.y2 + (ch0 - a.Ca); c.pitch = a.C - a.Ca; }
+    else { c.p = a.y + ch0; c.pitch = a.y2 ? a.Ca : a.C; }
+    return c;
+}
 
 // thread -> (row lane, first column chunk, column stride)
 __device__ __forceinline__ void gn_thread_map(int t, int CH, int& rl, int& nrl, int& c0, int& cstep, bool& active) {
@@ -109,18 +135,18 @@ __global__ __launch_bounds__(256) void gn_fwd_partial_kernel(GnArgs p) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) { s[j][e] = 0.f; q[j][e] = 0.f; }
     if (active) {
-        const half_t* base = p.x + (size_t)b * p.HW * p.C + cb;
+        GnCol col[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) { const int cc = c0 + j * cstep; col[j] = gn_in_col(p, cb + (cc < CH ? cc : c0) * 8); }
+        const size_t brow = (size_t)b * p.HW;
         for (int it0 = 0; it0 < nit; it0 += kGnU) {
             half8 v[kGnU][NJ];
 #pragma unroll
             for (int u = 0; u < kGnU; ++u) {                     // every load of the batch first ...
                 const int r = r_beg + rl + (it0 + u) * nrl;
-                const half_t* row = base + (size_t)(r < r_end ? r : r_beg) * p.C;
+                const size_t row = brow + (size_t)(r < r_end ? r : r_beg);
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) {
-                    const int cc = c0 + j * cstep;
-                    v[u][j] = ld8(row + (cc < CH ? cc : c0) * 8);
-                }
+                for (int j = 0; j < NJ; ++j) v[u][j] = ld8(col[j].p + row * col[j].pitch);
             }
 #pragma unroll
             for (int u = 0; u < kGnU; ++u) {                     // ... then the sums, rows past the chunk masked to zero
@@ -268,17 +294,18 @@ __global__ __launch_bounds__(256) void gn_fwd_apply2_kernel(GnArgs p) {
     const int r_end = (r_beg + p.rows_per_chunk < p.HW) ? r_beg + p.rows_per_chunk : p.HW;
     const int nit = (r_end - r_beg + nrl - 1) / nrl;              // block-uniform
     const size_t boff = (size_t)b * p.HW * p.C + cb;
+    GnCol col[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) { const int cc = c0 + j * cstep; col[j] = gn_in_col(p, cb + (cc < CH ? cc : c0) * 8); }
+    const size_t brow = (size_t)b * p.HW;
     for (int it0 = 0; it0 < nit; it0 += kGnU) {
         half8 v[kGnU][NJ];
 #pragma unroll
         for (int u = 0; u < kGnU; ++u) {
             const int r = r_beg + rl + (it0 + u) * nrl;
-            const size_t off = boff + (size_t)(r < r_end ? r : r_beg) * p.C;
+            const size_t row = brow + (size_t)(r < r_end ? r : r_beg);
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const int cc = c0 + j * cstep;
-                v[u][j] = ld8(p.x + off + (cc < CH ? cc : c0) * 8);
-            }
+            for (int j = 0; j < NJ; ++j) v[u][j] = ld8(col[j].p + row * col[j].pitch);
         }
 #pragma unroll
         for (int u = 0; u < kGnU; ++u) {
@@ -295,7 +322,10 @@ __global__ __launch_bounds__(256) void gn_fwd_apply2_kernel(GnArgs p) {
                     if (p.fuse_silu) yv = silu_f(yv);
                     o[e] = (half_t)yv;
                 }
-                if (r < r_end && cc < CH) st8(p.y + off + cc * 8, o);   // ... only the store is conditional
+                if (r < r_end && cc < CH) {                      // ... only the stores are conditional
+                    st8(p.y + off + cc * 8, o);
+                    if (p.xcopy) st8(p.xcopy + off + cc * 8, v[u][j]);      // the concatenated input, once, for the shortcut / backward
+                }
             }
         }
     }
@@ -370,7 +400,10 @@ __global__ __launch_bounds__(256) void gn_bwd_apply2_kernel(GnArgs p) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) o[e] = (half_t)((float)o[e] + (float)rv[u][j][e]);
                 }
-                if (r < r_end && cc < CH) st8(p.y + off + cc * 8, o);
+                if (r < r_end && cc < CH) {
+                    const GnColW dc = gn_dx_col(p, cb + cc * 8);
+                    st8(dc.p + ((size_t)b * p.HW + r) * dc.pitch, o);
+                }
             }
         }
     }
@@ -454,7 +487,9 @@ __device__ __forceinline__ void gn_res_reduce(float* red, float* chs, const floa
     __syncthreads();
 }
 
-template <int NT, int NPT>
+// DEF: x is a deferred split-K GEMM (GnArgs.fin_*): every chunk is folded from the slabs with the GEMM's own epilogue while it is
+// loaded (finish_chunk8: the bits the finish kernel would have stored) and written back once through xcopy.
+template <int NT, int NPT, bool DEF = false>
 __global__ __launch_bounds__(NT) void gn_fwd_resident_kernel(GnArgs p) {
     __shared__ float red[NT * 16];                               // [nrl][CS][2] with nrl * CS <= NT * 8
     __shared__ float chs[256 * 8 * 2];                           // per-channel totals of the slab (CS <= 2048)
@@ -464,7 +499,8 @@ __global__ __launch_bounds__(NT) void gn_fwd_resident_kernel(GnArgs p) {
     const int nrl = NT / CH, rl = t / CH, c0 = t - rl * CH;
     const bool active = rl < nrl;
     const int npt = (p.HW + nrl - 1) / nrl;                      // block-uniform, <= NPT
-    const half_t* base = p.x + (size_t)b * p.HW * p.C + cb + c0 * 8;
+    const GnCol col = gn_in_col(p, cb + (active ? c0 : 0) * 8);
+    const size_t brow = (size_t)b * p.HW;
     // the affine parameters of this thread's eight channels travel with the x loads (they were a second dependent round trip after
     // the reduction)
     const floatx4* gp = reinterpret_cast<const floatx4*>(p.gamma + cb + c0 * 8);
@@ -478,7 +514,12 @@ __global__ __launch_bounds__(NT) void gn_fwd_resident_kernel(GnArgs p) {
 #pragma unroll
         for (int k = 0; k < NPT; ++k) {
             const int r = rl + k * nrl;
-            v[k] = (k < npt) ? ld8(base + (size_t)(r < p.HW ? r : 0) * p.C) : zero8();
+            if constexpr (DEF) {
+                v[k] = zero8();
+                if (k < npt) v[k] = finish_chunk8(p.fin_partial, p.fin_splits, p.B * p.HW, p.C, p.fin_epi, (int)(brow + (r < p.HW ? r : 0)), cb + c0 * 8);
+            } else {
+                v[k] = (k < npt) ? ld8(col.p + (brow + (size_t)(r < p.HW ? r : 0)) * col.pitch) : zero8();
+            }
         }
 #pragma unroll
         for (int k = 0; k < NPT; ++k) {
@@ -517,11 +558,14 @@ __global__ __launch_bounds__(NT) void gn_fwd_resident_kernel(GnArgs p) {
             if (p.fuse_silu) yv = silu_f(yv);
             o[e] = (half_t)yv;
         }
-        if (k < npt && r < p.HW) st8(ybase + (size_t)r * p.C, o);
+        if (k < npt && r < p.HW) {
+            st8(ybase + (size_t)r * p.C, o);
+            if (p.xcopy) st8(p.xcopy + (size_t)b * p.HW * p.C + cb + c0 * 8 + (size_t)r * p.C, v[k]);
+        }
     }
 }
 
-template <int NT, int NPT>
+template <int NT, int NPT, bool DEF = false>
 __global__ __launch_bounds__(NT) void gn_bwd_resident_kernel(GnArgs p) {
     __shared__ float red[NT * 16];
     __shared__ float chs[256 * 8 * 2];
@@ -551,7 +595,12 @@ __global__ __launch_bounds__(NT) void gn_bwd_resident_kernel(GnArgs p) {
             const int r = rl + k * nrl;
             const size_t off = boff + (size_t)(r < p.HW ? r : 0) * p.C;
             xv[k] = (k < npt) ? ld8(p.x + off) : zero8();
-            gv[k] = (k < npt) ? ld8(p.dy + off) : zero8();
+            if constexpr (DEF) {
+                gv[k] = zero8();
+                if (k < npt) gv[k] = finish_chunk8(p.fin_partial, p.fin_splits, p.B * p.HW, p.C, p.fin_epi, b * p.HW + (r < p.HW ? r : 0), cb + c0 * 8);
+            } else {
+                gv[k] = (k < npt) ? ld8(p.dy + off) : zero8();
+            }
         }
 #pragma unroll
         for (int k = 0; k < NPT; ++k) {
@@ -577,6 +626,7 @@ __global__ __launch_bounds__(NT) void gn_bwd_resident_kernel(GnArgs p) {
         k3[e] = -k2[e] * mean[e] - rstd[e] * gs[g * 2];
     }
     const bool has_res = p.dres != nullptr;
+    const GnColW dxc = gn_dx_col(p, cb + c0 * 8);
 #pragma unroll
     for (int k = 0; k < NPT; ++k) {
         const int r = rl + k * nrl;
@@ -595,7 +645,7 @@ __global__ __launch_bounds__(NT) void gn_bwd_resident_kernel(GnArgs p) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = (half_t)((float)o[e] + (float)rv[e]);
         }
-        st8(p.y + off, o);
+        st8(dxc.p + ((size_t)b * p.HW + r) * dxc.pitch, o);
     }
 }
 
@@ -609,6 +659,9 @@ struct LnArgs {
     const float* beta;
     int M, C;
     float eps;
+    const float* fin_partial;   // bwd: dy is a deferred split-K GEMM (slabs [fin_splits][M][C] + its epilogue), see GnArgs
+    int fin_splits;
+    clora_epilogue_t fin_epi;
 };
 
 template <bool BWD>
@@ -694,7 +747,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs p) {
 // 42 MB).  Here a wave issues the loads of ROWS rows (and gamma / beta, once) before the first reduction; per row the
 // arithmetic and its order are exactly those of layernorm_kernel, so the results are bit-identical.
 //   NC = 16-byte chunks per lane (C <= 512: 1, <= 1024: 2, <= 1536: 3)
-template <bool BWD, int NC, int ROWS>
+template <bool BWD, int NC, int ROWS, bool DEF = false>
 __global__ __launch_bounds__(256) void layernorm_rows_kernel(LnArgs p) {
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
     const int row0 = (blockIdx.x * 4 + w) * ROWS;
@@ -712,7 +765,11 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(LnArgs p) {
         for (int j = 0; j < NC; ++j) {                           // branch-free: lanes past the row re-read chunk 0 (never used),
             const int cc = l + 64 * j, cl = cc < CH ? cc : 0;    // so every load of the wave is issued back to back
             xv[r][j] = ld8(p.x + off + cl * 8);
-            if (BWD) { gv[r][j] = ld8(p.dy + off + cl * 8); rv[r][j] = ld8(res + off + cl * 8); }
+            if (BWD) {
+                if constexpr (DEF) gv[r][j] = finish_chunk8(p.fin_partial, p.fin_splits, p.M, p.C, p.fin_epi, rok ? row0 + r : row0, cl * 8);
+                else gv[r][j] = ld8(p.dy + off + cl * 8);
+                rv[r][j] = ld8(res + off + cl * 8);
+            }
         }
     }
 #pragma unroll
@@ -800,19 +857,24 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(LnArgs p) {
     }
 }
 
-template <bool BWD>
+// can the deferred-dy form run?  (the several-rows kernels only; the one-row fallback kernel has no deferred variant)
+bool ln_rows_plan(const LnArgs& a, bool bwd) {
+    const bool al16 = (((uintptr_t)a.gamma | (uintptr_t)(bwd ? a.gamma : a.beta)) & 15) == 0;
+    return clora_ln_rows() && a.C / 8 <= 192 && al16;
+}
+
+template <bool BWD, bool DEF = false>
 void launch_layernorm(const LnArgs& a, hipStream_t s) {
     const int CH = a.C / 8;
-    const bool al16 = (((uintptr_t)a.gamma | (uintptr_t)(BWD ? a.gamma : a.beta)) & 15) == 0;
-    if (clora_ln_rows() && CH <= 192 && al16) {
+    if (ln_rows_plan(a, BWD)) {
         if (a.M >= 2048) {                                       // enough rows to keep the chip full with fewer, fatter waves
-            if (CH <= 64) hipLaunchKernelGGL((layernorm_rows_kernel<BWD, 1, 4>), dim3(clora_cdiv(a.M, 16)), dim3(256), 0, s, a);
-            else if (CH <= 128) hipLaunchKernelGGL((layernorm_rows_kernel<BWD, 2, 2>), dim3(clora_cdiv(a.M, 8)), dim3(256), 0, s, a);
-            else hipLaunchKernelGGL((layernorm_rows_kernel<BWD, 3, 2>), dim3(clora_cdiv(a.M, 8)), dim3(256), 0, s, a);
+            if (CH <= 64) hipLaunchKernelGGL((layernorm_rows_kernel<BWD, 1, 4, DEF>), dim3(clora_cdiv(a.M, 16)), dim3(256), 0, s, a);
+            else if (CH <= 128) hipLaunchKernelGGL((layernorm_rows_kernel<BWD, 2, 2, DEF>), dim3(clora_cdiv(a.M, 8)), dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((layernorm_rows_kernel<BWD, 3, 2, DEF>), dim3(clora_cdiv(a.M, 8)), dim3(256), 0, s, a);
         } else {                                                 // few rows (16x16 level, text tokens): one row per wave, but its 1-3 chunk
-            if (CH <= 64) hipLaunchKernelGGL((layernorm_rows_kernel<BWD, 1, 1>), dim3(clora_cdiv(a.M, 4)), dim3(256), 0, s, a);        // loads (and dy, dres, gamma)
-            else if (CH <= 128) hipLaunchKernelGGL((layernorm_rows_kernel<BWD, 2, 1>), dim3(clora_cdiv(a.M, 4)), dim3(256), 0, s, a);  // issued together instead of
-            else hipLaunchKernelGGL((layernorm_rows_kernel<BWD, 3, 1>), dim3(clora_cdiv(a.M, 4)), dim3(256), 0, s, a);                 // one block per chunk
+            if (CH <= 64) hipLaunchKernelGGL((layernorm_rows_kernel<BWD, 1, 1, DEF>), dim3(clora_cdiv(a.M, 4)), dim3(256), 0, s, a);        // loads (and dy, dres, gamma)
+            else if (CH <= 128) hipLaunchKernelGGL((layernorm_rows_kernel<BWD, 2, 1, DEF>), dim3(clora_cdiv(a.M, 4)), dim3(256), 0, s, a);  // issued together instead of
+            else hipLaunchKernelGGL((layernorm_rows_kernel<BWD, 3, 1, DEF>), dim3(clora_cdiv(a.M, 4)), dim3(256), 0, s, a);                 // one block per chunk
         }
         return;
     }
@@ -956,18 +1018,45 @@ extern "C" size_t clora_groupnorm_workspace_bytes(int B, int HW, int C, int G, i
     return need * sizeof(float);
 }
 
-extern "C" int clora_groupnorm_fwd_f16(const clora_half* x, clora_half* y, const float* gamma, const float* beta,
-                                       float* stats, int B, int HW, int C, int G, float eps, int fuse_silu,
-                                       void* workspace, size_t workspace_bytes, void* stream) {
-    if (!x || !y || !gamma || !beta || !stats) return CLORA_ERR_ARG;
+namespace {
+// does the consumer take this deferred producer as it is (N == C, M == B*HW, contiguous C)?  else: plain finish first
+bool deferred_fits(const clora_deferred_t* d, int M, int C) {
+    return d && d->splits > 1 && d->partial && d->M == M && d->N == C && d->ldc == C && d->C;
+}
+}  // namespace
+
+extern "C" int clora_groupnorm_fwd_f16_ex(const clora_half* x, const clora_half* x2, int Ca, const clora_deferred_t* src, clora_half* xcopy,
+                                          clora_half* y, const float* gamma, const float* beta, float* stats, int B, int HW, int C,
+                                          int G, float eps, int fuse_silu, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!y || !gamma || !beta || !stats) return CLORA_ERR_ARG;
+    if (B <= 0 || HW <= 0 || C <= 0 || G <= 0 || G > 64 || (C % G) || (C & 7) || C > 4096) return CLORA_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const bool deferred = src && src->splits > 0;
+    if (deferred) {
+        if (x2 || !deferred_fits(src, B * HW, C)) return CLORA_ERR_ARG;
+        x = src->C;                                              // where the finished tensor lives / will live
+    }
+    if (!x || (x2 && (Ca <= 0 || Ca >= C || (Ca & 7)))) return CLORA_ERR_ARG;
     GnArgs a = GnArgs();
     a.x = (const half_t*)x; a.y = (half_t*)y; a.gamma = gamma; a.beta = beta; a.stats = stats;
     a.B = B; a.HW = HW; a.C = C; a.G = G; a.eps = eps; a.fuse_silu = fuse_silu;
-    if (B <= 0 || HW <= 0 || C <= 0 || G <= 0 || G > 64 || (C % G) || (C & 7) || C > 4096) return CLORA_ERR_ARG;
-    hipStream_t s = (hipStream_t)stream;
+    a.x2 = (const half_t*)x2; a.Ca = x2 ? Ca : C; a.xcopy = (half_t*)xcopy;
     const GnResident res = gn_resident_plan(a, false, false);
+    if (deferred && !res.nt) {                                   // two-pass plan: finish first, then the plain passes over src->C
+        const int rc = clora_finish_deferred(src, stream);
+        if (rc != CLORA_OK) return rc;
+    }
     if (res.nt) {
         const dim3 rgrid(1, a.nslab, B);
+        if (deferred) {
+            a.fin_partial = src->partial; a.fin_splits = src->splits; a.fin_epi = src->epi; a.xcopy = (half_t*)src->C;
+            if (res.nt == 256 && res.npt == 4) hipLaunchKernelGGL((gn_fwd_resident_kernel<256, 4, true>), rgrid, dim3(256), 0, s, a);
+            else if (res.nt == 256 && res.npt == 8) hipLaunchKernelGGL((gn_fwd_resident_kernel<256, 8, true>), rgrid, dim3(256), 0, s, a);
+            else if (res.nt == 256) hipLaunchKernelGGL((gn_fwd_resident_kernel<256, 16, true>), rgrid, dim3(256), 0, s, a);
+            else if (res.npt <= 8) hipLaunchKernelGGL((gn_fwd_resident_kernel<512, 8, true>), rgrid, dim3(512), 0, s, a);
+            else hipLaunchKernelGGL((gn_fwd_resident_kernel<512, 16, true>), rgrid, dim3(512), 0, s, a);
+            return clora_check_launch();
+        }
         if (res.nt == 256 && res.npt == 4) hipLaunchKernelGGL((gn_fwd_resident_kernel<256, 4>), rgrid, dim3(256), 0, s, a);
         else if (res.nt == 256 && res.npt == 8) hipLaunchKernelGGL((gn_fwd_resident_kernel<256, 8>), rgrid, dim3(256), 0, s, a);
         else if (res.nt == 256) hipLaunchKernelGGL((gn_fwd_resident_kernel<256, 16>), rgrid, dim3(256), 0, s, a);
@@ -993,20 +1082,46 @@ extern "C" int clora_groupnorm_fwd_f16(const clora_half* x, clora_half* y, const
     return clora_check_launch();
 }
 
-extern "C" int clora_groupnorm_bwd_f16(const clora_half* x, const clora_half* dy, const clora_half* dres, clora_half* dx, const float* gamma,
-                                       const float* beta, const float* stats, float* dgamma, float* dbeta, int B,
-                                       int HW, int C, int G, int fuse_silu, int accumulate_params, void* workspace,
-                                       size_t workspace_bytes, void* stream) {
-    if (!x || !dy || !dx || !gamma || !beta || !stats || ((dgamma == nullptr) != (dbeta == nullptr))) return CLORA_ERR_ARG;
+extern "C" int clora_groupnorm_fwd_f16(const clora_half* x, clora_half* y, const float* gamma, const float* beta,
+                                       float* stats, int B, int HW, int C, int G, float eps, int fuse_silu,
+                                       void* workspace, size_t workspace_bytes, void* stream) {
+    return clora_groupnorm_fwd_f16_ex(x, nullptr, 0, nullptr, nullptr, y, gamma, beta, stats, B, HW, C, G, eps, fuse_silu, workspace,
+                                      workspace_bytes, stream);
+}
+
+extern "C" int clora_groupnorm_bwd_f16_ex(const clora_half* x, const clora_half* dy, const clora_deferred_t* dy_src, const clora_half* dres,
+                                          clora_half* dx, clora_half* dx2, int Ca, const float* gamma, const float* beta,
+                                          const float* stats, float* dgamma, float* dbeta, int B, int HW, int C, int G, int fuse_silu,
+                                          int accumulate_params, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!x || !dx || !gamma || !beta || !stats || ((dgamma == nullptr) != (dbeta == nullptr))) return CLORA_ERR_ARG;
+    if (B <= 0 || HW <= 0 || C <= 0 || G <= 0 || G > 64 || (C % G) || (C & 7) || C > 4096) return CLORA_ERR_ARG;
+    if (dx2 && (Ca <= 0 || Ca >= C || (Ca & 7))) return CLORA_ERR_ARG;
+    const bool deferred = dy_src && dy_src->splits > 0;
+    if (deferred) {
+        if (!deferred_fits(dy_src, B * HW, C)) return CLORA_ERR_ARG;
+        dy = dy_src->C;
+    }
+    if (!dy) return CLORA_ERR_ARG;
     GnArgs a = GnArgs();
     a.x = (const half_t*)x; a.dy = (const half_t*)dy; a.dres = (const half_t*)dres; a.y = (half_t*)dx; a.gamma = gamma; a.beta = beta;
     a.stats = const_cast<float*>(stats); a.dgamma = dgamma; a.dbeta = dbeta;
     a.B = B; a.HW = HW; a.C = C; a.G = G; a.fuse_silu = fuse_silu; a.accumulate_params = accumulate_params;
-    if (B <= 0 || HW <= 0 || C <= 0 || G <= 0 || G > 64 || (C % G) || (C & 7) || C > 4096) return CLORA_ERR_ARG;
+    a.y2 = (half_t*)dx2; a.Ca = dx2 ? Ca : C;
     hipStream_t s = (hipStream_t)stream;
     const GnResident res = gn_resident_plan(a, true, dgamma != nullptr);
+    if (deferred && !res.nt) {
+        const int rc = clora_finish_deferred(dy_src, stream);
+        if (rc != CLORA_OK) return rc;
+    }
     if (res.nt) {
         const dim3 rgrid(1, a.nslab, B);
+        if (deferred) {
+            a.fin_partial = dy_src->partial; a.fin_splits = dy_src->splits; a.fin_epi = dy_src->epi;
+            if (res.nt == 256 && res.npt == 4) hipLaunchKernelGGL((gn_bwd_resident_kernel<256, 4, true>), rgrid, dim3(256), 0, s, a);
+            else if (res.nt == 256) hipLaunchKernelGGL((gn_bwd_resident_kernel<256, 8, true>), rgrid, dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((gn_bwd_resident_kernel<512, 8, true>), rgrid, dim3(512), 0, s, a);
+            return clora_check_launch();
+        }
         if (res.nt == 256 && res.npt == 4) hipLaunchKernelGGL((gn_bwd_resident_kernel<256, 4>), rgrid, dim3(256), 0, s, a);
         else if (res.nt == 256) hipLaunchKernelGGL((gn_bwd_resident_kernel<256, 8>), rgrid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL((gn_bwd_resident_kernel<512, 8>), rgrid, dim3(512), 0, s, a);
@@ -1026,6 +1141,14 @@ extern "C" int clora_groupnorm_bwd_f16(const clora_half* x, const clora_half* dy
     return clora_check_launch();
 }
 
+extern "C" int clora_groupnorm_bwd_f16(const clora_half* x, const clora_half* dy, const clora_half* dres, clora_half* dx, const float* gamma,
+                                       const float* beta, const float* stats, float* dgamma, float* dbeta, int B,
+                                       int HW, int C, int G, int fuse_silu, int accumulate_params, void* workspace,
+                                       size_t workspace_bytes, void* stream) {
+    return clora_groupnorm_bwd_f16_ex(x, dy, nullptr, dres, dx, nullptr, 0, gamma, beta, stats, dgamma, dbeta, B, HW, C, G, fuse_silu,
+                                      accumulate_params, workspace, workspace_bytes, stream);
+}
+
 extern "C" int clora_layernorm_fwd_f16(const clora_half* x, clora_half* y, const float* gamma, const float* beta, int M,
                                        int C, float eps, void* stream) {
     if (!x || !y || !gamma || !beta || M <= 0 || C <= 0 || (C & 7) || C / 8 > 64 * kLnCols) return CLORA_ERR_ARG;
@@ -1035,13 +1158,33 @@ extern "C" int clora_layernorm_fwd_f16(const clora_half* x, clora_half* y, const
     return clora_check_launch();
 }
 
-extern "C" int clora_layernorm_bwd_f16(const clora_half* x, const clora_half* dy, const clora_half* dres, clora_half* dx,
-                                       const float* gamma, int M, int C, float eps, void* stream) {
-    if (!x || !dy || !dx || !gamma || M <= 0 || C <= 0 || (C & 7) || C / 8 > 64 * kLnCols) return CLORA_ERR_ARG;
+extern "C" int clora_layernorm_bwd_f16_ex(const clora_half* x, const clora_half* dy, const clora_deferred_t* dy_src, const clora_half* dres,
+                                          clora_half* dx, const float* gamma, int M, int C, float eps, void* stream) {
+    if (!x || !dx || !gamma || M <= 0 || C <= 0 || (C & 7) || C / 8 > 64 * kLnCols) return CLORA_ERR_ARG;
+    const bool deferred = dy_src && dy_src->splits > 0;
+    if (deferred) {
+        if (!deferred_fits(dy_src, M, C)) return CLORA_ERR_ARG;
+        dy = dy_src->C;
+    }
+    if (!dy) return CLORA_ERR_ARG;
     LnArgs a = LnArgs();
     a.x = (const half_t*)x; a.dy = (const half_t*)dy; a.dres = (const half_t*)dres; a.y = (half_t*)dx; a.gamma = gamma; a.M = M; a.C = C; a.eps = eps;
+    if (deferred && ln_rows_plan(a, true)) {
+        a.fin_partial = dy_src->partial; a.fin_splits = dy_src->splits; a.fin_epi = dy_src->epi;
+        launch_layernorm<true, true>(a, (hipStream_t)stream);
+        return clora_check_launch();
+    }
+    if (deferred) {
+        const int rc = clora_finish_deferred(dy_src, stream);
+        if (rc != CLORA_OK) return rc;
+    }
     launch_layernorm<true>(a, (hipStream_t)stream);
     return clora_check_launch();
+}
+
+extern "C" int clora_layernorm_bwd_f16(const clora_half* x, const clora_half* dy, const clora_half* dres, clora_half* dx,
+                                       const float* gamma, int M, int C, float eps, void* stream) {
+    return clora_layernorm_bwd_f16_ex(x, dy, nullptr, dres, dx, gamma, M, C, eps, stream);
 }
 
 extern "C" int clora_softmax_rows_f16(const clora_half* x, clora_half* y, int rows, int cols, int ld, float scale,

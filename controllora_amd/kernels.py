@@ -40,7 +40,35 @@ class KernelProfiler:
 PROFILER: Optional[KernelProfiler] = None
 
 
+# ---- deferred split-K finishes (include/clora.h clora_deferred_t).  A GEMM launched with defer=True that turned out split-K leaves
+# its slabs in the workspace and registers here under its OUTPUT's address; the GroupNorm / LayerNorm wrapper that reads that tensor
+# next takes the entry and folds the slabs while it loads (71 of the 108 finish launches of a train step).  Safety net: ANY other
+# kernel call first finishes whatever is still pending (the workspace may be reused, the tensor may be read) -- a caller may only ask
+# for deferral where the output's next reader goes through this module (torch-native reads would see an unwritten buffer).
+_PENDING = {}
+_pending_task = [None]
+DEFER_FINISH = os.environ.get("CLORA_DEFER_FINISH", "1") != "0"       # "0": every split-K GEMM runs its own finish pass (A/B runs)
+
+
+def flush_pending():
+    while _PENDING:
+        _, (d, keep) = _PENDING.popitem()
+        capi.lib().call("clora_finish_deferred", C.byref(d), capi.stream())
+
+
+def take_pending(t: torch.Tensor):
+    """-> (clora_deferred_t of the deferred producer of tensor `t`, its operand tensors) or (None, None); anything else pending is
+    finished now.  The caller keeps the second value referenced until its own launch has been issued: the producer's epilogue operands
+    (residual, bias, T ...) may have no other owner left."""
+    hit = _PENDING.pop(t.data_ptr(), None) if _PENDING else None
+    if _PENDING:
+        flush_pending()
+    return hit if hit is not None else (None, None)
+
+
 def _call(name, *args, flops=0.0, nbytes=0.0, tag=None):
+    if _PENDING:
+        flush_pending()
     if PROFILER is None:
         capi.lib().call(name, *args, capi.stream())
         return
@@ -140,7 +168,7 @@ def gemm(A: torch.Tensor, Bw: torch.Tensor, M: int, N: int, K: int, *, lda: Opti
          split_k: int = 0, tile_cfg: int = 0, _tuned: bool = True,
          geglu: int = 0, geglu_h: Optional[torch.Tensor] = None, geglu_y: Optional[torch.Tensor] = None,
          geglu_keep_h: bool = True, lora_dpack: Optional[torch.Tensor] = None, lora_t_in: Optional[torch.Tensor] = None,
-         lora_t_in_mask: int = 0, lora_t_in_rows: int = 0) -> torch.Tensor:
+         lora_t_in_mask: int = 0, lora_t_in_rows: int = 0, defer: bool = False) -> torch.Tensor:
     """C[M,N] = A . Bw^T with the fused epilogue of clora_epilogue_t.
     geglu=1 (Bw / bias packed by ops.GegluPack, N = 2F): returns (y [M,F], h [M,2F] or None when not geglu_keep_h);
     geglu=2 (N = F, geglu_h = the saved h): returns dh [M, 2F].
@@ -192,11 +220,22 @@ def gemm(A: torch.Tensor, Bw: torch.Tensor, M: int, N: int, K: int, *, lda: Opti
         if geglu == 1 and tile_cfg not in WIDE_TILE_CFGS:
             tile_cfg = 0                       # the library picks a >= 128-column tile itself
     ws = workspace(GEMM_WS_BYTES if split_k == 0 else max(split_k, 1) * M * N * 4, A.device) if split_k != 1 else None
+    # defer=True: if this launch is split-K, leave its finish pass to the GroupNorm / LayerNorm call that reads C next (_PENDING)
+    d = None
+    if defer and DEFER_FINISH and split_k != 1 and not geglu and PROFILER is None and C_ is not None and C_.is_contiguous():
+        d = capi.Deferred()
+        e.defer = C.addressof(d)
     _call("clora_gemm_f16_ex", ptr(A), lda if lda is not None else K, ptr(Bw), ptr(C_) if C_ is not None else None, ldc, M, N, K,
           C.byref(conv) if conv is not None else None, C.byref(e), split_k, tile_cfg,
           ptr(ws) if ws is not None else None, ws.numel() if ws is not None else 0,
           flops=2.0 * M * N * K, nbytes=2.0 * (A.numel() + N * K + M * N),
           tag=f"{M}x{N}x{K}{'conv' if conv is not None else ''}")
+    if d is not None and d.splits > 1:
+        _PENDING[C_.data_ptr()] = (d, (C_, bias, rowadd, residual, lora_t, lora_u, ws))     # operands stay alive until it is consumed
+        task = _graph_task_id()
+        if task >= 0 and _pending_task[0] != task:       # inside a backward pass: whatever nobody consumed is finished when the pass ends
+            _pending_task[0] = task
+            torch.autograd.Variable._execution_engine.queue_callback(flush_pending)
     if geglu == 1:
         return y, C_
     return C_
@@ -353,21 +392,38 @@ def _gn_ws(B, HW, Cc, G, device, bwd, params):
     return workspace(n, device)
 
 
-def groupnorm_fwd(x, gamma, beta, G, eps, silu):
-    B, HW, Cc = x.shape
-    y = torch.empty_like(x)
+def groupnorm_fwd(x, gamma, beta, G, eps, silu, x2=None):
+    """x2: the input is the channel concatenation cat(x, x2) read in place -> (y, stats, xcat) with xcat the concatenated
+    tensor (written once by the kernel for the shortcut / backward).  If x is the still-unfinished output of a deferred split-K
+    GEMM (take_pending) the kernel folds the slabs while it loads and stores the finished x."""
+    B, HW, Ca = x.shape
+    Cc = Ca + (x2.shape[-1] if x2 is not None else 0)
+    src, _keep = take_pending(x)
+    y = torch.empty((B, HW, Cc), dtype=f16, device=x.device)
     stats = torch.empty((B, G, 2), dtype=f32, device=x.device)
+    xcat = torch.empty((B, HW, Cc), dtype=f16, device=x.device) if x2 is not None else None
+    if src is not None and x2 is not None:          # the kernels take one or the other
+        capi.lib().call("clora_finish_deferred", C.byref(src), capi.stream())
+        src = None
     ws = _gn_ws(B, HW, Cc, G, x.device, False, False)
-    _call("clora_groupnorm_fwd_f16", ptr(x, f16), ptr(y), ptr(gamma, f32), ptr(beta, f32), ptr(stats), B, HW, Cc, G,
-          float(eps), int(silu), ptr(ws), ws.numel())
-    return y, stats
+    _call("clora_groupnorm_fwd_f16_ex", ptr(x, f16), ptr(x2, f16) if x2 is not None else None, Ca if x2 is not None else 0,
+          C.byref(src) if src is not None else None, ptr(xcat) if xcat is not None else None, ptr(y), ptr(gamma, f32), ptr(beta, f32),
+          ptr(stats), B, HW, Cc, G, float(eps), int(silu), ptr(ws), ws.numel())
+    return (y, stats, xcat) if x2 is not None else (y, stats)
 
 
-def groupnorm_bwd(x, dy, gamma, beta, stats, G, silu, want_param_grads=False, grads_into=None, dres=None):
+def groupnorm_bwd(x, dy, gamma, beta, stats, G, silu, want_param_grads=False, grads_into=None, dres=None, split_at=0):
     """grads_into = (dgamma_buffer, dbeta_buffer): accumulate the affine gradients there instead of returning them;
-    dres: gradient of x from the branch that bypasses the norm (added into dx by the kernel)"""
+    dres: gradient of x from the branch that bypasses the norm (added into dx by the kernel);
+    split_at = Ca > 0: dx is returned as the pair (dx[..., :Ca], dx[..., Ca:]) of contiguous tensors (the gradients of the two
+    inputs of a concatenating forward).  dy may be the unfinished output of a deferred split-K GEMM (take_pending)."""
     B, HW, Cc = x.shape
-    dx = torch.empty_like(x)
+    dy_src, _keep = take_pending(dy)
+    if split_at:
+        dx = torch.empty((B, HW, split_at), dtype=f16, device=x.device)
+        dx2 = torch.empty((B, HW, Cc - split_at), dtype=f16, device=x.device)
+    else:
+        dx, dx2 = torch.empty_like(x), None
     dg = db = None
     if grads_into is not None:
         dg, db = grads_into
@@ -377,10 +433,13 @@ def groupnorm_bwd(x, dy, gamma, beta, stats, G, silu, want_param_grads=False, gr
         db = torch.empty(Cc, dtype=f32, device=x.device)
     ws = _gn_ws(B, HW, Cc, G, x.device, True, want_param_grads)
     assert dres is None or (dres.shape == x.shape and dres.is_contiguous())
-    _call("clora_groupnorm_bwd_f16", ptr(x, f16), ptr(dy, f16), ptr(dres, f16) if dres is not None else None, ptr(dx),
+    _call("clora_groupnorm_bwd_f16_ex", ptr(x, f16), ptr(dy, f16), C.byref(dy_src) if dy_src is not None else None,
+          ptr(dres, f16) if dres is not None else None, ptr(dx), ptr(dx2) if dx2 is not None else None, int(split_at),
           ptr(gamma, f32), ptr(beta, f32), ptr(stats, f32),
           ptr(dg, f32) if dg is not None else None, ptr(db, f32) if db is not None else None, B, HW, Cc, G, int(silu),
           int(grads_into is not None), ptr(ws), ws.numel())
+    if split_at:
+        dx = (dx, dx2)
     return (dx, None, None) if grads_into is not None else (dx, dg, db)
 
 
@@ -395,8 +454,9 @@ def layernorm_bwd(x, dy, gamma, eps, dres=None):
     """dres: gradient of x from the branch that bypasses the norm (added into dx by the kernel)"""
     x2 = _c2(x)
     dx = torch.empty_like(x)
-    _call("clora_layernorm_bwd_f16", ptr(x2, f16), ptr(_c2(dy), f16), ptr(_c2(dres), f16) if dres is not None else None, ptr(dx),
-          ptr(gamma, f32), x2.shape[0], x2.shape[1], float(eps))
+    dy_src, _keep = take_pending(dy)     # dy may be the unfinished output of a deferred split-K dgrad GEMM: folded while loading
+    _call("clora_layernorm_bwd_f16_ex", ptr(x2, f16), ptr(_c2(dy), f16), C.byref(dy_src) if dy_src is not None else None,
+          ptr(_c2(dres), f16) if dres is not None else None, ptr(dx), ptr(gamma, f32), x2.shape[0], x2.shape[1], float(eps))
     return dx
 
 

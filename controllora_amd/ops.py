@@ -103,36 +103,39 @@ class ConvPack:
 
 
 # ------------------------------------------------------------------------------------------------ frozen layers
+# defer_out / defer_dx (round 6, K._PENDING): the caller states that the NEXT reader of the output (forward) / of the input gradient
+# (backward: x is the output of a norm with no other consumer) is a GroupNorm / LayerNorm kernel call -- a split-K launch then leaves its
+# finish pass to that call.  Never set it where a torch-native op may read the tensor first.
 class _FrozenLinearFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, pack: LinearPack, residual, rowadd, rows_per_batch):
+    def forward(ctx, x, pack: LinearPack, residual, rowadd, rows_per_batch, defer_out=False, defer_dx=False):
         M = x.shape[0]
         y = K.gemm(x, pack.w, M, pack.N, pack.K, bias=pack.bias, residual=residual, rowadd=rowadd,
-                   rows_per_batch=rows_per_batch)
-        ctx.pack, ctx.has_res = pack, residual is not None
+                   rows_per_batch=rows_per_batch, defer=defer_out)
+        ctx.pack, ctx.has_res, ctx.defer_dx = pack, residual is not None, defer_dx
         return y
 
     @staticmethod
     def backward(ctx, dy):
         dy = dy.contiguous()
         p = ctx.pack
-        dx = K.gemm(dy, p.wt, dy.shape[0], p.K, p.N) if ctx.needs_input_grad[0] else None
-        return dx, None, (dy if ctx.has_res and ctx.needs_input_grad[2] else None), None, None
+        dx = K.gemm(dy, p.wt, dy.shape[0], p.K, p.N, defer=ctx.defer_dx) if ctx.needs_input_grad[0] else None
+        return dx, None, (dy if ctx.has_res and ctx.needs_input_grad[2] else None), None, None, None, None
 
 
-def frozen_linear(x, pack: LinearPack, residual=None, rowadd=None, rows_per_batch=0):
+def frozen_linear(x, pack: LinearPack, residual=None, rowadd=None, rows_per_batch=0, defer_out=False, defer_dx=False):
     """y = x W^T + b (+ rowadd[batch]) (+ residual); x [M,K] fp16."""
-    return _FrozenLinearFn.apply(x, pack, residual, rowadd, rows_per_batch)
+    return _FrozenLinearFn.apply(x, pack, residual, rowadd, rows_per_batch, defer_out, defer_dx)
 
 
 class _FrozenConvFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, pack: ConvPack, B, H, W, residual, rowadd):
+    def forward(ctx, x, pack: ConvPack, B, H, W, residual, rowadd, defer_out=False, defer_dx=False):
         cd, Ho, Wo = K.conv_fwd_desc(H, W, pack.Cip, 3, pack.stride, pack.pad, pack.upsample, pack.asym_pad, pack.kchunk)
         M = B * Ho * Wo
         y = K.gemm(x, pack.w, M, pack.Cop, 9 * pack.Cip, conv=cd, bias=pack.bias, residual=residual, rowadd=rowadd,
-                   rows_per_batch=Ho * Wo)
-        ctx.pack, ctx.dims, ctx.has_res = pack, (B, H, W, Ho, Wo), residual is not None
+                   rows_per_batch=Ho * Wo, defer=defer_out)
+        ctx.pack, ctx.dims, ctx.has_res, ctx.defer_dx = pack, (B, H, W, Ho, Wo), residual is not None, defer_dx
         return y
 
     @staticmethod
@@ -144,15 +147,15 @@ class _FrozenConvFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             Hi, Wi = (2 * H, 2 * W) if p.upsample else (H, W)
             cdd = K.conv_dgrad_desc(Ho, Wo, p.Cop, Hi, Wi, 3, p.stride, p.pad, p.asym_pad, p.kchunk_d)
-            dx = K.gemm(dy, p.wd, B * Hi * Wi, p.Cip, 9 * p.Cop, conv=cdd)
+            dx = K.gemm(dy, p.wd, B * Hi * Wi, p.Cip, 9 * p.Cop, conv=cdd, defer=ctx.defer_dx and not p.upsample)
             if p.upsample:
                 dx = K.pool2x2_sum(dx, B, H, W, p.Cip).reshape(B * H * W, p.Cip)
-        return dx, None, None, None, None, (dy if ctx.has_res and ctx.needs_input_grad[5] else None), None
+        return dx, None, None, None, None, (dy if ctx.has_res and ctx.needs_input_grad[5] else None), None, None, None
 
 
-def frozen_conv3x3(x, pack: ConvPack, B, H, W, residual=None, rowadd=None):
+def frozen_conv3x3(x, pack: ConvPack, B, H, W, residual=None, rowadd=None, defer_out=False, defer_dx=False):
     """x [B*H*W, Cip] NHWC -> [B*Ho*Wo, Cop]."""
-    return _FrozenConvFn.apply(x, pack, B, H, W, residual, rowadd)
+    return _FrozenConvFn.apply(x, pack, B, H, W, residual, rowadd, defer_out, defer_dx)
 
 
 # ------------------------------------------------------------------------------------------------ norms / activations
@@ -185,6 +188,34 @@ class _GroupNormFn(torch.autograd.Function):
 def group_norm(x, gamma, beta, G, eps, silu):
     """x [B, HW, C] fp16, gamma/beta fp32 (frozen buffers or trainable parameters)."""
     return _GroupNormFn.apply(x, gamma, beta, G, eps, silu, False)
+
+
+class _GroupNormCatFn(torch.autograd.Function):
+    """GroupNorm(cat([a, b], channels)) without the concatenation launches (upstream up blocks: `torch.cat([hidden_states,
+    res_hidden_states], dim=1)` in front of every ResnetBlock2D): the kernels read the two tensors in place and write
+    the concatenated input ONCE as a by-product (the block's 1x1 shortcut reads it, the backward re-reads it); the backward writes the
+    two input gradients as two tensors.  Returns (norm(cat), cat): route the shortcut through the second output (see _GroupNormFn).
+    Until round 6: 2 copy launches forward + 2 backward per up-block resnet (48 per train step)."""
+
+    @staticmethod
+    def forward(ctx, a, b, gamma, beta, G, eps, silu):
+        y, stats, xcat = K.groupnorm_fwd(a, gamma, beta, G, eps, silu, x2=b)
+        ctx.save_for_backward(xcat, gamma, beta, stats)
+        ctx.cfg = (G, silu, a.shape[-1])
+        return y, xcat
+
+    @staticmethod
+    def backward(ctx, dy, dres=None):
+        xcat, gamma, beta, stats = ctx.saved_tensors
+        G, silu, Ca = ctx.cfg
+        (da, db), _, _ = K.groupnorm_bwd(xcat, dy.contiguous(), gamma, beta, stats, G, silu,
+                                         dres=dres.contiguous().view_as(xcat) if dres is not None else None, split_at=Ca)
+        return da, db, None, None, None, None, None
+
+
+def group_norm_cat(a, b, gamma, beta, G, eps, silu):
+    """-> (GroupNorm(cat(a, b)), cat(a, b)); a [B, HW, Ca], b [B, HW, Cb] fp16"""
+    return _GroupNormCatFn.apply(a, b, gamma, beta, G, eps, silu)
 
 
 def group_norm_fork(x, gamma, beta, G, eps, silu):
@@ -241,7 +272,8 @@ class _FeedForwardFn(torch.autograd.Function):
     re-read h: 69 + 46 MB per launch at level 0)."""
 
     @staticmethod
-    def forward(ctx, x, pack1: "GegluPack", pack2: LinearPack, residual):
+    def forward(ctx, x, pack1: "GegluPack", pack2: LinearPack, residual, defer_dx=False):
+        ctx.defer_dx = defer_dx
         M = x.shape[0]
         need = ctx.needs_input_grad[0]            # inference: h = (a | g) is never written
         y, h = K.gemm(x, pack1.w, M, pack1.N, pack1.K, bias=pack1.bias, geglu=1, geglu_keep_h=need)
@@ -260,12 +292,13 @@ class _FeedForwardFn(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dh = K.gemm(dout, p2.wt, M, p2.K, p2.N, geglu=2, geglu_h=h)          # [M, 2F] = d(a | g)
-            dx = K.gemm(dh, p1.wt, M, p1.K, p1.N)
-        return dx, None, None, (dout if ctx.has_res and ctx.needs_input_grad[3] else None)
+            dx = K.gemm(dh, p1.wt, M, p1.K, p1.N, defer=ctx.defer_dx)            # -> LayerNorm backward (norm3)
+        return dx, None, None, (dout if ctx.has_res and ctx.needs_input_grad[3] else None), None
 
 
-def feed_forward(x, pack1: "GegluPack", pack2: LinearPack, residual=None):
-    return _FeedForwardFn.apply(x, pack1, pack2, residual)
+def feed_forward(x, pack1: "GegluPack", pack2: LinearPack, residual=None, defer_dx=False):
+    """defer_dx: x is a LayerNorm output with no other consumer (see _FrozenLinearFn)"""
+    return _FeedForwardFn.apply(x, pack1, pack2, residual, defer_dx)
 
 
 class _AddFn(torch.autograd.Function):
@@ -758,6 +791,26 @@ def _fusable(pack, meta, ranks, seg_w, M):
     return _fuse_plan(M, pack.N, pack.K, seg_w)
 
 
+# Dynamic scope set by the UNet's transformer block around an attention call whose hidden_states IS a LayerNorm output with no
+# other consumer: the projection's dgrad GEMM may then leave a split-K finish to the LayerNorm backward (see _FrozenLinearFn).
+_FROM_NORM = [0]
+
+
+class input_from_norm:
+    def __enter__(self):
+        _FROM_NORM[0] += 1
+        return self
+
+    def __exit__(self, *exc):
+        _FROM_NORM[0] -= 1
+        return False
+
+
+class _Meta(tuple):
+    """the per-segment adapter description of _LoraProjFn plus call flags (a tuple subclass: autograd passes it through untouched)"""
+    defer_dx = False
+
+
 class _LoraProjFn(torch.autograd.Function):
     """y = x W^T (+b) (+residual) + scale_s * up_s(down_s(xa_s)) on column segment s.
 
@@ -839,6 +892,7 @@ class _LoraProjFn(torch.autograd.Function):
             y = K.gemm(x, pack.w, M, pack.N, pack.K, bias=pack.bias, residual=residual, lora_t=T, lora_u=U,
                        lora_seg=seg_w, lora_scale=1.0)
         ctx.pack, ctx.info, ctx.n_xa, ctx.r, ctx.has_res = pack, info, n_xa, r, residual is not None
+        ctx.defer_dx = bool(getattr(meta, "defer_dx", False))
         ctx.t_pre_rows = t_pre.shape[0] if t_pre is not None else 0
         ctx.params = params                       # the Parameter objects themselves (leaf tensors)
         ctx.save_for_backward(T, *xas)
@@ -919,20 +973,21 @@ class _LoraProjFn(torch.autograd.Function):
                 A_, T_, to_, G_, gsn, gsj, N_, rs_, sc_, lda_ = item
                 K.lora_wgrad(A_, T_, to_, G_, gsn, gsj, M, N_, rs_, scale=sc_, lda=lda_)
         if ctx.needs_input_grad[4] and not fused_bwd:
+            dfr = ctx.defer_dx                      # the dgrad is this backward's last launch: its finish may ride in the norm's backward
             if not own:
-                dx = K.gemm(dy, pack.wt, M, pack.K, pack.N)
+                dx = K.gemm(dy, pack.wt, M, pack.K, pack.N, defer=dfr)
             else:
                 segs = [s for s, _ in own]
                 contiguous = segs == list(range(segs[0], segs[0] + len(segs))) and all(D.shape[0] == r for _, D in own)
                 if contiguous:                                   # rank-r part of dx rides in the GEMM epilogue
                     Dcat = _stack_rows([D.detach() for _, D in own])
                     dx = K.gemm(dy, pack.wt, M, pack.K, pack.N, lora_t=dT[:, segs[0] * r:], lora_u=Dcat,
-                                lora_seg=pack.K, lora_u_tr=True, lora_r=Dcat.shape[0])
+                                lora_seg=pack.K, lora_u_tr=True, lora_r=Dcat.shape[0], defer=dfr)
                 else:
                     Dx = torch.zeros((S * r, pack.K), dtype=f32, device=dy.device)
                     for s, D in own:
                         Dx[s * r:s * r + D.shape[0]] = D.detach()
-                    dx = K.gemm(dy, pack.wt, M, pack.K, pack.N, lora_t=dT, lora_u=Dx, lora_seg=pack.K, lora_u_tr=True)
+                    dx = K.gemm(dy, pack.wt, M, pack.K, pack.N, lora_t=dT, lora_u=Dx, lora_seg=pack.K, lora_u_tr=True, defer=dfr)
         dres = dy if ctx.has_res and ctx.needs_input_grad[5] else None
         d_tpre = None
         if ctx.t_pre_rows and ctx.needs_input_grad[3]:           # d(rank-space share of the q adapter) = dT of segment 0
@@ -963,7 +1018,9 @@ def lora_proj(x, pack: LinearPack, segs: Sequence[Optional[Tuple[torch.Tensor, t
             idxs.append(idx)
         meta.append((tuple(idxs), float(sc)))
         params += [D, U]
-    return _LoraProjFn.apply(pack, tuple(meta), len(xas), t_pre, x, residual, *xas[1:], *params)
+    meta = _Meta(meta)
+    meta.defer_dx = _FROM_NORM[0] > 0
+    return _LoraProjFn.apply(pack, meta, len(xas), t_pre, x, residual, *xas[1:], *params)
 
 
 class _ControlAddFn(torch.autograd.Function):

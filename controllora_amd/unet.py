@@ -26,6 +26,9 @@ from . import ops
 
 f16, f32 = torch.float16, torch.float32
 
+import os as _os
+CAT_IN_PLACE = _os.environ.get("CLORA_CAT_IN_PLACE", "1") != "0"      # "0": materialise cat([x, skip]) with copy launches (round-5 path, A/B)
+
 SD15_CONFIG = dict(
     in_channels=4, out_channels=4, block_out_channels=(320, 640, 1280, 1280), layers_per_block=2,
     down_block_types=("CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "DownBlock2D"),
@@ -65,8 +68,8 @@ class Conv3x3(_Packed):
     def _build(self):
         return ops.ConvPack(self.weight, self.bias, **self.cfg)
 
-    def forward(self, x, B, H, W, residual=None, rowadd=None):
-        return ops.frozen_conv3x3(x, self.pack(), B, H, W, residual, rowadd)
+    def forward(self, x, B, H, W, residual=None, rowadd=None, defer_out=False, defer_dx=False):
+        return ops.frozen_conv3x3(x, self.pack(), B, H, W, residual, rowadd, defer_out, defer_dx)
 
 
 class Conv1x1(_Packed):
@@ -80,8 +83,8 @@ class Conv1x1(_Packed):
     def _build(self):
         return ops.LinearPack(self.weight, self.bias)
 
-    def forward(self, x, residual=None):
-        return ops.frozen_linear(x, self.pack(), residual)
+    def forward(self, x, residual=None, defer_out=False, defer_dx=False):
+        return ops.frozen_linear(x, self.pack(), residual, defer_out=defer_out, defer_dx=defer_dx)
 
 
 class Linear(_Packed):
@@ -120,6 +123,11 @@ class GroupNorm(_Norm):
         """-> (norm(x), x'): route the branch that bypasses the norm through x' (gradient add fused into the backward)"""
         g, b = self.pack()
         return ops.group_norm_fork(x, g, b, self.groups, self.eps, silu)
+
+    def fork_cat(self, x, skip, silu):
+        """-> (norm(cat(x, skip)), cat(x, skip)) with the concatenation read in place by the norm kernels (ops._GroupNormCatFn)"""
+        g, b = self.pack()
+        return ops.group_norm_cat(x, skip, g, b, self.groups, self.eps, silu)
 
 
 class LayerNorm(_Norm):
@@ -226,8 +234,8 @@ class FeedForward(nn.Module):
         super().__init__()
         self.net = nn.ModuleList([GEGLU(dim, dim * mult), nn.Dropout(0.0), Linear(dim * mult, dim)])
 
-    def forward(self, x, residual):
-        return ops.feed_forward(x, self.net[0].proj.pack(), self.net[2].pack(), residual)
+    def forward(self, x, residual, defer_dx=False):
+        return ops.feed_forward(x, self.net[0].proj.pack(), self.net[2].pack(), residual, defer_dx)
 
 
 class BasicTransformerBlock(nn.Module):
@@ -241,12 +249,16 @@ class BasicTransformerBlock(nn.Module):
     def forward(self, x, ehs, kw):
         B, N, C_ = x.shape
         grad = torch.is_grad_enabled() and x.requires_grad
+        # the attention / feed-forward inputs below are LayerNorm outputs with no other consumer: their projections' dgrad GEMMs may
+        # leave a split-K finish to the LayerNorm backward (ops.input_from_norm)
         n, xr = self.norm1.fork(x) if grad else (self.norm1(x), x)
-        x = self.attn1(n, residual=xr, **kw)
+        with ops.input_from_norm():
+            x = self.attn1(n, residual=xr, **kw)
         n, xr = self.norm2.fork(x) if grad else (self.norm2(x), x)
-        x = self.attn2(n, encoder_hidden_states=ehs, residual=xr, **kw)
+        with ops.input_from_norm():
+            x = self.attn2(n, encoder_hidden_states=ehs, residual=xr, **kw)
         n, xr = self.norm3.fork(x) if grad else (self.norm3(x), x)
-        return self.ff(n.reshape(B * N, C_), xr.reshape(B * N, C_)).reshape(B, N, C_)
+        return self.ff(n.reshape(B * N, C_), xr.reshape(B * N, C_), defer_dx=grad).reshape(B, N, C_)
 
 
 class Transformer2DModel(nn.Module):
@@ -258,13 +270,15 @@ class Transformer2DModel(nn.Module):
         self.transformer_blocks = nn.ModuleList([BasicTransformerBlock(inner, heads, dim_head, cross_attention_dim)])
         self.proj_out = Conv1x1(inner, in_channels)
 
-    def forward(self, x, ehs, kw):
+    def forward(self, x, ehs, kw, out_to_norm=False):
+        """out_to_norm: the caller feeds the result straight to a GroupNorm (see ops._FrozenLinearFn defer_out)"""
         B, N, C_ = x.shape
-        n, xr = self.norm.fork(x, False) if (torch.is_grad_enabled() and x.requires_grad) else (self.norm(x, False), x)
-        h = self.proj_in(n.reshape(B * N, C_)).reshape(B, N, -1)
+        grad = torch.is_grad_enabled() and x.requires_grad
+        n, xr = self.norm.fork(x, False) if grad else (self.norm(x, False), x)
+        h = self.proj_in(n.reshape(B * N, C_), defer_dx=grad).reshape(B, N, -1)
         for blk in self.transformer_blocks:
             h = blk(h, ehs, kw)
-        return self.proj_out(h.reshape(B * N, -1), xr.reshape(B * N, C_)).reshape(B, N, C_)
+        return self.proj_out(h.reshape(B * N, -1), xr.reshape(B * N, C_), defer_out=out_to_norm).reshape(B, N, C_)
 
 
 # ------------------------------------------------------------------------------------------------ resnet / samplers
@@ -278,20 +292,28 @@ class ResnetBlock2D(nn.Module):
         self.conv2 = Conv3x3(cout, cout)
         self.conv_shortcut = Conv1x1(cin, cout) if cin != cout else None
 
-    def forward(self, x, temb_act, H, W, temb_proj=None):
-        B, N, Cin = x.shape
+    def forward(self, x, temb_act, H, W, temb_proj=None, skip=None, out_to_norm=False):
+        """skip: the block input is cat([x, skip], channels) (up blocks), read in place by norm1; out_to_norm: the caller feeds the
+        result straight to a GroupNorm (a split-K conv2 then leaves its finish pass to that norm, ops._FrozenConvFn defer_out)"""
+        B, N, _ = x.shape
         if temb_proj is not None:          # this block's column slice of the UNet's batched time-embedding projections
             t = temb_proj
         else:
             with torch.no_grad():          # the time embedding has no trainable ancestor
                 t = self.time_emb_proj(temb_act)
-        n, xr = self.norm1.fork(x, True) if (torch.is_grad_enabled() and x.requires_grad) else (self.norm1(x, True), x)
-        h = self.conv1(n.reshape(B * N, Cin), B, H, W, rowadd=t)
+        grad = torch.is_grad_enabled() and (x.requires_grad or (skip is not None and skip.requires_grad))
+        if skip is not None:
+            n, xr = self.norm1.fork_cat(x, skip, True)
+        else:
+            n, xr = self.norm1.fork(x, True) if grad else (self.norm1(x, True), x)
+        Cin = xr.shape[-1]
+        # conv1 / conv2 read GroupNorm outputs that have no other consumer (defer_dx) and conv1 feeds norm2 (defer_out)
+        h = self.conv1(n.reshape(B * N, Cin), B, H, W, rowadd=t, defer_out=True, defer_dx=grad)
         Cout = h.shape[1]
         h = self.norm2(h.reshape(B, N, Cout), True).reshape(B * N, Cout)
         x2 = xr.reshape(B * N, Cin)
         sc = self.conv_shortcut(x2) if self.conv_shortcut is not None else x2
-        return self.conv2(h, B, H, W, residual=sc).reshape(B, N, Cout)
+        return self.conv2(h, B, H, W, residual=sc, defer_out=out_to_norm, defer_dx=grad).reshape(B, N, Cout)
 
 
 class Downsample2D(nn.Module):
@@ -299,9 +321,9 @@ class Downsample2D(nn.Module):
         super().__init__()
         self.conv = Conv3x3(c, c, stride=2, pad=1)
 
-    def forward(self, x, H, W):
+    def forward(self, x, H, W, out_to_norm=False):
         B, N, C_ = x.shape
-        return self.conv(x.reshape(B * N, C_), B, H, W).reshape(B, (H // 2) * (W // 2), C_)
+        return self.conv(x.reshape(B * N, C_), B, H, W, defer_out=out_to_norm).reshape(B, (H // 2) * (W // 2), C_)
 
 
 class Upsample2D(nn.Module):
@@ -309,9 +331,9 @@ class Upsample2D(nn.Module):
         super().__init__()
         self.conv = Conv3x3(c, c, upsample=True)
 
-    def forward(self, x, H, W):
+    def forward(self, x, H, W, out_to_norm=False):
         B, N, C_ = x.shape
-        return self.conv(x.reshape(B * N, C_), B, H, W).reshape(B, 4 * N, C_)
+        return self.conv(x.reshape(B * N, C_), B, H, W, defer_out=out_to_norm).reshape(B, 4 * N, C_)
 
 
 class CrossAttnDownBlock2D(nn.Module):
@@ -487,28 +509,39 @@ class UNet2DConditionModel(nn.Module):
         x = sample.new_zeros((B, H, W, self.conv_in.pack().Cip), dtype=f16)
         x[..., :Cin] = sample.permute(0, 2, 3, 1)
         x = self.conv_in(x.reshape(B * H * W, -1), B, H, W).reshape(B, H * W, -1)
+        # out_to_norm below: the NEXT reader of the tensor is a GroupNorm kernel call (a resnet's norm1 -- also through the in-place
+        # concatenation of the up path --, a transformer's norm, conv_norm_out), never a torch-native op: a split-K producer may then
+        # leave its finish pass to that norm (kernels._PENDING).  The tensors in front of a downsampler conv are the exception.
         skips = [(x, H, W)]
         for blk in self.down_blocks:
+            nres = len(blk.resnets)
             for j, r in enumerate(blk.resnets):
-                x = r(x, temb_act, H, W, tproj(r))
+                last = j == nres - 1
+                to_norm = True if blk.has_attn else not (last and blk.downsamplers is not None)
+                x = r(x, temb_act, H, W, tproj(r), out_to_norm=to_norm)
                 if blk.has_attn:
-                    x = blk.attentions[j](x, ehs, kw)
+                    x = blk.attentions[j](x, ehs, kw, out_to_norm=not (last and blk.downsamplers is not None))
                 skips.append((x, H, W))
             if blk.downsamplers is not None:
-                x = blk.downsamplers[0](x, H, W)
+                x = blk.downsamplers[0](x, H, W, out_to_norm=True)
                 H, W = H // 2, W // 2
                 skips.append((x, H, W))
-        x = self.mid_block.resnets[0](x, temb_act, H, W, tproj(self.mid_block.resnets[0]))
-        x = self.mid_block.attentions[0](x, ehs, kw)
-        x = self.mid_block.resnets[1](x, temb_act, H, W, tproj(self.mid_block.resnets[1]))
+        x = self.mid_block.resnets[0](x, temb_act, H, W, tproj(self.mid_block.resnets[0]), out_to_norm=True)
+        x = self.mid_block.attentions[0](x, ehs, kw, out_to_norm=True)
+        x = self.mid_block.resnets[1](x, temb_act, H, W, tproj(self.mid_block.resnets[1]), out_to_norm=CAT_IN_PLACE)
         for blk in self.up_blocks:
             for j, r in enumerate(blk.resnets):
                 s, _, _ = skips.pop()
-                x = r(ops.concat_channels(x, s), temb_act, H, W, tproj(r))
+                if CAT_IN_PLACE:
+                    nxt_norm = blk.has_attn or j < len(blk.resnets) - 1 or blk.upsamplers is None
+                    x = r(x, temb_act, H, W, tproj(r), skip=s, out_to_norm=nxt_norm)
+                else:
+                    x = r(ops.concat_channels(x, s), temb_act, H, W, tproj(r), out_to_norm=blk.has_attn)
                 if blk.has_attn:
-                    x = blk.attentions[j](x, ehs, kw)
+                    last = j == len(blk.resnets) - 1     # then: the upsampler conv, or conv_norm_out after the last block
+                    x = blk.attentions[j](x, ehs, kw, out_to_norm=(CAT_IN_PLACE and not last) or (last and blk.upsamplers is None))
             if blk.upsamplers is not None:
-                x = blk.upsamplers[0](x, H, W)
+                x = blk.upsamplers[0](x, H, W, out_to_norm=CAT_IN_PLACE)
                 H, W = 2 * H, 2 * W
         x = self.conv_norm_out(x, True)
         y = self.conv_out(x.reshape(B * H * W, -1), B, H, W)

@@ -48,6 +48,8 @@ typedef struct {
                           * activation per tap) */
 } clora_conv_t;
 
+struct clora_deferred;      /* below: a split-K GEMM whose reduction + epilogue is left to the consumer of its output */
+
 /* ---- fused epilogue of clora_gemm_f16:
  *   acc[m,n] (+ bias[n]) (+ rowadd[m / rows_per_batch, n]) (+ lora_scale * sum_j T[m, toff+j] * U[n, j])
  *   -> fp16 -> (+ residual[m,n]) -> C[m,n]
@@ -95,7 +97,26 @@ typedef struct {
     const float* lora_t_in;
     int ldt_in, lora_t_in_rows;
     unsigned lora_t_in_mask;
+    /* round 6: `defer` != NULL asks the launch NOT to run its split-K finish pass: if the launch is split-K (the caller's or the
+     * planner's choice) the slabs stay in `workspace`, *defer is filled in and C is left unwritten; otherwise defer->splits = 0 and C
+     * is complete as usual.  The caller hands *defer to the consumer of C (clora_groupnorm_*_ex / clora_layernorm_bwd_f16_ex), or to
+     * clora_finish_deferred, before anything else uses `workspace`.  Not with GEGLU. */
+    struct clora_deferred* defer;
 } clora_epilogue_t;
+
+/* A deferred split-K GEMM (clora_epilogue_t.defer).  element (m, n) of the GEMM's output is
+ *   fp16( fp16( sum_z partial[z][m][n] + bias / rowadd / adapter terms of `epi` ) + residual )
+ * -- exactly what the library's own finish pass stores -- evaluated by the consumer while it loads its input: 71 of the 108 finish
+ * launches of a train step sit directly in front of a GroupNorm / LayerNorm launch that re-reads what they wrote. */
+typedef struct clora_deferred {
+    const float* partial;       /* [splits][M][N] fp32 */
+    int splits, M, N;
+    clora_half* C;              /* where the finished tensor belongs (the GEMM's own C / ldc) */
+    int ldc;
+    clora_epilogue_t epi;       /* the GEMM's epilogue (defer = NULL inside) */
+} clora_deferred_t;
+/* the plain finish pass for a deferred GEMM (a consumer that cannot fold it, or no consumer at all) */
+int clora_finish_deferred(const clora_deferred_t* d, void* stream);
 
 /* Packs adapter matrices for `lora_dpack`: out[8][K] fp16, rows 0..R-1 = fp16(scale * D), rows 4..4+R-1 = fp16(scale * D -
  * fp16(scale * D)), other rows zero; R <= 4.  kmajor = 0: D is a down weight [R, K] with row pitch ldd (LoRALinearLayer.down,
@@ -256,6 +277,23 @@ int clora_groupnorm_bwd_f16(const clora_half* x, const clora_half* dy, const clo
                             int G, int fuse_silu, int accumulate_params, void* workspace, size_t workspace_bytes,
                             void* stream);
 
+/* Round 6 forms of the two calls above (they are `_ex` with the extra arguments NULL / 0):
+ *  - x2 != NULL: the input is the channel CONCATENATION of x [B*HW, Ca] and x2 [B*HW, C - Ca] (upstream UNet up blocks:
+ *    `torch.cat([hidden_states, res_hidden_states], dim=1)` feeding ResnetBlock2D.norm1) read in place; xcopy (optional,
+ *    [B*HW, C]) receives the concatenated tensor for the block's 1x1 shortcut and for the backward.  Ca % 8 == 0.
+ *  - src != NULL with src->splits > 0: the input is a deferred split-K GEMM (clora_deferred_t; src->N == C, src->M == B*HW,
+ *    src->ldc == C): folded while loading where the one-launch plan applies, else finished first; either way src->C holds the
+ *    finished tensor afterwards and x is ignored.
+ *  backward: dy_src = deferred producer of dy (dy is then only a scratch buffer of the fallback); dx2 != NULL: dx is written as
+ *  two tensors [B*HW, Ca] and [B*HW, C - Ca] (the gradients of the two concatenated inputs). */
+int clora_groupnorm_fwd_f16_ex(const clora_half* x, const clora_half* x2, int Ca, const clora_deferred_t* src, clora_half* xcopy,
+                               clora_half* y, const float* gamma, const float* beta, float* stats, int B, int HW, int C, int G,
+                               float eps, int fuse_silu, void* workspace, size_t workspace_bytes, void* stream);
+int clora_groupnorm_bwd_f16_ex(const clora_half* x, const clora_half* dy, const clora_deferred_t* dy_src, const clora_half* dres,
+                               clora_half* dx, clora_half* dx2, int Ca, const float* gamma, const float* beta, const float* stats,
+                               float* dgamma, float* dbeta, int B, int HW, int C, int G, int fuse_silu, int accumulate_params,
+                               void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- row softmax  y[r,:] = softmax(scale * x[r,:])  (fp32 max/sum; cols % 8 == 0, cols <= 8192, scale > 0; in place
  * allowed).  Normalises the materialised scores of the VAE's single-head d=512 attention (upstream AutoencoderKL
  * AttentionBlock, used at reference train_text_to_image_control_lora.py:753 / apps/gradio_canny2image.py). */
@@ -266,6 +304,10 @@ int clora_layernorm_fwd_f16(const clora_half* x, clora_half* y, const float* gam
                             float eps, void* stream);
 int clora_layernorm_bwd_f16(const clora_half* x, const clora_half* dy, const clora_half* dres, clora_half* dx,
                             const float* gamma, int M, int C, float eps, void* stream);
+/* dy_src != NULL with dy_src->splits > 0: dy is a deferred split-K GEMM (the dgrad of the projection that consumed LN(x)),
+ * folded while loading (dy_src->N == C, dy_src->M == M); dy itself is not read. */
+int clora_layernorm_bwd_f16_ex(const clora_half* x, const clora_half* dy, const clora_deferred_t* dy_src, const clora_half* dres,
+                               clora_half* dx, const float* gamma, int M, int C, float eps, void* stream);
 /* dres (both norm backwards, may be NULL): a second gradient of x -- the residual / shortcut branch that forked off
  * before the norm (x + attn(LN(x)), ResnetBlock2D's shortcut) -- added into dx, so autograd never issues the add. */
 
@@ -415,8 +457,8 @@ int clora_adamw_flat_f32(float* p, const float* g, float* m, float* v, size_t n,
 int clora_clock_probe(unsigned long long* out, int blocks, int iters, void* stream);
 
 /* library info: clora_abi_version() changes whenever a struct of this header changes layout (2: round 4's clora_epilogue_t /
- * clora_lora_down_job_t fields); a host built against another version must refuse the library */
-#define CLORA_ABI_VERSION 2
+ * clora_lora_down_job_t fields; 3: round 6's clora_epilogue_t.defer); a host built against another version must refuse the library */
+#define CLORA_ABI_VERSION 3
 int clora_abi_version(void);
 const char* clora_build_info(void);
 

@@ -496,6 +496,70 @@ def case_groupnorm(dev, B, HW, C, G, silu, eps=1e-5, seed=4, train_params=False)
         assert torch.equal(out1, out) and torch.equal(stats1, stats)
 
 
+def case_groupnorm_concat(dev, B, HW, Ca, Cb, G, silu, eps=1e-5, seed=11):
+    """Round 6 (include/clora.h clora_groupnorm_*_ex, x2 / dx2): GroupNorm over the channel concatenation of two tensors read in
+    place == GroupNorm over the materialised concatenation, BIT for bit (same loads, same arithmetic, same order): output, statistics,
+    the concatenated copy the kernel writes, and the backward's two gradient tensors."""
+    g = torch.Generator().manual_seed(seed)
+    a = (rnd((B, HW, Ca), dev, g).float() * 1.5 + 0.3).half()
+    b = (rnd((B, HW, Cb), dev, g).float() * 0.7 - 0.2).half()
+    C_ = Ca + Cb
+    gamma, beta = (1 + 0.2 * rnd((C_,), dev, g, dtype=f32)), 0.2 * rnd((C_,), dev, g, dtype=f32)
+    xc = torch.cat([a, b], -1).contiguous()
+    y0, st0 = K.groupnorm_fwd(xc, gamma, beta, G, eps, silu)
+    y1, st1, xcat = K.groupnorm_fwd(a, gamma, beta, G, eps, silu, x2=b)
+    assert torch.equal(xcat, xc) and torch.equal(y0, y1) and torch.equal(st0, st1)
+    dy, dres = rnd((B, HW, C_), dev, g), rnd((B, HW, C_), dev, g)
+    for dr in (None, dres):
+        dx0, _, _ = K.groupnorm_bwd(xc, dy, gamma, beta, st0, G, silu, dres=dr)
+        (da, db), _, _ = K.groupnorm_bwd(xc, dy, gamma, beta, st0, G, silu, dres=dr, split_at=Ca)
+        assert da.shape == (B, HW, Ca) and db.shape == (B, HW, Cb) and da.is_contiguous() and db.is_contiguous()
+        assert torch.equal(da, dx0[..., :Ca]) and torch.equal(db, dx0[..., Ca:])
+
+
+def case_deferred_finish(dev, B, HW, C, Kd, G, split, silu=True, seed=12, lora=False):
+    """Round 6 (clora_deferred_t): a split-K GEMM whose finish pass is left to the GroupNorm / LayerNorm launch that reads its output
+    == the same GEMM with its own finish pass followed by the plain norm launch, BIT for bit -- forward GroupNorm (the finished
+    tensor must also land in the GEMM's C), GroupNorm backward and LayerNorm backward with the GEMM producing dy; epilogue = bias +
+    row add + residual (+ a rank-4 adapter term for the LayerNorm case, what the attention projections' dgrad carries)."""
+    g = torch.Generator().manual_seed(seed)
+    M = B * HW
+    A = rnd((M, Kd), dev, g)
+    Wt = (rnd((C, Kd), dev, g).float() * 0.1).half()
+    bias = rnd((C,), dev, g, dtype=f32)
+    res = rnd((M, C), dev, g)
+    rowadd = rnd((B, C), dev, g)
+    gamma, beta = (1 + 0.2 * rnd((C,), dev, g, dtype=f32)), 0.2 * rnd((C,), dev, g, dtype=f32)
+    kw = dict(bias=bias, residual=res, rowadd=rowadd, rows_per_batch=HW, split_k=split)
+    if lora:
+        kw.update(lora_t=rnd((M, 8), dev, g, dtype=f32), lora_u=rnd((8, C), dev, g, dtype=f32), lora_seg=C, lora_u_tr=True, lora_r=8)
+    assert not K._PENDING
+    ref = K.gemm(A, Wt, M, C, Kd, **kw)
+    y0, st0 = K.groupnorm_fwd(ref.reshape(B, HW, C), gamma, beta, G, 1e-5, silu)
+    out = K.gemm(A, Wt, M, C, Kd, defer=True, **kw)
+    deferred = bool(K._PENDING)
+    assert deferred == (split > 1 and K.DEFER_FINISH)
+    y1, st1 = K.groupnorm_fwd(out.reshape(B, HW, C), gamma, beta, G, 1e-5, silu)
+    assert not K._PENDING and torch.equal(out, ref) and torch.equal(y0, y1) and torch.equal(st0, st1)
+    x = rnd((B, HW, C), dev, g)
+    dres = rnd((B, HW, C), dev, g)
+    _, stx = K.groupnorm_fwd(x, gamma, beta, G, 1e-5, silu)
+    dx0, _, _ = K.groupnorm_bwd(x, ref.reshape(B, HW, C), gamma, beta, stx, G, silu, dres=dres)
+    dyd = K.gemm(A, Wt, M, C, Kd, defer=True, **kw)
+    dx1, _, _ = K.groupnorm_bwd(x, dyd.reshape(B, HW, C), gamma, beta, stx, G, silu, dres=dres)
+    assert not K._PENDING and torch.equal(dx0, dx1)
+    if C <= 1536:
+        x2 = x.reshape(M, C)
+        l0 = K.layernorm_bwd(x2, ref, gamma, 1e-5, dres=dres.reshape(M, C))
+        dyd = K.gemm(A, Wt, M, C, Kd, defer=True, **kw)
+        l1 = K.layernorm_bwd(x2, dyd, gamma, 1e-5, dres=dres.reshape(M, C))
+        assert not K._PENDING and torch.equal(l0, l1)
+    # the safety net: any OTHER kernel call first finishes what is pending
+    dyd = K.gemm(A, Wt, M, C, Kd, defer=True, **kw)
+    z = K.add(dyd, dyd)
+    assert not K._PENDING and torch.equal(dyd, ref) and torch.equal(z, K.add(ref, ref))
+
+
 def case_softmax_rows(dev, rows, cols, scale=0.37, seed=6):
     g = torch.Generator().manual_seed(seed)
     x = (rnd((rows, cols), dev, g).float() * 4).half()

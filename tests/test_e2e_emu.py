@@ -220,6 +220,37 @@ def test_grouped_text_kv_projection_equals_per_site(case):
     assert E.rel(res[True]["grads"], res[False]["grads"]) < 2e-5, E.rel(res[True]["grads"], res[False]["grads"])
 
 
+@pytest.mark.parametrize("case", ["v1", "v2"])
+def test_deferred_finishes_and_in_place_concat_do_not_change_a_train_step(case):
+    """Round 6: (a) split-K finishes folded into the GroupNorm / LayerNorm launch that reads the GEMM's output (kernels._PENDING,
+    include/clora.h clora_deferred_t) and (b) the up path's cat([x, skip]) read in place by norm1 (ops._GroupNormCatFn) are pure
+    launch merges: prediction, loss and every gradient of a train step are BIT-identical to the unmerged path."""
+    from controllora_amd import kernels as K
+    from controllora_amd import unet as U
+    from tests.emu_fixture import use_emulator
+    res = {}
+    with use_emulator():
+        for merged in (True, False):
+            K.DEFER_FINISH, U.CAT_IN_PLACE = merged, merged
+            taken = []
+            orig = K.take_pending
+
+            def spy(t):
+                r = orig(t)
+                taken.append(r[0] is not None)
+                return r
+            K.take_pending = spy
+            try:
+                out, _ = E.run_product_step(case, "cpu")
+            finally:
+                K.take_pending = orig
+                K.DEFER_FINISH, U.CAT_IN_PLACE = True, True
+            assert any(taken) == merged and not K._PENDING
+            res[merged] = out
+    for k in ("pred", "loss", "grads"):
+        assert torch.equal(res[True][k], res[False][k]), k
+
+
 def test_vae_encode_decode_matches_oracle():
     from tests import vae_cases
     print(vae_cases.check_vae("cpu", res=32, batch=1))

@@ -80,6 +80,9 @@ def test_graph_replay_matches_eager_step():
         if graphed:
             tr.capture(*args, warmup=1)          # warm-up steps move the parameters: restore them
             tr.flat.data.copy_(start); tr.flat.exp_avg.zero_(); tr.flat.exp_avg_sq.zero_(); tr.state[2] = 0
+            from controllora_amd import ops
+            ops.repack_adapters()                # a write to the flat buffer behind torch's back: refresh the fp16 operands derived from
+            #                                      it (adapter blocks, hint-encoder conv operands), as ControlLoRATrainer.load_state_dict does
             for _ in range(2):
                 tr.step_graphed(*args)
         else:

@@ -242,6 +242,20 @@ def test_groupnorm_wide_groups(B, HW, C, G):
     KC.case_groupnorm("cpu", B, HW, C, G, True, seed=B + HW)
 
 
+@pytest.mark.parametrize("B,HW,Ca,Cb,G,silu", [(2, 64, 320, 320, 32, True), (1, 256, 640, 320, 32, True), (2, 16, 1280, 1280, 32, True),
+                                               (1, 300, 64, 32, 8, False), (2, 9, 1280, 640, 32, True), (1, 1024, 320, 640, 32, True),
+                                               (3, 37, 8, 56, 8, True)])
+def test_groupnorm_concat_in_place(B, HW, Ca, Cb, G, silu):
+    KC.case_groupnorm_concat("cpu", B, HW, Ca, Cb, G, silu)
+
+
+@pytest.mark.parametrize("B,HW,C,Kd,G,split,lora", [(2, 16, 128, 256, 8, 2, False), (2, 64, 320, 320, 32, 3, True), (1, 256, 640, 128, 32, 2, False),
+                                                    (2, 300, 64, 96, 8, 2, True),       # two-launch GroupNorm plan: finished first
+                                                    (1, 16, 1280, 256, 32, 4, True), (2, 64, 64, 128, 8, 1, False)])
+def test_deferred_split_k_finish_in_the_norm_kernels(B, HW, C, Kd, G, split, lora):
+    KC.case_deferred_finish("cpu", B, HW, C, Kd, G, split, lora=lora)
+
+
 @pytest.mark.parametrize("M,C", [(37, 320), (9, 1280), (5, 64)])
 def test_layernorm(M, C):
     KC.case_layernorm("cpu", M, C)

@@ -168,6 +168,21 @@ def test_groupnorm(B, HW, C, G, silu, train):
     KC.case_groupnorm(DEV, B, HW, C, G, silu, train_params=train)
 
 
+@pytest.mark.parametrize("B,HW,Ca,Cb,G,silu", [(4, 4096, 320, 320, 32, True), (4, 4096, 640, 320, 32, True), (4, 1024, 640, 640, 32, True),
+                                               (4, 1024, 1280, 640, 32, True), (4, 256, 1280, 1280, 32, True), (4, 64, 1280, 1280, 32, True),
+                                               (1, 300, 64, 32, 8, False)])
+def test_groupnorm_concat_in_place(B, HW, Ca, Cb, G, silu):
+    """the up-path resnets' norm1 at the train shapes (512^2 bs 4): concatenation read in place == materialised, bit for bit"""
+    KC.case_groupnorm_concat(DEV, B, HW, Ca, Cb, G, silu)
+
+
+@pytest.mark.parametrize("B,HW,C,Kd,G,split,lora", [(4, 256, 1280, 2560, 32, 4, False), (4, 1024, 640, 640, 32, 2, True), (4, 64, 1280, 1280, 32, 6, True),
+                                                    (4, 4096, 320, 320, 32, 2, False),   # 64x64 maps: two-launch plan, finished first
+                                                    (2, 16, 128, 256, 8, 2, False), (4, 256, 1280, 1280, 32, 3, True), (2, 64, 64, 128, 8, 1, False)])
+def test_deferred_split_k_finish_in_the_norm_kernels(B, HW, C, Kd, G, split, lora):
+    KC.case_deferred_finish(DEV, B, HW, C, Kd, G, split, lora=lora)
+
+
 @pytest.mark.parametrize("M,C", [(4096, 320), (1024, 640), (259, 1280)])
 def test_layernorm(M, C):
     KC.case_layernorm(DEV, M, C)

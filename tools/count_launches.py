@@ -35,10 +35,30 @@ def main():
     counts, phase = collections.Counter(), ["setup"]
     real_call = lib.call
 
+    seq = []
+
     def fake_call(name, *args):
         if name in ("clora_set_option", "clora_comm_library"):
             return real_call(name, *args)
         counts[(phase[0], name)] += 1
+        if a.detail and phase[0] == "step":
+            if name == "clora_gemm_f16_ex":
+                A_, lda, B_, C_, ldc, M, N, K_, conv, epi, split, cfg = args[:12]
+                e = epi._obj if hasattr(epi, "_obj") else None
+                cv = conv._obj if conv is not None and hasattr(conv, "_obj") else None
+                seq.append(("gemm", M, N, K_, "conv" if cv is not None else "", split, cfg, A_, C_,
+                            "res" if (e is not None and e.residual) else "", "rowadd" if (e is not None and e.rowadd) else "",
+                            "lora" if (e is not None and e.lora_t) else "", "geglu%d" % e.geglu if (e is not None and e.geglu) else ""))
+            elif name == "clora_groupnorm_fwd_f16":
+                seq.append(("gn_fwd", args[5], args[6], args[7], args[0], args[1]))
+            elif name == "clora_groupnorm_bwd_f16":
+                seq.append(("gn_bwd", args[9], args[10], args[11], args[1], args[3]))
+            elif name == "clora_layernorm_fwd_f16":
+                seq.append(("ln_fwd", args[4], args[5], args[0], args[1]))
+            elif name == "clora_layernorm_bwd_f16":
+                seq.append(("ln_bwd", args[5], args[6], args[1], args[3]))
+            else:
+                seq.append((name.replace("clora_", ""),))
 
     lib.call = fake_call
     capi._LIB = lib
@@ -63,6 +83,9 @@ def main():
             by[name] += v
     for name, v in by.most_common():
         print(f"  {v:5d}  {name}")
+    if a.detail:
+        for rec in seq:
+            print("  ".join(str(x) for x in rec))
 
 
 if __name__ == "__main__":
