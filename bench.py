@@ -97,7 +97,7 @@ def _pick_cpu_threads(unet, b):
     loses to a smaller pool on many-core hosts (oversubscribed SMT / NUMA).  One UNet forward per candidate, ~2-3 s each."""
     import os as _os
     hw = _os.cpu_count() or 1
-    cands = sorted({c for c in (hw // 2, hw // 4, hw // 8, 32, min(hw, 8)) if 1 <= c <= hw}, reverse=True)   # all `hw` threads lost 5x on the GPU hosts
+    cands = sorted({c for c in (hw // 2, hw // 4, hw // 8, 32, 16, min(hw, 8)) if 1 <= c <= hw}, reverse=True)   # all `hw` threads lost 5x on the GPU hosts
     best, best_t = torch.get_num_threads(), None
     with torch.no_grad():
         for c in cands:
@@ -112,11 +112,35 @@ def _pick_cpu_threads(unet, b):
     return best
 
 
+def _cpu_limits():
+    """what the container may actually use of the host's hardware threads: the scheduler affinity mask and the cgroup CPU quota
+    (cgroup v2 `cpu.max`, v1 `cpu.cfs_quota_us / cpu.cfs_period_us`) -- a quota of e.g. 8 CPUs on a 256-thread host is why the
+    oracle is fastest on 8 threads there"""
+    out = {"hardware_threads": os.cpu_count()}
+    try:
+        out["affinity"] = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        pass
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        quota = None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            quota = None if q <= 0 else q / per
+        except (OSError, ValueError):
+            pass
+    out["cgroup_cpu_quota"] = round(quota, 2) if quota is not None else "none"
+    return out
+
+
 def cpu_baseline(steps=3, full=False):
     """The CPU oracle (pure-torch fp32 restatement of the reference path, materialised attention) on BASELINE
     configs[0]: fill50k.json, SD-1.5, 256x256, batch 1.  Bounded sample: 1 warm-up + `steps` timed steps (SURVEY.md
-    section 8d asks for >= 3).  full=True (--cpu-baseline-full) adds one 512x512 bs1 step and the oracle's DDIM + CFG
-    UNet evaluation (batch 2) at 512x512: minutes of CPU work, reported in extra keys."""
+    section 8d asks for >= 3) plus one timed 512x512 bs1 step (train_512_bs1).  full=True (--cpu-baseline-full) adds the oracle's
+    DDIM + CFG UNet evaluation (batch 2) at 512x512: minutes of CPU work, reported in extra keys."""
     from oracle import cases, unet_ref
     from oracle.controllora_ref import ControlLoRARef, map_processors_to_unet
     torch.manual_seed(0)
@@ -153,10 +177,14 @@ def cpu_baseline(steps=3, full=False):
            "sample": f"oracle (pure-torch fp32, materialised attention) train step, fill50k.json SD-1.5 256x256 bs1, "
                      f"{steps} steps after 1 warm-up, {sec:.2f} s/step, {threads} of {os.cpu_count()} hardware threads "
                      f"(fastest of the candidates tried)"}
+    out["host_cpu"] = _cpu_limits()
+    # the like-for-like resolution ("512x512 too, rather than extrapolating"): one timed 512x512 bs 1 step after
+    # one warm-up step, ~10 s of CPU work, part of the default line since round 6
+    inp512 = batch_of(512)
+    sec512 = timed_steps(inp512, 1)
+    out["train_512_bs1"] = {"s_per_step": round(sec512, 2), "images_per_s": round(1.0 / sec512, 4), "steps": 1,
+                            "what": "the same oracle step at BASELINE configs[1]'s resolution, batch 1 (1 timed step after 1 warm-up)"}
     if full:
-        inp512 = batch_of(512)
-        sec512 = timed_steps(inp512, 1)
-        out["train_512_bs1"] = {"s_per_step": round(sec512, 2), "images_per_s": round(1.0 / sec512, 4), "steps": 1}
         with torch.no_grad():
             clora(inp512["guide"])
             x = torch.cat([inp512["latents"]] * 2)

@@ -6,6 +6,17 @@
 #include "clora_common.h"
 #include "../../include/clora.h"
 
+// The residual add of the epilogue (x + f(x): ResnetBlock2D, every BasicTransformerBlock sub-layer, Transformer2DModel).
+// Until round 6 the branch was rounded to fp16 FIRST and the sum again -- the reference's fp16 arithmetic (`hidden_states = attn(...) +
+// hidden_states` on fp16 tensors).  Now the sum is formed from the fp32 accumulator and rounded once: one rounding fewer per residual
+// site (~100 per UNet evaluation), which is what stands between the product and the fp32 oracle (parity target of north_star).
+// -DCLORA_RES_ADD_TWICE restores the double rounding for A/B.
+#ifdef CLORA_RES_ADD_TWICE
+#define CLORA_RES_ADD(acc_f32, rounded_f16, res_f16) ((half_t)((float)(rounded_f16) + (float)(res_f16)))
+#else
+#define CLORA_RES_ADD(acc_f32, rounded_f16, res_f16) ((half_t)((acc_f32) + (float)(res_f16)))
+#endif
+
 namespace {
 
 // everything of the epilogue that happens BEFORE the fp16 rounding (scalar form: split-K finish, v1 kernel)
@@ -192,7 +203,7 @@ __device__ __forceinline__ half8 finish_chunk8(const float* partial, int splits,
     for (int e = 0; e < 8; ++e) v[e] = (half_t)s[e];
     if (epi.residual) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)rr[e]);
+        for (int e = 0; e < 8; ++e) v[e] = CLORA_RES_ADD(s[e], v[e], rr[e]);
     }
     return v;
 }

@@ -401,7 +401,11 @@ __device__ __forceinline__ void dma_epilogue(const GemmArgs& p, floatx4 (&acc)[B
                         for (int e = 0; e < 8; ++e) {
                             a8[e] = (half_t)va[e];
                             g8[e] = (half_t)vg[e];
+#ifdef CLORA_RES_ADD_TWICE
                             y8[e] = (half_t)((float)a8[e] * gelu_f((float)g8[e]));
+#else
+                            y8[e] = (half_t)(va[e] * gelu_f(vg[e]));             // from the fp32 values: one rounding (see CLORA_RES_ADD)
+#endif
                         }
                         st8((half_t*)p.epi.geglu_y + (size_t)m * F + j, y8);
                         if (p.C) {
@@ -477,10 +481,10 @@ __device__ __forceinline__ void dma_epilogue(const GemmArgs& p, floatx4 (&acc)[B
                     st8(p.C + (size_t)m * p.ldc + F + n, dg);
                     return;
                 }
-                if (p.epi.residual) {
+                if (p.epi.residual) {                          // the sum is formed in fp32 and rounded ONCE (CLORA_RES_ADD, clora_epilogue.h)
                     const half8 rr = ld8((const half_t*)p.epi.residual + (size_t)m * p.epi.ldr + n);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) o[e] = (half_t)((float)o[e] + (float)rr[e]);
+                    for (int e = 0; e < 8; ++e) o[e] = CLORA_RES_ADD(v[e], o[e], rr[e]);
                 }
                 st8(p.C + (size_t)m * p.ldc + n, o);
             }
@@ -550,7 +554,7 @@ __device__ __forceinline__ void dma_epilogue(const GemmArgs& p, floatx4 (&acc)[B
                         for (int e = 0; e < 8; ++e) o[e] = (half_t)v[e];
                         if (has_res) {
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) o[e] = (half_t)((float)o[e] + (float)rrs[it][e]);
+                            for (int e = 0; e < 8; ++e) o[e] = CLORA_RES_ADD(v[e], o[e], rrs[it][e]);
                         }
                         st8(p.C + (size_t)m * p.ldc + n, o);
                     }
@@ -1466,7 +1470,7 @@ int conv_mode(const GemmArgs& a, int bk) {
 // panels of its range under either order.   "tile_order": 0 m-major always, 1 n-major always
 // (tests), 2 pick by the model, 3 (default since round 5: live PMC traffic 1.69x -> 1.59x of the algorithmic bytes, bit-identical
 // outputs) = 2 plus a per-XCD rectangle of tiles where whole divisors exist.
-int g_opts[CLORA_OPT_COUNT] = {3, 1, 0, 0, 512, 1, 1, 0, 1, 1};    // tile_order, ln_rows, attn_fwd_waves (0 = auto), attn_bwd_waves (0 = auto), gn_blocks, epi_two_phase, lora_down_mode, gn_unroll, epi_hoist, gn_resident
+int g_opts[CLORA_OPT_COUNT] = {3, 1, 0, 0, 512, 1, 1, 0, 1, 1, 4};    // tile_order, ln_rows, attn_fwd_waves (0 = auto), attn_bwd_waves (0 = auto), gn_blocks, epi_two_phase, lora_down_mode, gn_unroll, epi_hoist, gn_resident, defer_max_rows
 int tile_order_mode() { return g_opts[CLORA_OPT_TILE_ORDER]; }
 
 double fabric_model_bytes(int tiles_m, int tiles_n, int splits, double a_panel, double b_panel, bool n_major) {
@@ -1846,7 +1850,8 @@ extern "C" int clora_set_option(const char* name, int value) {
                                 {"attn_fwd_waves", CLORA_OPT_ATTN_FWD_WAVES, 0, 16}, {"attn_bwd_waves", CLORA_OPT_ATTN_BWD_WAVES, 0, 8},
                                 {"gn_blocks", CLORA_OPT_GN_BLOCKS, 64, 1 << 16}, {"epi_two_phase", CLORA_OPT_EPI_TWO_PHASE, 0, 1},
                                 {"lora_down_mode", CLORA_OPT_LORA_DOWN_MODE, 0, 2}, {"gn_unroll", CLORA_OPT_GN_UNROLL, 0, 1},
-                                {"epi_hoist", CLORA_OPT_EPI_HOIST, 0, 1}, {"gn_resident", CLORA_OPT_GN_RESIDENT, 0, 1}};
+                                {"epi_hoist", CLORA_OPT_EPI_HOIST, 0, 1}, {"gn_resident", CLORA_OPT_GN_RESIDENT, 0, 1},
+                                {"defer_max_rows", CLORA_OPT_DEFER_MAX_ROWS, 0, 16}};
     for (const Opt& o : kOpts)
         if (!strcmp(name, o.name)) {
             if (value < o.lo || value > o.hi) return CLORA_ERR_ARG;

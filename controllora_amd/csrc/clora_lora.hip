@@ -178,8 +178,12 @@ __global__ __launch_bounds__(256) void lora_up_kernel(UpJobs jobs) {
             const half8 bv = ld8(p.base + m * p.ldb + n);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const half_t c16 = (half_t)(p.scale * (float)(half_t)acc[e]);  // fp16(scale * fp16(up(down)))
+#ifdef CLORA_RES_ADD_TWICE
+                const half_t c16 = (half_t)(p.scale * (float)(half_t)acc[e]);  // fp16(scale * fp16(up(down))): the reference's fp16 arithmetic
                 o[e] = (half_t)((float)bv[e] + (float)c16);
+#else
+                o[e] = (half_t)((float)bv[e] + p.scale * acc[e]);              // round 6: base + update formed in fp32, ONE rounding (clora_epilogue.h CLORA_RES_ADD)
+#endif
             }
         } else {
 #pragma unroll

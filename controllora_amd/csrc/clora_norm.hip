@@ -1042,13 +1042,18 @@ extern "C" int clora_groupnorm_fwd_f16_ex(const clora_half* x, const clora_half*
     a.B = B; a.HW = HW; a.C = C; a.G = G; a.eps = eps; a.fuse_silu = fuse_silu;
     a.x2 = (const half_t*)x2; a.Ca = x2 ? Ca : C; a.xcopy = (half_t*)xcopy;
     const GnResident res = gn_resident_plan(a, false, false);
-    if (deferred && !res.nt) {                                   // two-pass plan: finish first, then the plain passes over src->C
+    // Folding pays only where a thread owns few rows (npt <= 4: the 8x8 / 16x16 maps): the one-launch kernels run 32-128 blocks and a
+    // thread's rows are folded one after the other -- measured on MI355X (profiles/r06_deferred_ab.txt): 9.6 us against 6.6 + 6.0 for
+    // finish + plain at npt 4, but 17.4 against 8.1 + 6.0 at npt 8 and 36.2 against 13.9 + 6.0 at npt 16.  Everything else: the
+    // plain finish pass (2048 blocks) first.
+    bool deferred_here = deferred && res.nt && res.npt <= clora_option(CLORA_OPT_DEFER_MAX_ROWS);
+    if (deferred && !deferred_here) {                            // finish first, then the plain passes over src->C
         const int rc = clora_finish_deferred(src, stream);
         if (rc != CLORA_OK) return rc;
     }
     if (res.nt) {
         const dim3 rgrid(1, a.nslab, B);
-        if (deferred) {
+        if (deferred_here) {
             a.fin_partial = src->partial; a.fin_splits = src->splits; a.fin_epi = src->epi; a.xcopy = (half_t*)src->C;
             if (res.nt == 256 && res.npt == 4) hipLaunchKernelGGL((gn_fwd_resident_kernel<256, 4, true>), rgrid, dim3(256), 0, s, a);
             else if (res.nt == 256 && res.npt == 8) hipLaunchKernelGGL((gn_fwd_resident_kernel<256, 8, true>), rgrid, dim3(256), 0, s, a);
@@ -1109,13 +1114,14 @@ extern "C" int clora_groupnorm_bwd_f16_ex(const clora_half* x, const clora_half*
     a.y2 = (half_t*)dx2; a.Ca = dx2 ? Ca : C;
     hipStream_t s = (hipStream_t)stream;
     const GnResident res = gn_resident_plan(a, true, dgamma != nullptr);
-    if (deferred && !res.nt) {
+    const bool deferred_here = deferred && res.nt && res.npt <= clora_option(CLORA_OPT_DEFER_MAX_ROWS);      // see the forward
+    if (deferred && !deferred_here) {
         const int rc = clora_finish_deferred(dy_src, stream);
         if (rc != CLORA_OK) return rc;
     }
     if (res.nt) {
         const dim3 rgrid(1, a.nslab, B);
-        if (deferred) {
+        if (deferred_here) {
             a.fin_partial = dy_src->partial; a.fin_splits = dy_src->splits; a.fin_epi = dy_src->epi;
             if (res.nt == 256 && res.npt == 4) hipLaunchKernelGGL((gn_bwd_resident_kernel<256, 4, true>), rgrid, dim3(256), 0, s, a);
             else if (res.nt == 256) hipLaunchKernelGGL((gn_bwd_resident_kernel<256, 8, true>), rgrid, dim3(256), 0, s, a);
@@ -1169,7 +1175,9 @@ extern "C" int clora_layernorm_bwd_f16_ex(const clora_half* x, const clora_half*
     if (!dy) return CLORA_ERR_ARG;
     LnArgs a = LnArgs();
     a.x = (const half_t*)x; a.dy = (const half_t*)dy; a.dres = (const half_t*)dres; a.y = (half_t*)dx; a.gamma = gamma; a.M = M; a.C = C; a.eps = eps;
-    if (deferred && ln_rows_plan(a, true)) {
+    // (measured: the folded LayerNorm backward costs 13.0 / 18.4 us against 7.5 / 5.7 + 6.0 for finish + plain at C = 640 / 1280 -- a lane
+    // folds its 2-3 chunks one after the other; it is taken only with the "defer_max_rows" knob at 16, the A/B setting)
+    if (deferred && ln_rows_plan(a, true) && clora_option(CLORA_OPT_DEFER_MAX_ROWS) >= 16) {
         a.fin_partial = dy_src->partial; a.fin_splits = dy_src->splits; a.fin_epi = dy_src->epi;
         launch_layernorm<true, true>(a, (hipStream_t)stream);
         return clora_check_launch();

@@ -541,7 +541,7 @@ def down_job(X, D, T, toff, M, K, accumulate=False, x_rows=0, ldx=None, kmajor=F
 
 
 def up_job(base, T, toff, U, Y, M, N, scale, u_tr=False):
-    """one problem of lora_up_multi: Y = base + fp16(scale * fp16(T[:, toff:toff+R] . U^T))"""
+    """one problem of lora_up_multi: Y = fp16(base + scale * T[:, toff:toff+R] . U^T), one rounding (base None: fp16(scale * fp16(T . U^T)))"""
     assert U.dtype == f32 and U.stride(1) == 1 and T.dtype == f32 and Y.dtype == f16
     return capi.LoraUpJob(ptr(base, f16) if base is not None else None, base.stride(0) if base is not None else 0, ptr(T), T.stride(0),
                           toff, ptr(U), U.stride(0), int(u_tr), ptr(Y), Y.stride(0), M, N, U.shape[0] if u_tr else U.shape[1], float(scale))
@@ -661,7 +661,7 @@ def lora_wgrad_flush():
 
 
 def lora_up(base, T, toff, U, M, N, scale, out=None, u_tr=False):
-    """Y = base + fp16(scale * fp16(T[:, toff:toff+R] . U^T)); U is [N, R], or with u_tr a down matrix [R, N]."""
+    """Y = fp16(base + scale * T[:, toff:toff+R] . U^T), one rounding (base None: fp16(scale * fp16(T . U^T))); U is [N, R], or with u_tr a down matrix [R, N]."""
     assert U.dtype == f32 and U.stride(1) == 1 and T.dtype == f32
     y = out if out is not None else torch.empty((M, N), dtype=f16, device=T.device)
     _call("clora_lora_up_f16", ptr(base, f16) if base is not None else None, base.stride(0) if base is not None else 0,

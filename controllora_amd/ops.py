@@ -1024,8 +1024,8 @@ def lora_proj(x, pack: LinearPack, segs: Sequence[Optional[Tuple[torch.Tensor, t
 
 
 class _ControlAddFn(torch.autograd.Function):
-    """y = h + fp16(scale * fp16(up(down(ctrl))))            (v1, reference models.py:214-218, 237-238)
-       y = h + fp16(scale * fp16(up(down(cat(h, ctrl)))))    (concat_hidden / V2, models.py:209-214, 343-349)
+    """y = fp16(h + scale * up(down(ctrl)))                  (v1, reference models.py:214-218, 237-238)
+       y = fp16(h + scale * up(down(cat(h, ctrl))))          (concat_hidden / V2, models.py:209-214, 343-349)
     ctrl [Mc, Cc] may hold fewer batch elements than h (control batch 1 broadcast, quirk C6)."""
 
     @staticmethod
@@ -1418,7 +1418,7 @@ def control_q_parts(terms, q_downs):
 
 
 class _LoraApplyFn(torch.autograd.Function):
-    """y = base + fp16(scale * fp16(up(down(x))))  -- one LoRALinearLayer applied the way the reference writes it
+    """y = fp16(base + scale * up(down(x)))  -- one LoRALinearLayer applied where the reference writes it
     (`t = t + scale * lora(x)`, models.py:125-147, 232-282).  Building block of the generic (unfused) processor
     path: post_add=True and pre_loras / post_loras chains, where adapter inputs depend on earlier adapter outputs."""
 

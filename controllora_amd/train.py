@@ -289,11 +289,34 @@ class ControlLoRATrainer:
         return self
 
     def _capture_optimizer_graph(self):
+        """exchange + clip + AdamW + repack as one hipGraph.  With the C ABI's communicator (comm "clora") the all-reduce is captured
+        INSIDE it -- RCCL enqueues on the capturing stream -- so a rank's step is two graph replays and no host-issued collective
+        (round 6; reference train...:683-685, 790: DDP's reduce inside `accelerator.backward`).  torch.distributed's all-reduce
+        (comm "torch") stays an eager call between the two graphs; so does "clora" if RCCL refuses the capture (loud fallback)."""
         from . import ops
+        import sys as _sys
         torch.cuda.synchronize()
-        self._g_opt = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._g_opt, pool=self._g_fb.pool()):
-            self._optimizer_kernels()
+        want = self.comm == "clora" and (self.world > 1 or getattr(self, "exchange_at_world_1", False)) and \
+            getattr(self, "_exchange_in_graph", None) is not False
+        self._exchange_in_graph = False
+        if want:
+            try:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=self._g_fb.pool()):
+                    self._all_reduce_grads()
+                    self._optimizer_kernels()
+                self._g_opt, self._exchange_in_graph = g, True
+            except Exception as e:                                   # noqa: BLE001 -- RCCL refused the capture: eager exchange
+                torch.cuda.synchronize()
+                self.exchange_capture_error = repr(e)
+                print(f"[controllora_amd] WARNING: the RCCL all-reduce could not be captured into the optimizer graph ({e!r}); "
+                      "it stays an eager call between the two graphs", file=_sys.stderr, flush=True)
+        if not self._exchange_in_graph:
+            if want:
+                self._exchange_in_graph = False                      # remembered: later re-captures do not try again
+            self._g_opt = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._g_opt, pool=self._g_fb.pool()):
+                self._optimizer_kernels()
         self._pack_epoch = ops.ADAPTER_PACKS.epoch       # the captured repack launch covers the adapter groups registered so far
 
     def step_graphed(self, noisy_latents=None, timesteps=None, encoder_hidden_states=None, guide=None, target=None):
@@ -303,7 +326,9 @@ class ControlLoRATrainer:
         assert self.accum == 1, "the captured step assumes one micro-batch per optimizer step"
         self._reduced = False
         self._g_fb.replay()
-        if self.world > 1:
+        if self._exchange_in_graph:
+            self._reduced = self.world > 1                           # the all-reduce is the first node of the optimizer graph
+        elif self.world > 1:
             self._all_reduce_grads()
             self._reduced = True
         if self.lr_lambda is not None:

@@ -195,6 +195,10 @@ int clora_conv_patch_eligible(int M, const clora_conv_t* conv, int tile_cfg);
  *   "gn_resident"     1 = GroupNorm passes whose (batch element, channel slab) fits in a block's registers run as ONE launch (statistics
  *                     and apply from the same registers: the 8x8 / 16x16 / 32x32 feature maps of the UNet); 0 = always the two-launch
  *                     partial + apply scheme.  Frozen affine only; same arithmetic, a different (still fixed) summation order.
+ *   "defer_max_rows"  a deferred split-K GEMM (clora_deferred_t) is folded inside the one-launch GroupNorm kernels whose threads own at
+ *                     most this many rows (default 4: the 8x8 / 16x16 maps, where it is faster than finish + plain); above it -- and in
+ *                     the LayerNorm backward unless the value is 16 -- the library runs the plain finish pass first.  0 = never fold.
+ *                     Bit-identical results at every setting.
  * Unknown names / values: CLORA_ERR_ARG. */
 int clora_set_option(const char* name, int value);
 
@@ -378,8 +382,9 @@ int clora_rank_mix_f32(const clora_rank_site_t* sites, int n, int backward, floa
 size_t clora_rank_gram_ws_bytes(int rows, int n);
 int clora_rank_compose_bwd_f32(const clora_rank_site_t* sites, int n, const float* gram_ws, void* stream);
 
-/* Y[m,n] = (base ? base[m,n] : 0) + fp16(scale * fp16(sum_j T[m,toff+j] U[n,j]))  -- the explicit
- * "hidden + to_control(control)" of models.py:214-218,237-238 and the V2 pre/post adds (:369,:415). */
+/* base != NULL: Y[m,n] = fp16(base[m,n] + scale * sum_j T[m,toff+j] U[n,j])  -- the explicit "hidden + to_control(control)" of
+ * models.py:214-218,237-238 and the V2 pre/post adds (:369,:415), the sum formed in fp32 and rounded once (round 6; until then the
+ * update was rounded twice first, the reference's fp16 arithmetic);  base == NULL: Y = fp16(scale * fp16(sum_j ...)), the term alone. */
 int clora_lora_up_f16(const clora_half* base, int ldb, const float* T, int ldt, int toff, const float* U, int ldu,
                       int u_transposed, clora_half* Y, int ldy, int M, int N, int R, float scale, void* stream);
 /* several of them in one launch: the control terms of the 10 attention sites of a UNet level share one hint-encoder

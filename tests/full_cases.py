@@ -284,7 +284,7 @@ def load_fixture(name):
         return {k: f.get_tensor(k) for k in f.keys()}, f.metadata()
 
 
-def train_step_vs_fixture(dev, fixture="full_train_512_bs4.safetensors"):
+def train_step_vs_fixture(dev, fixture="full_train_512_bs4.safetensors", regime_floor=False):
     """BASELINE configs[1] (configs/fill50k.json, SD-1.5 topology, 512x512, batch 4; reference train...:751-796) -- or, with
     fixture="full_train_512_bs8_v2.safetensors", BASELINE configs[3] as quoted (configs/mpii-pose-v2.json, batch 8; reference
     models.py:292-431): the product train step on the GPU against the committed oracle record -- prediction, loss, the four
@@ -325,11 +325,55 @@ def train_step_vs_fixture(dev, fixture="full_train_512_bs4.safetensors"):
     got = torch.stack([c.double().norm() for c in torch.split(grads, sizes)])
     big = want > 1e-3 * want.max()
     errs["param_norm_worst"] = float(((got - want).abs() / want)[big].max())
+    relerr = ((got - want).abs() / want) * big
+    errs["param_norm_worst_name"] = names[int(relerr.argmax())]
     errs["param_norm_small_abs_worst"] = float(((got - want).abs()[~big]).max() / want.max()) if bool((~big).any()) else 0.0
     errs["n_params"] = len(names)
     errs["oracle_seconds"] = float(fx["oracle_seconds"])
     errs["clora_impl"] = meta.get("clora_impl", "restatement")
+    if regime_floor:
+        errs["fp16_regime"] = fp16_regime_train_step_errs(o_unet, o_clora, inp, fx, meta, sizes, dev)
     return errs
+
+
+def fp16_regime_train_step_errs(o_unet, o_clora, inp, fx, meta, sizes, dev, loss_scale=1024.0):
+    """The ORACLE's train step in the reference's fp16 arithmetic (oracle/precision_regimes.py "fp16": stock torch ops, every
+    weight / activation / gradient in fp16, loss scaled like the product's trainer), run on the GPU, against the same committed fp32
+    record: the distance any fp16 implementation of this step sits from the fixture -- for the quantities that have no other
+    measured regime figure (gradient samples / norms, per-parameter norms, control maps)."""
+    from oracle import precision_regimes as PR
+    from oracle.unet_ref import DDPMSchedule
+    import torch.nn.functional as Fn
+    u16, c16 = PR.build_regime(o_unet, o_clora, "fp16", dev)
+    for p in u16.parameters():
+        p.requires_grad_(False)
+    for p in c16.parameters():
+        p.requires_grad_(True)
+        p.grad = None
+    ctrl = c16(inp["guide"].to(dev).half()).control_states
+    noisy = DDPMSchedule().add_noise(inp["latents"], inp["noise"], inp["timesteps"]).to(dev).half()
+    pred = u16(noisy, inp["timesteps"].to(dev), inp["ehs"].to(dev).half()).sample
+    loss = Fn.mse_loss(pred.float(), inp["noise"].to(dev).float(), reduction="mean")
+    (loss * loss_scale).backward()
+    grads = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).float() for p in c16.parameters()]).cpu() / loss_scale
+    assert grads.numel() == sum(sizes)
+    sg, sc = int(meta["stride_grad"]), int(meta["stride_ctrl"])
+    r = {"pred": rel(pred, fx["pred"]), "grads_sample": rel(grads[::sg], fx["grads_sample"]),
+         "grads_norm": abs(float(grads.double().norm()) - float(fx["grads_norm"])) / float(fx["grads_norm"])}
+    if "grads_sample2" in fx:
+        r["grads_sample2"] = rel(grads[::int(meta["stride_grad2"])], fx["grads_sample2"])
+    for i, c in enumerate(ctrl):
+        c = c.detach().float().cpu()
+        r[f"control_{i}"] = rel(c.reshape(-1)[::sc], fx[f"control_{i}_sample"])
+        r[f"control_{i}_norm"] = abs(float(c.double().norm()) - float(fx[f"control_{i}_norm"])) / float(fx[f"control_{i}_norm"])
+    want = fx["grads_param_norms"].double()
+    got = torch.stack([c.double().norm() for c in torch.split(grads, sizes)])
+    big = want > 1e-3 * want.max()
+    r["param_norm_worst"] = float(((got - want).abs() / want)[big].max())
+    r["finite"] = bool(torch.isfinite(grads).all())
+    del u16, c16
+    torch.cuda.empty_cache()
+    return r
 
 
 class _StopSampling(Exception):

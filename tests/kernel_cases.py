@@ -518,6 +518,17 @@ def case_groupnorm_concat(dev, B, HW, Ca, Cb, G, silu, eps=1e-5, seed=11):
 
 
 def case_deferred_finish(dev, B, HW, C, Kd, G, split, silu=True, seed=12, lora=False):
+    """both settings of the "defer_max_rows" knob: the default (fold only in the few-rows-per-thread GroupNorm plans, finish first
+    elsewhere) and 16 (fold wherever a folding kernel exists, incl. the LayerNorm backward) -- bit-identical either way"""
+    for rows in (16, int(os.environ.get("CLORA_DEFER_MAX_ROWS", "4"))):
+        K.set_option("defer_max_rows", rows)
+        try:
+            _case_deferred_finish(dev, B, HW, C, Kd, G, split, silu, seed, lora)
+        finally:
+            K.set_option("defer_max_rows", int(os.environ.get("CLORA_DEFER_MAX_ROWS", "4")))
+
+
+def _case_deferred_finish(dev, B, HW, C, Kd, G, split, silu=True, seed=12, lora=False):
     """Round 6 (clora_deferred_t): a split-K GEMM whose finish pass is left to the GroupNorm / LayerNorm launch that reads its output
     == the same GEMM with its own finish pass followed by the plain norm launch, BIT for bit -- forward GroupNorm (the finished
     tensor must also land in the GEMM's C), GroupNorm backward and LayerNorm backward with the GEMM producing dy; epilogue = bias +
@@ -738,9 +749,10 @@ def case_feed_forward_fused(dev, M=200, C=64, seed=12, tile_cfg=0):
     xu = x.clone().requires_grad_(True)
     out_u = ops.frozen_linear(ops.geglu(ops.frozen_linear(xu, lp1)), p2, res)
     out_u.backward(dout)
-    # same rounding points as the unfused kernels; the compiler may contract the activation's fp32 expressions differently in
-    # the two kernels (fma formation), so allow last-bit differences of a few fp16 values
-    assert rel(out, out_u) < 2e-4, rel(out, out_u)
+    # round 6: the fused forward forms a * gelu(g) from the fp32 accumulators and adds the residual in fp32 (ONE rounding each, the
+    # unfused kernels round a, g and the branch first): the two differ by fp16 rounding, and the fused result must not be farther
+    # from the fp32 reference than the unfused one (checked below); the backward reads the same stored fp16 h in both
+    assert rel(out, out_u) < 6e-4, rel(out, out_u)
     assert rel(xf.grad, xu.grad) < 2e-4, rel(xf.grad, xu.grad)
     # (ii) fp32 reference
     x32 = x.float().cpu().requires_grad_(True)
@@ -749,6 +761,7 @@ def case_feed_forward_fused(dev, M=200, C=64, seed=12, tile_cfg=0):
     ref = F.linear(a * F.gelu(gg), w2.float().cpu(), b2.float().cpu()) + res.float().cpu()
     ref.backward(dout.float().cpu())
     assert rel(out, ref.detach()) < 2e-3, rel(out, ref.detach())
+    assert rel(out, ref.detach()) <= 1.05 * rel(out_u, ref.detach()), (rel(out, ref.detach()), rel(out_u, ref.detach()))
     assert rel(xf.grad, x32.grad) < 3e-3, rel(xf.grad, x32.grad)
     # inference: no h is written
     with torch.no_grad():

@@ -187,3 +187,43 @@ def test_c_abi_rccl_exchange_single_rank():
     assert torch.equal(g, before)
     tr._init_clora_comm(None, 1)                                   # idempotent: a second trainer joins the existing communicator
     assert capi.lib().cdll.clora_comm_destroy() == 0 and capi.lib().cdll.clora_comm_world() == 0
+
+
+def test_exchange_captured_inside_the_optimizer_graph_single_rank():
+    """Round 6: with the C ABI's communicator the all-reduce is a node of the optimizer hipGraph (RCCL enqueues on the capturing
+    stream; reference train...:683-685, 790: DDP reduces inside `accelerator.backward`) -- a rank's step is two graph replays and
+    no host-issued collective.  One GPU here: a communicator of one rank (`exchange_at_world_1`), graph replay == eager steps
+    on parameters, loss and step count, and the capture must really contain the exchange."""
+    from controllora_amd import capi
+    from controllora_amd.train import ControlLoRATrainer
+    from oracle import cases, unet_ref
+    out = []
+    for graphed in (False, True):
+        torch.manual_seed(0)
+        unet, params, clora = E.build_product_case("v1", "cuda")
+        inp = {k: v.cuda() for k, v in cases.seeded_inputs().items()}
+        noisy = unet_ref.DDPMSchedule().add_noise(inp["latents"].cpu(), inp["noise"].cpu(), inp["timesteps"].cpu()).cuda().half()
+        tr = ControlLoRATrainer(unet, params, init_scale=128.0, dynamic_scale=False, comm="clora")
+        tr.exchange_at_world_1 = True
+        args = (noisy, inp["timesteps"], inp["ehs"].half(), inp["guide"].half(), inp["noise"].half())
+        start = tr.flat.data.clone()
+        if graphed:
+            tr.capture(*args, warmup=1)
+            assert tr._exchange_in_graph, getattr(tr, "exchange_capture_error", "the all-reduce was not captured")
+            tr.flat.data.copy_(start); tr.flat.exp_avg.zero_(); tr.flat.exp_avg_sq.zero_(); tr.state[2] = 0
+            from controllora_amd import ops
+            ops.repack_adapters()
+            for _ in range(2):
+                tr.step_graphed(*args)
+        else:
+            for _ in range(2):
+                tr.forward_backward(*args)
+                tr._all_reduce_grads()                 # what world > 1 does eagerly: the sum over one rank
+                tr.optimizer_step()
+        torch.cuda.synchronize()
+        out.append((tr.flat.data.clone(), tr.loss(noisy.numel()), float(tr.state[2])))
+        tr.close()
+    (p0, l0, s0), (p1, l1, s1) = out
+    assert s0 == s1 == 2.0
+    assert abs(l0 - l1) < 1e-5 * max(1.0, abs(l0))
+    assert float((p0 - p1).norm() / p0.norm()) < 1e-5
