@@ -273,8 +273,11 @@ class LoRACrossAttnProcessor(nn.Module):
             src = q if p.post_add else h
             if version == 1 and isinstance(p, ControlLoRACrossAttnProcessor):
                 if p.post_add and p.concat_hidden:
-                    raise NotImplementedError("post_add together with concat_hidden (no shipped config uses it)")
-                src = p.process_control_states(src.reshape(B, N, C_), scale)     # src + scale*to_control(control)
+                    # reference models.py:208-218 with :236-238: the concatenation reads hidden_states, the sum reads the query:
+                    # lora_in = query + scale * to_control(cat(hidden_states, control))
+                    src = ops.add(src, p.process_control_states(h3, scale, term_only=True))
+                else:
+                    src = p.process_control_states(src.reshape(B, N, C_), scale)     # src + scale*to_control(control)
             q = ops.lora_apply(q, src, p.to_q_lora.down.weight, p.to_q_lora.up.weight, scale)
         for p in chain:
             if not p.key_states_skipped:
@@ -382,9 +385,10 @@ class _ControlMixin:
             ctrl = ctrl.repeat_interleave(b2 // b1, dim=0)
         return ctrl.contiguous()
 
-    def process_control_states(self, hidden_states, scale=1.0, is_out=False):
+    def process_control_states(self, hidden_states, scale=1.0, is_out=False, term_only=False):
         """Returns hidden_states + scale * to_control[_out](control | cat(hidden, control)) -- i.e. the sum the
-        reference forms right after calling its process_control_states (control_self_add is always False, C1)."""
+        reference forms right after calling its process_control_states (control_self_add is always False, C1); term_only:
+        the second summand alone (the reference's own return value), for a caller that adds it to another tensor."""
         ctrl = self._control_tokens(hidden_states)
         layer = self.to_control_out if is_out else self.to_control
         # the control map's share of a concat adapter's down-projection, evaluated for the whole level by ControlLoRA.forward
@@ -393,7 +397,7 @@ class _ControlMixin:
         t_ctrl = parts.get(id(layer)) if (parts and self.concat_hidden and ctrl.shape[0] in (1, hidden_states.shape[0])
                                           and ctrl.shape[0] * ctrl.shape[1] == parts["rows"]) else None
         return ops.control_add(_flat2(hidden_states), _flat2(ctrl), layer.down.weight, layer.up.weight, scale,
-                               self.concat_hidden, t_ctrl=t_ctrl)
+                               self.concat_hidden, t_ctrl=t_ctrl, term_only=term_only)
 
 
 class ControlLoRACrossAttnProcessor(_ControlMixin, LoRACrossAttnProcessor):

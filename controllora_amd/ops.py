@@ -1029,7 +1029,9 @@ class _ControlAddFn(torch.autograd.Function):
     ctrl [Mc, Cc] may hold fewer batch elements than h (control batch 1 broadcast, quirk C6)."""
 
     @staticmethod
-    def forward(ctx, h, ctrl, D, U, scale, concat, t_ctrl=None):
+    def forward(ctx, h, ctrl, D, U, scale, concat, t_ctrl=None, term_only=False):
+        # term_only: return the control term alone, fp16(scale * fp16(up(down(...)))) -- for a caller that adds it to ANOTHER tensor
+        # (post_add together with concat_hidden: `query + to_control(cat(hidden_states, control))`, reference models.py:208-218, 236-238)
         M, C_ = h.shape
         Mc, Cc = ctrl.shape
         R = D.shape[0]
@@ -1044,10 +1046,11 @@ class _ControlAddFn(torch.autograd.Function):
             K.lora_down(ctrl, Dd[:, C_:], T, 0, M, Cc, accumulate=True, x_rows=xr)
         else:
             K.lora_down(ctrl, Dd, T, 0, M, Cc, x_rows=xr)
-        y = K.lora_up(h, T, 0, Ud, M, C_, scale)
+        y = K.lora_up(None if term_only else h, T, 0, Ud, M, C_, scale)
         ctx.save_for_backward(h, ctrl, T)
         ctx.params = (D, U)
         ctx.cfg = (scale, concat, xr, t_ctrl is not None)
+        ctx.term_only = term_only
         return y
 
     @staticmethod
@@ -1065,7 +1068,7 @@ class _ControlAddFn(torch.autograd.Function):
         wj = []       # (A, T, toff, G, gs_n, gs_j, N, scale, a_rows): batched below when the rank allows
         if U.requires_grad:
             wj.append((dy, T, 0, _grad_buffer(U), R, 1, C_, scale, 0))
-        dh = dy
+        dh = None if ctx.term_only else dy
         dctrl = None
         if concat:
             if D.requires_grad:
@@ -1073,7 +1076,7 @@ class _ControlAddFn(torch.autograd.Function):
                 wj.append((h, dT, 0, gD, 1, D.shape[1], C_, 1.0, 0))
                 if not parts:
                     wj.append((ctrl, dT, 0, gD[:, C_:], 1, D.shape[1], Cc, 1.0, xr))
-            dh = K.lora_up(dy, dT, 0, Dd[:, :C_], M, C_, 1.0, u_tr=True)
+            dh = K.lora_up(None if ctx.term_only else dy, dT, 0, Dd[:, :C_], M, C_, 1.0, u_tr=True)
             Dc = Dd[:, C_:]
         else:
             if D.requires_grad:
@@ -1088,12 +1091,12 @@ class _ControlAddFn(torch.autograd.Function):
         if parts:
             # d(ctrl) and the control columns of dD are formed once per level from every site's dT (_ControlDownPartsFn.backward)
             dt_ctrl = dT.reshape(M // Mc, Mc, R).sum(0) if xr else dT
-            return dh, None, None, None, None, None, dt_ctrl
+            return dh, None, None, None, None, None, dt_ctrl, None
         if ctx.needs_input_grad[1]:
             dctrl = K.lora_up(None, dT, 0, Dc, M, Cc, 1.0, u_tr=True)
             if xr:
                 dctrl = dctrl.reshape(M // Mc, Mc, Cc).float().sum(0).to(f16)
-        return dh, dctrl, None, None, None, None, None
+        return dh, dctrl, None, None, None, None, None, None
 
 
 class _ControlAddWideFn(torch.autograd.Function):
@@ -1159,10 +1162,10 @@ class _ControlAddWideFn(torch.autograd.Function):
 WIDE_RANK = _os.environ.get("CLORA_WIDE_RANK", "1") != "0"      # "0": rank > 16 adapters stay on the rank-r kernels (A/B)
 
 
-def control_add(h, ctrl, D, U, scale, concat, t_ctrl=None):
-    if WIDE_RANK and D.shape[0] > 16 and t_ctrl is None and D.shape[0] % 8 == 0 and D.shape[1] % 8 == 0 and h.shape[0] % ctrl.shape[0] == 0:
+def control_add(h, ctrl, D, U, scale, concat, t_ctrl=None, term_only=False):
+    if WIDE_RANK and not term_only and D.shape[0] > 16 and t_ctrl is None and D.shape[0] % 8 == 0 and D.shape[1] % 8 == 0 and h.shape[0] % ctrl.shape[0] == 0:
         return _ControlAddWideFn.apply(h, ctrl, D, U, float(scale), bool(concat))
-    return _ControlAddFn.apply(h, ctrl, D, U, float(scale), bool(concat), t_ctrl)
+    return _ControlAddFn.apply(h, ctrl, D, U, float(scale), bool(concat), t_ctrl, bool(term_only))
 
 
 CONTROL_PARTS = _os.environ.get("CLORA_CONTROL_PARTS", "1") != "0"      # "0": every concat adapter projects the control map itself (A/B)

@@ -31,7 +31,12 @@ SMALL_CLORA_SKETCH = dict(SMALL_CLORA_V1, lora_concat_hidden=True, lora_pre_conv
 
 SMALL_CLORA_POSTADD = dict(SMALL_CLORA_V1, lora_post_add=True)
 
-CASES = {"v1": SMALL_CLORA_V1, "v2": SMALL_CLORA_V2, "sketch": SMALL_CLORA_SKETCH, "postadd": SMALL_CLORA_POSTADD}
+# post_add together with concat_hidden (reference models.py:208-218 with :236-238; no shipped config, round 6)
+SMALL_CLORA_POSTADD_CONCAT = dict(SMALL_CLORA_V1, lora_post_add=True, lora_concat_hidden=True, lora_pre_conv_skipped=True,
+                                  lora_control_self_add=False, lora_control_channels=(32, 32, 32))
+
+CASES = {"v1": SMALL_CLORA_V1, "v2": SMALL_CLORA_V2, "sketch": SMALL_CLORA_SKETCH, "postadd": SMALL_CLORA_POSTADD,
+         "postadd_concat": SMALL_CLORA_POSTADD_CONCAT}
 
 LATENT, RES, BATCH, CTX_LEN = 16, 128, 2, 7
 

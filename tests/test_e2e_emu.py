@@ -14,7 +14,7 @@ def _emu():
         yield
 
 
-@pytest.mark.parametrize("case", ["v1", "v2", "sketch", "lora", "postadd"])
+@pytest.mark.parametrize("case", ["v1", "v2", "sketch", "lora", "postadd", "postadd_concat"])
 def test_train_step_matches_reference_golden(case, golden_dir):
     errs = E.check_against_golden(case, "cpu", golden_dir)
     print(case, errs)

@@ -9,7 +9,7 @@ from tests import e2e_cases as E
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("case", ["v1", "v2", "sketch", "lora", "postadd"])
+@pytest.mark.parametrize("case", ["v1", "v2", "sketch", "lora", "postadd", "postadd_concat"])
 def test_train_step_matches_reference_golden(case, golden_dir):
     errs = E.check_against_golden(case, "cuda", golden_dir)
     print(case, errs)
