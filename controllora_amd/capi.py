@@ -39,7 +39,8 @@ class Epilogue(C.Structure):
                 ("lora_u", C.c_void_p), ("ldu", C.c_int), ("lora_u_tr", C.c_int), ("lora_r", C.c_int), ("lora_seg", C.c_int), ("lora_scale", C.c_float),
                 ("geglu", C.c_int), ("geglu_f", C.c_int), ("geglu_h", C.c_void_p), ("geglu_y", C.c_void_p),
                 ("lora_dpack", C.c_void_p), ("lora_t_in", C.c_void_p), ("ldt_in", C.c_int), ("lora_t_in_rows", C.c_int),
-                ("lora_t_in_mask", C.c_uint), ("defer", C.c_void_p)]
+                ("lora_t_in_mask", C.c_uint), ("defer", C.c_void_p),
+                ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p), ("ln_out", C.c_void_p), ("ln_eps", C.c_float)]
 
 
 class Deferred(C.Structure):
@@ -118,6 +119,7 @@ _PROTOS = {
     "clora_groupnorm_bwd_f16_ex": [_P, _P, C.POINTER(Deferred), _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _Z, _P],
     "clora_layernorm_bwd_f16_ex": [_P, _P, C.POINTER(Deferred), _P, _P, _P, _I, _I, _F, _P],
     "clora_finish_deferred": [C.POINTER(Deferred), _P],
+    "clora_gemm_ln_fusable": [_I, _I, _I, _I, _I],
     "clora_layernorm_fwd_f16": [_P, _P, _P, _P, _I, _I, _F, _P],
     "clora_softmax_rows_f16": [_P, _P, _I, _I, _I, _F, _P],
     "clora_layernorm_bwd_f16": [_P, _P, _P, _P, _P, _I, _I, _F, _P],

@@ -324,6 +324,7 @@ __device__ __forceinline__ void dma_epilogue(const GemmArgs& p, floatx4 (&acc)[B
 #else
     constexpr bool SMALL2 = BM == 64 && BN == 64 && NT == 256 && NPASS == 1 && SMEM >= 24576;
 #endif
+    constexpr bool LN_TILE = BN == 320 && NT == 512 && (BM == 64 || BM == 128);      // tiles that may carry clora_epilogue_t.ln_out
     constexpr bool FIXED_COL = HOIST_PAYS || SMALL2;           // thread -> one fixed chunk column, rows t / CPR + it * RPIT
     static_assert(EXT == 0 || FIXED_COL, "EXT tiles take the fixed-column hoisted epilogue");
     constexpr bool TWO_PHASE = (HOIST_PAYS && NT == 512 && BM <= 128) || SMALL2;
@@ -487,6 +488,15 @@ __device__ __forceinline__ void dma_epilogue(const GemmArgs& p, floatx4 (&acc)[B
                     for (int e = 0; e < 8; ++e) o[e] = CLORA_RES_ADD(v[e], o[e], rr[e]);
                 }
                 st8(p.C + (size_t)m * p.ldc + n, o);
+                if constexpr (LN_TILE) {                       // the stored fp16 values back to the staging rows: the LayerNorm pass below
+                    if (p.epi.ln_out) {
+                        floatx4 w0, w1;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { w0[e] = (float)o[e]; w1[e] = (float)o[4 + e]; }
+                        *reinterpret_cast<floatx4*>(Cf + ml * F_LD + nc * 8) = w0;
+                        *reinterpret_cast<floatx4*>(Cf + ml * F_LD + nc * 8 + 4) = w1;
+                    }
+                }
             }
         };
         if constexpr (FIXED_COL) {
@@ -557,6 +567,15 @@ __device__ __forceinline__ void dma_epilogue(const GemmArgs& p, floatx4 (&acc)[B
                             for (int e = 0; e < 8; ++e) o[e] = CLORA_RES_ADD(v[e], o[e], rrs[it][e]);
                         }
                         st8(p.C + (size_t)m * p.ldc + n, o);
+                        if constexpr (LN_TILE) {
+                            if (p.epi.ln_out) {
+                                floatx4 w0, w1;
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) { w0[e] = (float)o[e]; w1[e] = (float)o[4 + e]; }
+                                *reinterpret_cast<floatx4*>(Cf + ml * F_LD + nc * 8) = w0;
+                                *reinterpret_cast<floatx4*>(Cf + ml * F_LD + nc * 8 + 4) = w1;
+                            }
+                        }
                     }
                 }
             } else {
@@ -566,6 +585,48 @@ __device__ __forceinline__ void dma_epilogue(const GemmArgs& p, floatx4 (&acc)[B
             for (int c = t; c < PR * CPR; c += NT) {
                 const int ml = c / CPR, ncc = c - ml * CPR;
                 chunk(ml, ncc, n0 + ncc * 8);
+            }
+        }
+        // ---- fused LayerNorm of the rows just stored (clora_epilogue_t.ln_out; the tile spans the row: N == BN == 320).  One wave per
+        // row, lane l < 40 owns chunk l -- the partition, the formulas and the summation order of layernorm_rows_kernel
+        // (clora_norm.hip), on the fp16 values that went to C (read back from the staging rows).
+        if constexpr (LN_TILE) {
+            if (p.epi.ln_out) {
+                __syncthreads();
+                const int lane = t & 63, wv = t >> 6;
+                const bool lok = lane < CPR;
+                const int cl = lok ? lane : 0;
+                float gm[8], bt[8];
+                {
+                    const floatx4 g0 = *reinterpret_cast<const floatx4*>(p.epi.ln_gamma + cl * 8), g1 = *reinterpret_cast<const floatx4*>(p.epi.ln_gamma + cl * 8 + 4);
+                    const floatx4 b0 = *reinterpret_cast<const floatx4*>(p.epi.ln_beta + cl * 8), b1 = *reinterpret_cast<const floatx4*>(p.epi.ln_beta + cl * 8 + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { gm[e] = g0[e]; gm[4 + e] = g1[e]; bt[e] = b0[e]; bt[4 + e] = b1[e]; }
+                }
+                for (int r = wv; r < PR; r += NT / 64) {
+                    const int m = m0 + ph * PR + r;
+                    const floatx4 x0 = *reinterpret_cast<const floatx4*>(Cf + r * F_LD + cl * 8);
+                    const floatx4 x1 = *reinterpret_cast<const floatx4*>(Cf + r * F_LD + cl * 8 + 4);
+                    float x[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+                    float sum = 0.f;
+                    if (lok) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) sum += x[e];
+                    }
+                    const float mean = wave_sum(sum) / (float)BN;
+                    float q = 0.f;
+                    if (lok) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { const float d = x[e] - mean; q += d * d; }
+                    }
+                    const float rstd = rsqrtf(wave_sum(q) / (float)BN + p.epi.ln_eps);
+                    if (lok && m < p.M) {
+                        half8 y;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) y[e] = (half_t)((x[e] - mean) * rstd * gm[e] + bt[e]);
+                        st8((half_t*)p.epi.ln_out + (size_t)m * BN + cl * 8, y);
+                    }
+                }
             }
         }
     }
@@ -1657,6 +1718,9 @@ extern "C" int clora_gemm_f16_ex(const clora_half* A, int lda, const clora_half*
         if (lda & 7) return CLORA_ERR_ARG;
     }
     if (epi) a.epi = *epi; else a.epi = clora_epilogue_t();
+    if (a.epi.ln_out && (!a.epi.ln_gamma || !a.epi.ln_beta || !clora_gemm_ln_fusable(M, N, K, tile_cfg, split_k) || a.epi.geglu ||
+                         a.conv.enabled || ((uintptr_t)a.epi.ln_gamma & 15) || ((uintptr_t)a.epi.ln_beta & 15)))
+        return CLORA_ERR_ARG;
     clora_deferred_t* const defer = a.epi.defer;             // host-side request: never travels in the kernel arguments
     a.epi.defer = nullptr;
     if (defer) {
@@ -1831,6 +1895,11 @@ extern "C" int clora_gemm_f16_ex(const clora_half* A, int lda, const clora_half*
     if (rc != CLORA_OK) return rc;
     if (splits > 1) rc = finish_or_defer(a, splits, defer, s);
     return rc;
+}
+
+extern "C" int clora_gemm_ln_fusable(int M, int N, int K, int tile_cfg, int split_k) {
+    (void)K;
+    return M > 0 && N == 320 && split_k == 1 && (tile_cfg == 51 || tile_cfg == 52 || tile_cfg == 54 || tile_cfg == 55) ? 1 : 0;
 }
 
 extern "C" int clora_finish_deferred(const clora_deferred_t* d, void* stream) {

@@ -47,6 +47,16 @@ PROFILER: Optional[KernelProfiler] = None
 # for deferral where the output's next reader goes through this module (torch-native reads would see an unwritten buffer).
 _PENDING = {}
 _pending_task = [None]
+FUSE_LN = os.environ.get("CLORA_FUSE_LN", "1") != "0"                 # "0": every LayerNorm is its own launch (round-5 path, A/B runs)
+
+
+class LayerNormSlot:
+    """A LayerNorm that FOLLOWS a projection (upstream BasicTransformerBlock: x = attn(...) + x; n = norm(x)), offered to the GEMM that
+    produces x: `params` = (gamma fp32, beta fp32, eps); `out` is filled with LayerNorm(x) by a launch that could fuse it (gemm `ln=`),
+    else stays None and the caller launches the norm itself."""
+
+    def __init__(self, gamma, beta, eps):
+        self.params, self.out = (gamma, beta, eps), None
 DEFER_FINISH = os.environ.get("CLORA_DEFER_FINISH", "1") != "0"       # "0": every split-K GEMM runs its own finish pass (A/B runs)
 
 
@@ -168,7 +178,7 @@ def gemm(A: torch.Tensor, Bw: torch.Tensor, M: int, N: int, K: int, *, lda: Opti
          split_k: int = 0, tile_cfg: int = 0, _tuned: bool = True,
          geglu: int = 0, geglu_h: Optional[torch.Tensor] = None, geglu_y: Optional[torch.Tensor] = None,
          geglu_keep_h: bool = True, lora_dpack: Optional[torch.Tensor] = None, lora_t_in: Optional[torch.Tensor] = None,
-         lora_t_in_mask: int = 0, lora_t_in_rows: int = 0, defer: bool = False) -> torch.Tensor:
+         lora_t_in_mask: int = 0, lora_t_in_rows: int = 0, defer: bool = False, ln=None) -> torch.Tensor:
     """C[M,N] = A . Bw^T with the fused epilogue of clora_epilogue_t.
     geglu=1 (Bw / bias packed by ops.GegluPack, N = 2F): returns (y [M,F], h [M,2F] or None when not geglu_keep_h);
     geglu=2 (N = F, geglu_h = the saved h): returns dh [M, 2F].
@@ -220,6 +230,18 @@ def gemm(A: torch.Tensor, Bw: torch.Tensor, M: int, N: int, K: int, *, lda: Opti
         if geglu == 1 and tile_cfg not in WIDE_TILE_CFGS:
             tile_cfg = 0                       # the library picks a >= 128-column tile itself
     ws = workspace(GEMM_WS_BYTES if split_k == 0 else max(split_k, 1) * M * N * 4, A.device) if split_k != 1 else None
+    # ln (a LayerNormSlot): where one tile spans the output row (N = 320 on the 8-wave 320-column tiles) the launch also writes
+    # LayerNorm(C) -- the norm that follows an attention out-projection / proj_in in every BasicTransformerBlock -- into ln.out
+    if ln is not None and ln.out is None and FUSE_LN and not geglu and conv is None and C_ is not None and C_.is_contiguous():
+        tc = tile_cfg
+        if lora_dpack is not None and tc not in (51, 52, 54, 55) and e.lora_seg % 320 == 0:
+            tc = 54 if M >= 32768 else 55                    # what the library would pick (clora_gemm_f16_ex): made explicit
+        if capi.lib().cdll.clora_gemm_ln_fusable(M, N, K, tc, split_k):
+            g_, b_, eps_ = ln.params
+            assert g_.dtype == f32 and b_.dtype == f32 and g_.numel() == N and b_.numel() == N
+            tile_cfg = tc
+            ln.out = torch.empty((M, N), dtype=f16, device=A.device)
+            e.ln_gamma, e.ln_beta, e.ln_out, e.ln_eps = ptr(g_), ptr(b_), ptr(ln.out), float(eps_)
     # defer=True: if this launch is split-K, leave its finish pass to the GroupNorm / LayerNorm call that reads C next (_PENDING)
     d = None
     if defer and DEFER_FINISH and split_k != 1 and not geglu and PROFILER is None and C_ is not None and C_.is_contiguous():

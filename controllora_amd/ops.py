@@ -108,10 +108,10 @@ class ConvPack:
 # finish pass to that call.  Never set it where a torch-native op may read the tensor first.
 class _FrozenLinearFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, pack: LinearPack, residual, rowadd, rows_per_batch, defer_out=False, defer_dx=False):
+    def forward(ctx, x, pack: LinearPack, residual, rowadd, rows_per_batch, defer_out=False, defer_dx=False, ln=None):
         M = x.shape[0]
         y = K.gemm(x, pack.w, M, pack.N, pack.K, bias=pack.bias, residual=residual, rowadd=rowadd,
-                   rows_per_batch=rows_per_batch, defer=defer_out)
+                   rows_per_batch=rows_per_batch, defer=defer_out and ln is None, ln=ln)
         ctx.pack, ctx.has_res, ctx.defer_dx = pack, residual is not None, defer_dx
         return y
 
@@ -120,12 +120,13 @@ class _FrozenLinearFn(torch.autograd.Function):
         dy = dy.contiguous()
         p = ctx.pack
         dx = K.gemm(dy, p.wt, dy.shape[0], p.K, p.N, defer=ctx.defer_dx) if ctx.needs_input_grad[0] else None
-        return dx, None, (dy if ctx.has_res and ctx.needs_input_grad[2] else None), None, None, None, None
+        return dx, None, (dy if ctx.has_res and ctx.needs_input_grad[2] else None), None, None, None, None, None
 
 
-def frozen_linear(x, pack: LinearPack, residual=None, rowadd=None, rows_per_batch=0, defer_out=False, defer_dx=False):
-    """y = x W^T + b (+ rowadd[batch]) (+ residual); x [M,K] fp16."""
-    return _FrozenLinearFn.apply(x, pack, residual, rowadd, rows_per_batch, defer_out, defer_dx)
+def frozen_linear(x, pack: LinearPack, residual=None, rowadd=None, rows_per_batch=0, defer_out=False, defer_dx=False, ln=None):
+    """y = x W^T + b (+ rowadd[batch]) (+ residual); x [M,K] fp16.  ln (kernels.LayerNormSlot): the LayerNorm that follows y, offered to
+    the launch (filled in ln.out where one tile spans the row, see kernels.gemm)."""
+    return _FrozenLinearFn.apply(x, pack, residual, rowadd, rows_per_batch, defer_out, defer_dx, ln)
 
 
 class _FrozenConvFn(torch.autograd.Function):
@@ -228,25 +229,27 @@ class _LayerNormFn(torch.autograd.Function):
     (x + f(LN(x)) is every BasicTransformerBlock sub-layer; see _GroupNormFn)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps, fork):
+    def forward(ctx, x, gamma, beta, eps, fork, pre=None):
+        # pre: LayerNorm(x) as the launch that produced x already wrote it (kernels.LayerNormSlot): nothing to launch here, the
+        # backward is this function's as always
         ctx.save_for_backward(x, gamma)
         ctx.eps = eps
-        y = K.layernorm_fwd(x, gamma, beta, eps)
+        y = pre.view_as(x) if pre is not None else K.layernorm_fwd(x, gamma, beta, eps)
         return (y, x) if fork else y
 
     @staticmethod
     def backward(ctx, dy, dres=None):
         x, gamma = ctx.saved_tensors
         dx = K.layernorm_bwd(x, dy.contiguous(), gamma, ctx.eps, dres=dres.contiguous().view_as(x) if dres is not None else None)
-        return dx, None, None, None, None
+        return dx, None, None, None, None, None
 
 
-def layer_norm(x, gamma, beta, eps=1e-5):
-    return _LayerNormFn.apply(x, gamma, beta, eps, False)
+def layer_norm(x, gamma, beta, eps=1e-5, pre=None):
+    return _LayerNormFn.apply(x, gamma, beta, eps, False, pre)
 
 
-def layer_norm_fork(x, gamma, beta, eps=1e-5):
-    return _LayerNormFn.apply(x, gamma, beta, eps, True)
+def layer_norm_fork(x, gamma, beta, eps=1e-5, pre=None):
+    return _LayerNormFn.apply(x, gamma, beta, eps, True, pre)
 
 
 class _GegluFn(torch.autograd.Function):
@@ -806,9 +809,28 @@ class input_from_norm:
         return False
 
 
+# Dynamic scope set by the transformer block around an attention call: the LayerNorm that FOLLOWS the call's result (norm2 after
+# attn1, norm3 after attn2), offered to the out-projection GEMM -- the one lora_proj call of the processor that carries the residual.
+_NEXT_LN = [None]
+
+
+class next_layernorm:
+    def __init__(self, slot):
+        self.slot = slot
+
+    def __enter__(self):
+        self.prev, _NEXT_LN[0] = _NEXT_LN[0], self.slot
+        return self.slot
+
+    def __exit__(self, *exc):
+        _NEXT_LN[0] = self.prev
+        return False
+
+
 class _Meta(tuple):
     """the per-segment adapter description of _LoraProjFn plus call flags (a tuple subclass: autograd passes it through untouched)"""
     defer_dx = False
+    ln = None
 
 
 class _LoraProjFn(torch.autograd.Function):
@@ -887,10 +909,10 @@ class _LoraProjFn(torch.autograd.Function):
                 t_in, t_in_rows = pre, (rows if rows != M else 0)
             y = K.gemm(x, pack.w, M, pack.N, pack.K, bias=pack.bias, residual=residual, lora_t=T, lora_u=U,
                        lora_seg=seg_w, lora_scale=1.0, lora_dpack=ADAPTER_PACKS.get(f_srcs), lora_t_in=t_in,
-                       lora_t_in_mask=f_in_mask, lora_t_in_rows=t_in_rows, tile_cfg=plan)
+                       lora_t_in_mask=f_in_mask, lora_t_in_rows=t_in_rows, tile_cfg=plan, ln=getattr(meta, "ln", None))
         else:
             y = K.gemm(x, pack.w, M, pack.N, pack.K, bias=pack.bias, residual=residual, lora_t=T, lora_u=U,
-                       lora_seg=seg_w, lora_scale=1.0)
+                       lora_seg=seg_w, lora_scale=1.0, ln=getattr(meta, "ln", None))
         ctx.pack, ctx.info, ctx.n_xa, ctx.r, ctx.has_res = pack, info, n_xa, r, residual is not None
         ctx.defer_dx = bool(getattr(meta, "defer_dx", False))
         ctx.t_pre_rows = t_pre.shape[0] if t_pre is not None else 0
@@ -1020,6 +1042,8 @@ def lora_proj(x, pack: LinearPack, segs: Sequence[Optional[Tuple[torch.Tensor, t
         params += [D, U]
     meta = _Meta(meta)
     meta.defer_dx = _FROM_NORM[0] > 0
+    if residual is not None and _NEXT_LN[0] is not None:      # the out-projection of an attention call whose result feeds a LayerNorm
+        meta.ln = _NEXT_LN[0]
     return _LoraProjFn.apply(pack, meta, len(xas), t_pre, x, residual, *xas[1:], *params)
 
 

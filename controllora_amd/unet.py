@@ -83,8 +83,8 @@ class Conv1x1(_Packed):
     def _build(self):
         return ops.LinearPack(self.weight, self.bias)
 
-    def forward(self, x, residual=None, defer_out=False, defer_dx=False):
-        return ops.frozen_linear(x, self.pack(), residual, defer_out=defer_out, defer_dx=defer_dx)
+    def forward(self, x, residual=None, defer_out=False, defer_dx=False, ln=None):
+        return ops.frozen_linear(x, self.pack(), residual, defer_out=defer_out, defer_dx=defer_dx, ln=ln)
 
 
 class Linear(_Packed):
@@ -131,13 +131,18 @@ class GroupNorm(_Norm):
 
 
 class LayerNorm(_Norm):
-    def forward(self, x):
+    def forward(self, x, pre=None):
         g, b = self.pack()
-        return ops.layer_norm(x, g, b, 1e-5)
+        return ops.layer_norm(x, g, b, 1e-5, pre)
 
-    def fork(self, x):
+    def fork(self, x, pre=None):
         g, b = self.pack()
-        return ops.layer_norm_fork(x, g, b, 1e-5)
+        return ops.layer_norm_fork(x, g, b, 1e-5, pre)
+
+    def slot(self):
+        """this norm offered to the GEMM that produces its input (kernels.LayerNormSlot)"""
+        g, b = self.pack()
+        return K.LayerNormSlot(g, b, 1e-5)
 
 
 # ------------------------------------------------------------------------------------------------ attention
@@ -246,18 +251,21 @@ class BasicTransformerBlock(nn.Module):
         self.attn2 = CrossAttention(dim, cross_attention_dim, heads, dim_head)
         self.norm1, self.norm2, self.norm3 = LayerNorm(dim), LayerNorm(dim), LayerNorm(dim)
 
-    def forward(self, x, ehs, kw):
+    def forward(self, x, ehs, kw, pre_ln1=None):
+        """pre_ln1: norm1(x) as the launch that produced x already wrote it (Transformer2DModel.proj_in), or None"""
         B, N, C_ = x.shape
         grad = torch.is_grad_enabled() and x.requires_grad
         # the attention / feed-forward inputs below are LayerNorm outputs with no other consumer: their projections' dgrad GEMMs may
         # leave a split-K finish to the LayerNorm backward (ops.input_from_norm)
-        n, xr = self.norm1.fork(x) if grad else (self.norm1(x), x)
-        with ops.input_from_norm():
+        # norm2 / norm3 are offered to the out-projection of the attention call in front of them (ops.next_layernorm): where one GEMM tile
+        # spans the row (C = 320) that launch writes the normalised rows too and the norm's own forward launch disappears
+        n, xr = self.norm1.fork(x, pre_ln1) if grad else (self.norm1(x, pre_ln1), x)
+        with ops.input_from_norm(), ops.next_layernorm(self.norm2.slot()) as s2:
             x = self.attn1(n, residual=xr, **kw)
-        n, xr = self.norm2.fork(x) if grad else (self.norm2(x), x)
-        with ops.input_from_norm():
+        n, xr = self.norm2.fork(x, s2.out) if grad else (self.norm2(x, s2.out), x)
+        with ops.input_from_norm(), ops.next_layernorm(self.norm3.slot()) as s3:
             x = self.attn2(n, encoder_hidden_states=ehs, residual=xr, **kw)
-        n, xr = self.norm3.fork(x) if grad else (self.norm3(x), x)
+        n, xr = self.norm3.fork(x, s3.out) if grad else (self.norm3(x, s3.out), x)
         return self.ff(n.reshape(B * N, C_), xr.reshape(B * N, C_), defer_dx=grad).reshape(B, N, C_)
 
 
@@ -275,9 +283,10 @@ class Transformer2DModel(nn.Module):
         B, N, C_ = x.shape
         grad = torch.is_grad_enabled() and x.requires_grad
         n, xr = self.norm.fork(x, False) if grad else (self.norm(x, False), x)
-        h = self.proj_in(n.reshape(B * N, C_), defer_dx=grad).reshape(B, N, -1)
-        for blk in self.transformer_blocks:
-            h = blk(h, ehs, kw)
+        s1 = self.transformer_blocks[0].norm1.slot()          # the first block's norm1, offered to proj_in's launch
+        h = self.proj_in(n.reshape(B * N, C_), defer_dx=grad, ln=s1).reshape(B, N, -1)
+        for i, blk in enumerate(self.transformer_blocks):
+            h = blk(h, ehs, kw, pre_ln1=s1.out if i == 0 else None)
         return self.proj_out(h.reshape(B * N, -1), xr.reshape(B * N, C_), defer_out=out_to_norm).reshape(B, N, C_)
 
 

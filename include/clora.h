@@ -102,6 +102,15 @@ typedef struct {
      * is complete as usual.  The caller hands *defer to the consumer of C (clora_groupnorm_*_ex / clora_layernorm_bwd_f16_ex), or to
      * clora_finish_deferred, before anything else uses `workspace`.  Not with GEGLU. */
     struct clora_deferred* defer;
+    /* round 6: LayerNorm of the OUTPUT rows evaluated by this launch (upstream BasicTransformerBlock: `norm2(attn1(...) + x)`,
+     * `norm3(...)`, and norm1 of proj_in's output): ln_out[m, :] = LayerNorm(C[m, :]) * ln_gamma + ln_beta over the
+     * N columns, from the fp16 values stored to C (the arithmetic of clora_layernorm_fwd_f16, same summation order), written next to
+     * C (row pitch N).  Only where ONE tile spans the row: N == 320 on tile_cfg 51 / 52 / 54 / 55 (the level-0 projections of the
+     * SD-1.5 UNet), split_k == 1, no GEGLU; anything else: CLORA_ERR_ARG (ask clora_gemm_ln_fusable first). */
+    const float* ln_gamma;
+    const float* ln_beta;
+    clora_half* ln_out;
+    float ln_eps;
 } clora_epilogue_t;
 
 /* A deferred split-K GEMM (clora_epilogue_t.defer).  element (m, n) of the GEMM's output is
@@ -115,6 +124,8 @@ typedef struct clora_deferred {
     int ldc;
     clora_epilogue_t epi;       /* the GEMM's epilogue (defer = NULL inside) */
 } clora_deferred_t;
+/* would clora_gemm_f16_ex(..., tile_cfg, split_k) take clora_epilogue_t.ln_out for this shape?  (host-only, no launch) */
+int clora_gemm_ln_fusable(int M, int N, int K, int tile_cfg, int split_k);
 /* the plain finish pass for a deferred GEMM (a consumer that cannot fold it, or no consumer at all) */
 int clora_finish_deferred(const clora_deferred_t* d, void* stream);
 

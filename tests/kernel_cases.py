@@ -571,6 +571,37 @@ def _case_deferred_finish(dev, B, HW, C, Kd, G, split, silu=True, seed=12, lora=
     assert not K._PENDING and torch.equal(dyd, ref) and torch.equal(z, K.add(ref, ref))
 
 
+def case_gemm_fused_layernorm(dev, M, Kd, tile_cfg, seed=13, lora=False, residual=True):
+    """Round 6 (clora_epilogue_t.ln_out): the LayerNorm that follows a projection, written by the projection's own launch where one
+    320-column tile spans the row, == clora_layernorm_fwd_f16 on the stored output (same partition / formulas / summation order: the
+    compiler may contract the final affine differently in the two kernels, so equality is asserted up to one fp16 ulp on a handful of
+    elements); C itself must be bit-identical to the launch without the fused norm."""
+    g = torch.Generator().manual_seed(seed)
+    N = 320
+    A = rnd((M, Kd), dev, g)
+    Wt = (rnd((N, Kd), dev, g).float() * 0.1).half()
+    bias = rnd((N,), dev, g, dtype=f32)
+    res = rnd((M, N), dev, g) if residual else None
+    gamma, beta = (1 + 0.2 * rnd((N,), dev, g, dtype=f32)), 0.2 * rnd((N,), dev, g, dtype=f32)
+    kw = dict(bias=bias, residual=res, tile_cfg=tile_cfg, split_k=1)
+    if lora:
+        kw.update(lora_t=rnd((M, 4), dev, g, dtype=f32), lora_u=rnd((N, 4), dev, g, dtype=f32) * 0.1, lora_seg=N)
+    ref = K.gemm(A, Wt, M, N, Kd, **kw)
+    ln_ref = K.layernorm_fwd(ref, gamma, beta, 1e-5)
+    slot = K.LayerNormSlot(gamma, beta, 1e-5)
+    out = K.gemm(A, Wt, M, N, Kd, ln=slot, **kw)
+    assert slot.out is not None, "the launch did not take the fused LayerNorm"
+    assert torch.equal(out, ref)
+    diff = (slot.out.float() - ln_ref.float()).abs()
+    ulp = ln_ref.float().abs().clamp_min(2.0 ** -10) * 2.0 ** -10
+    assert bool((diff <= ulp).all()), float((diff / ulp).max())
+    assert float((diff > 0).float().mean()) < 0.02
+    # a shape / tile that cannot fuse leaves the slot empty (the caller launches the norm itself)
+    slot2 = K.LayerNormSlot(gamma, beta, 1e-5)
+    K.gemm(A, Wt, M, N, Kd, ln=slot2, bias=bias, tile_cfg=43, split_k=1)
+    assert slot2.out is None
+
+
 def case_softmax_rows(dev, rows, cols, scale=0.37, seed=6):
     g = torch.Generator().manual_seed(seed)
     x = (rnd((rows, cols), dev, g).float() * 4).half()

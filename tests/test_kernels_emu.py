@@ -256,6 +256,12 @@ def test_deferred_split_k_finish_in_the_norm_kernels(B, HW, C, Kd, G, split, lor
     KC.case_deferred_finish("cpu", B, HW, C, Kd, G, split, lora=lora)
 
 
+@pytest.mark.parametrize("M,Kd,tile,lora,res", [(150, 320, 55, False, True), (200, 128, 52, True, True), (130, 320, 54, True, False),
+                                                (300, 64, 51, False, True), (64, 1280, 55, True, True)])
+def test_gemm_fused_layernorm(M, Kd, tile, lora, res):
+    KC.case_gemm_fused_layernorm("cpu", M, Kd, tile, lora=lora, residual=res)
+
+
 @pytest.mark.parametrize("M,C", [(37, 320), (9, 1280), (5, 64)])
 def test_layernorm(M, C):
     KC.case_layernorm("cpu", M, C)

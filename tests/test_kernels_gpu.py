@@ -183,6 +183,13 @@ def test_deferred_split_k_finish_in_the_norm_kernels(B, HW, C, Kd, G, split, lor
     KC.case_deferred_finish(DEV, B, HW, C, Kd, G, split, lora=lora)
 
 
+@pytest.mark.parametrize("M,Kd,tile,lora,res", [(16384, 320, 55, True, True), (16384, 320, 55, False, False), (16384, 1280, 55, False, True),
+                                                (32768, 320, 54, True, True), (16384, 320, 52, True, True), (1000, 320, 51, False, True)])
+def test_gemm_fused_layernorm(M, Kd, tile, lora, res):
+    """the level-0 projections (16384 x 320) with the LayerNorm that follows them written by the same launch"""
+    KC.case_gemm_fused_layernorm(DEV, M, Kd, tile, lora=lora, residual=res)
+
+
 @pytest.mark.parametrize("M,C", [(4096, 320), (1024, 640), (259, 1280)])
 def test_layernorm(M, C):
     KC.case_layernorm(DEV, M, C)
