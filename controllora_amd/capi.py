@@ -98,6 +98,7 @@ class ConvUnpackJob(C.Structure):
 
 
 LORA_MAX_JOBS = 16
+LORA_WGRAD_MAX_JOBS = 32       # CLORA_LORA_WGRAD_MAX_JOBS
 CONV_MAX_JOBS = 32
 _P, _I, _Z, _F = C.c_void_p, C.c_int, C.c_size_t, C.c_float
 _PROTOS = {
@@ -144,6 +145,7 @@ _PROTOS = {
     "clora_comm_destroy": [],
     "clora_add_f16": [_P, _P, _P, _Z, _P],
     "clora_silu_f16": [_P, _P, _Z, _P],
+    "clora_timestep_embedding_f16": [_P, _I, _I, _P, _P, _I, _I, _P],
     "clora_silu_bwd_f16": [_P, _P, _P, _Z, _P],
     "clora_quick_gelu_f16": [_P, _P, _Z, _P],
     "clora_copy2d_f16": [_P, _I, _P, _I, _Z, _I, _P],
@@ -199,7 +201,7 @@ class Lib:
                     "CLORA_GN_BLOCKS": ("gn_blocks", None), "CLORA_EPI_TWO_PHASE": ("epi_two_phase", None),
                     "CLORA_LORA_DOWN_MODE": ("lora_down_mode", None), "CLORA_GN_UNROLL": ("gn_unroll", None),
                     "CLORA_EPI_HOIST": ("epi_hoist", None), "CLORA_GN_RESIDENT": ("gn_resident", None),
-                    "CLORA_DEFER_MAX_ROWS": ("defer_max_rows", None)}
+                    "CLORA_DEFER_MAX_ROWS": ("defer_max_rows", None), "CLORA_SPLITK_TAIL": ("splitk_tail", None)}
 
     def _options_from_env(self):
         for var, (name, names) in self._ENV_OPTIONS.items():

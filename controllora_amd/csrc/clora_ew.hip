@@ -242,6 +242,20 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, fl
     }
 }
 
+// sinusoidal timestep embedding (upstream get_timestep_embedding with flip_sin_to_cos, shift 0: SURVEY.md U1): out[b, j] = cos(t_b f_j),
+// out[b, half + j] = sin(t_b f_j), fp32 math, fp16 result; t is int64 or fp32, one value per batch element or one for all
+__global__ __launch_bounds__(256) void timestep_embedding_kernel(const void* t, int t_is_i64, int t_count, const float* freq, half_t* out,
+                                                                 int batch, int half) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= batch * half) return;
+    const int b = i / half, j = i - b * half;
+    const int ti = t_count == 1 ? 0 : b;
+    const float tv = t_is_i64 ? (float)((const long long*)t)[ti] : ((const float*)t)[ti];
+    const float arg = tv * freq[j];
+    out[(size_t)b * 2 * half + j] = (half_t)cosf(arg);
+    out[(size_t)b * 2 * half + half + j] = (half_t)sinf(arg);
+}
+
 }  // namespace
 
 #define H(x) ((const half_t*)(x))
@@ -250,6 +264,13 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, fl
 extern "C" int clora_add_f16(const clora_half* a, const clora_half* b, clora_half* y, size_t n, void* stream) {
     if (!a || !b || !y || (n & 7)) return CLORA_ERR_ARG;
     hipLaunchKernelGGL(add_kernel, dim3(ew_grid(n / 8)), dim3(256), 0, (hipStream_t)stream, H(a), H(b), HM(y), n / 8);
+    return clora_check_launch();
+}
+extern "C" int clora_timestep_embedding_f16(const void* t, int t_is_i64, int t_count, const float* freq, clora_half* out, int batch,
+                                            int half, void* stream) {
+    if (!t || !freq || !out || batch <= 0 || half <= 0 || (t_count != 1 && t_count != batch)) return CLORA_ERR_ARG;
+    hipLaunchKernelGGL(timestep_embedding_kernel, dim3(clora_cdiv((long)batch * half, 256)), dim3(256), 0, (hipStream_t)stream, t, t_is_i64,
+                       t_count, freq, HM(out), batch, half);
     return clora_check_launch();
 }
 extern "C" int clora_silu_f16(const clora_half* x, clora_half* y, size_t n, void* stream) {

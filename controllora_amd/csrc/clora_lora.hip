@@ -201,10 +201,11 @@ __global__ __launch_bounds__(256) void lora_up_kernel(UpJobs jobs) {
 //            LDS and the block writes its [N x RT] slab to the workspace;
 //   stage 2: 64 outputs x 4 slab-lanes per block fold the slabs in a fixed order and add into G.
 struct WgradJobs {
-    clora_lora_wgrad_job_t j[CLORA_LORA_MAX_JOBS];
-    float* part[CLORA_LORA_MAX_JOBS];       // slab area of each job
-    int rpb[CLORA_LORA_MAX_JOBS], nblk[CLORA_LORA_MAX_JOBS];
+    clora_lora_wgrad_job_t j[CLORA_LORA_WGRAD_MAX_JOBS];
+    float* part[CLORA_LORA_WGRAD_MAX_JOBS];       // slab area of each job
+    int rpb[CLORA_LORA_WGRAD_MAX_JOBS], nblk[CLORA_LORA_WGRAD_MAX_JOBS];
 };
+static_assert(sizeof(WgradJobs) <= 4096, "kernel arguments are limited to 4 KB");
 
 template <int RT>
 __global__ __launch_bounds__(256) void lora_wgrad_kernel(WgradJobs jobs) {
@@ -440,7 +441,7 @@ extern "C" size_t clora_lora_wgrad_workspace_bytes(int M, int N, int R) {
 /* all jobs of one launch must share the rank class (R <= 4, <= 8 or <= 16) */
 extern "C" int clora_lora_wgrad_multi_f16(const clora_lora_wgrad_job_t* jobs, int njobs, void* workspace,
                                           size_t workspace_bytes, void* stream) {
-    if (!jobs || njobs <= 0 || njobs > CLORA_LORA_MAX_JOBS) return CLORA_ERR_ARG;
+    if (!jobs || njobs <= 0 || njobs > CLORA_LORA_WGRAD_MAX_JOBS) return CLORA_ERR_ARG;
     WgradJobs wj;
     const int rt = wgrad_rt(jobs[0].R);
     size_t off = 0;

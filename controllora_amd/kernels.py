@@ -599,8 +599,8 @@ def lora_wgrad_multi(jobs, device):
         groups.setdefault(4 if j.R <= 4 else (8 if j.R <= 8 else 16), []).append(j)
     wsb = capi.lib().cdll.clora_lora_wgrad_workspace_bytes
     for _, js in groups.items():
-        for i in range(0, len(js), capi.LORA_MAX_JOBS):
-            chunk = js[i:i + capi.LORA_MAX_JOBS]
+        for i in range(0, len(js), capi.LORA_WGRAD_MAX_JOBS):
+            chunk = js[i:i + capi.LORA_WGRAD_MAX_JOBS]
             ws = workspace(sum(wsb(j.M, j.N, j.R) for j in chunk), device)
             arr = (capi.LoraWgradJob * len(chunk))(*chunk)
             _call("clora_lora_wgrad_multi_f16", arr, len(chunk), ptr(ws), ws.numel(), nbytes=sum(2.0 * j.M * j.N for j in chunk))
@@ -608,7 +608,7 @@ def lora_wgrad_multi(jobs, device):
 
 # ---- deferred adapter weight gradients.  dU / dD are leaves of the backward pass (only the optimizer reads them), so
 # the autograd functions queue their reduction jobs instead of launching them one site at a time; the queue is flushed
-# ONCE at the end of the backward pass, 16 jobs per launch: ~110 small launch pairs per step become ~25 large ones.
+# ONCE at the end of the backward pass, 32 jobs per launch (16 until round 6): ~110 small launch pairs per step become ~10 large ones.
 # Tensors the jobs read are kept alive until the flush.  Jobs that target the same gradient buffer never share a launch.
 _wgrad_queue = {"jobs": [], "refs": [], "task": None, "enabled": os.environ.get("CLORA_DEFER_WGRAD", "1") != "0", "unpack": []}
 DEFER_UNPACK = os.environ.get("CLORA_DEFER_UNPACK", "1") != "0"        # "0": one unpack launch per hint-encoder convolution (A/B runs)
@@ -672,7 +672,7 @@ def lora_wgrad_flush():
         batches = []               # greedy packing: a batch never holds two jobs with the same destination
         for j in jobs:
             for b in batches:
-                if len(b[0]) < capi.LORA_MAX_JOBS and j.G not in b[1] and b[2] == (4 if j.R <= 4 else (8 if j.R <= 8 else 16)):
+                if len(b[0]) < capi.LORA_WGRAD_MAX_JOBS and j.G not in b[1] and b[2] == (4 if j.R <= 4 else (8 if j.R <= 8 else 16)):
                     b[0].append(j); b[1].add(j.G)
                     break
             else:
@@ -724,6 +724,18 @@ def add(a, b):
     y = torch.empty_like(a)
     _call("clora_add_f16", ptr(a, f16), ptr(b, f16), ptr(y), a.numel())
     return y
+
+
+def timestep_embedding(timestep, batch, freq):
+    """[batch, 2 * len(freq)] fp16 = cat(cos(t f), sin(t f)); timestep: int64 or fp32, `batch` values or one"""
+    t = timestep.reshape(-1)
+    if t.dtype not in (torch.int64, f32):
+        t = t.float() if t.is_floating_point() else t.long()
+    t = t.contiguous()
+    assert t.numel() in (1, batch) and freq.dtype == f32 and freq.is_contiguous()
+    out = torch.empty((batch, 2 * freq.numel()), dtype=f16, device=freq.device)
+    _call("clora_timestep_embedding_f16", ptr(t), int(t.dtype == torch.int64), t.numel(), ptr(freq, f32), ptr(out), batch, freq.numel())
+    return out
 
 
 def silu(x):

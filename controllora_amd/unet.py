@@ -470,11 +470,16 @@ class UNet2DConditionModel(nn.Module):
     def time_embed(self, timestep, batch, device):
         if not torch.is_tensor(timestep):
             timestep = torch.tensor([timestep], dtype=torch.long, device=device)
-        timestep = timestep.reshape(-1).to(device).expand(batch)
+        timestep = timestep.reshape(-1).to(device)
         half = self.config.block_out_channels[0] // 2
-        exponent = -math.log(10000) * torch.arange(half, dtype=f32, device=device) / half
-        arg = timestep[:, None].float() * torch.exp(exponent)[None, :]
-        t_emb = torch.cat([torch.cos(arg), torch.sin(arg)], dim=-1).to(f16)        # flip_sin_to_cos, shift 0
+        freq = getattr(self, "_temb_freq", None)
+        if freq is None or freq.device != timestep.device or freq.numel() != half:
+            # the frequencies never change: evaluated once with the ops the embedding used to be made of on every call
+            exponent = -math.log(10000) * torch.arange(half, dtype=f32, device=device) / half
+            freq = self._temb_freq = torch.exp(exponent).contiguous()
+        if timestep.numel() not in (1, batch):
+            timestep = timestep.expand(batch)
+        t_emb = K.timestep_embedding(timestep, batch, freq)      # cat(cos, sin): flip_sin_to_cos, shift 0 -- one launch (round 6)
         with torch.no_grad():
             e = self.time_embedding.linear_1(t_emb)
             e = self.time_embedding.linear_2(K.silu(e))

@@ -180,8 +180,8 @@ int clora_conv_patch_eligible(int M, const clora_conv_t* conv, int tile_cfg);
  * exceptions re-partition an fp32 sum: "lora_down_mode" (the sum over K) -- bit-identical per mode, equal to ~1e-7 relative across
  * modes, tests/test_kernels_gpu.py::test_lora_down_launch_modes -- and "gn_resident" (the GroupNorm statistics) -- bit-identical per
  * setting, a few fp16 ulps on a handful of outputs across settings, tests/kernel_cases.py::case_groupnorm).
- * This table is the ABI's ONLY process-global state (every other entry point is a pure function of its arguments and the
- * stream); the library reads no environment variable.  A knob takes effect for the launches that follow (a captured hipGraph
+ * This table and the ticket words of "splitk_tail" below are the ABI's ONLY process-global state (every other entry point is a pure
+ * function of its arguments and the stream); the library reads no environment variable.  A knob takes effect for the launches that follow (a captured hipGraph
  * keeps what it was captured with).
  *   "tile_order"      how clora_gemm_f16[_ex] assigns output tiles -- and the attention kernels their (batch, head) blocks -- to
  *                     the eight XCDs.  0 = every XCD a contiguous range of tiles in m-major order, attention blocks in launch
@@ -210,6 +210,13 @@ int clora_conv_patch_eligible(int M, const clora_conv_t* conv, int tile_cfg);
  *                     most this many rows (default 4: the 8x8 / 16x16 maps, where it is faster than finish + plain); above it -- and in
  *                     the LayerNorm backward unless the value is 16 -- the library runs the plain finish pass first.  0 = never fold.
  *                     Bit-identical results at every setting.
+ *   "splitk_tail"     1 (default) = a split-K clora_gemm_f16[_ex] launch finishes itself: every block stores its fp32 slab (write-through,
+ *                     agent scope) and takes a ticket from its output tile's counter; the block that draws the last ticket folds all slabs
+ *                     of the tile in slab order and applies the epilogue -- the finish pass's own arithmetic in the same order, bit-identical
+ *                     to 0 = the separate finish launch (85 launches of a train step).  Nobody waits for anybody: no residency requirement.
+ *                     The counters are library-owned device words (one per output tile, zero when the library is loaded, reset by the
+ *                     finishing block): launches that use them must be ordered on ONE stream, the way the reference's Python issues
+ *                     its ops.  A launch whose consumer folds the slabs itself (clora_epilogue_t.defer) is never finished in the kernel.
  * Unknown names / values: CLORA_ERR_ARG. */
 int clora_set_option(const char* name, int value);
 
@@ -341,6 +348,7 @@ int clora_lora_down_f16(const clora_half* X, int ldx, const float* D, int ldd, f
  * down-projections in the forward pass and six weight-gradient reductions in the backward pass; each is
  * launch-latency bound on its own).  R <= 16 per job; wgrad jobs of one call share the rank class (<=4, <=8, <=16). */
 #define CLORA_LORA_MAX_JOBS 16
+#define CLORA_LORA_WGRAD_MAX_JOBS 32   /* clora_lora_wgrad_multi_f16 (round 6: the end-of-backward flush in half as many launch pairs) */
 typedef struct {
     const clora_half* X; int ldx; const float* D; int ldd; float* T; int ldt; int toff;
     int M, K, R, accumulate, x_rows, d_kmajor; float d_scale;
@@ -435,6 +443,12 @@ int clora_comm_destroy(void);
 /* ---- small elementwise / data-movement kernels on the path */
 int clora_add_f16(const clora_half* a, const clora_half* b, clora_half* y, size_t n, void* stream);
 int clora_silu_f16(const clora_half* x, clora_half* y, size_t n, void* stream);
+/* Sinusoidal timestep embedding of the UNet (upstream `Timesteps(320, flip_sin_to_cos=True, freq_shift=0)`; what the
+ * reference's `unet(noisy_latents, timesteps, ...)` at train_text_to_image_control_lora.py:782 evaluates first): out[b, j] = cos(t_b f_j),
+ * out[b, half + j] = sin(t_b f_j), fp32 math, fp16 result -- ONE launch for upstream's arange / exp / mul / cos / sin / cat / cast.
+ * t: int64 (t_is_i64) or fp32, t_count = batch values or 1 broadcast value; freq = the `half` frequencies exp(-ln(10000) j / half). */
+int clora_timestep_embedding_f16(const void* t, int t_is_i64, int t_count, const float* freq, clora_half* out, int batch, int half,
+                                 void* stream);
 int clora_silu_bwd_f16(const clora_half* x, const clora_half* dy, clora_half* dx, size_t n, void* stream);
 /* y = x * sigmoid(1.702 x): the activation of the CLIP text encoder's MLP (transformers `quick_gelu`; the frozen text
  * encoder the reference calls at train_text_to_image_control_lora.py:768). */

@@ -546,6 +546,14 @@ def _case_deferred_finish(dev, B, HW, C, Kd, G, split, silu=True, seed=12, lora=
         kw.update(lora_t=rnd((M, 8), dev, g, dtype=f32), lora_u=rnd((8, C), dev, g, dtype=f32), lora_seg=C, lora_u_tr=True, lora_r=8)
     assert not K._PENDING
     ref = K.gemm(A, Wt, M, C, Kd, **kw)
+    # round 6 ("splitk_tail", default on): the split-K sum is finished by the last block of every output tile inside the GEMM launch --
+    # bit-identical to the separate finish launch
+    K.set_option("splitk_tail", 0)
+    try:
+        ref_finish_launch = K.gemm(A, Wt, M, C, Kd, **kw)
+    finally:
+        K.set_option("splitk_tail", int(os.environ.get("CLORA_SPLITK_TAIL", "1")))
+    assert torch.equal(ref, ref_finish_launch) and torch.equal(ref, K.gemm(A, Wt, M, C, Kd, **kw))
     y0, st0 = K.groupnorm_fwd(ref.reshape(B, HW, C), gamma, beta, G, 1e-5, silu)
     out = K.gemm(A, Wt, M, C, Kd, defer=True, **kw)
     deferred = bool(K._PENDING)
@@ -715,6 +723,18 @@ def case_elementwise(dev, seed=8):
     assert torch.equal(cat.cpu(), torch.cat([a, c], -1).cpu())
     sa, sc = K.split_channels(cat, 24)
     assert torch.equal(sa.cpu(), a.cpu()) and torch.equal(sc.cpu(), c.cpu())
+    # sinusoidal timestep embedding in one launch (round 6) vs upstream's op sequence (get_timestep_embedding, flip_sin_to_cos, shift 0):
+    # int64 per-sample timesteps (training), one fp32 value for the whole batch (samplers)
+    half = 160
+    freq = torch.exp(-math.log(10000) * torch.arange(half, dtype=f32, device=dev) / half).contiguous()
+    for t, batch in ((torch.tensor([0, 999, 1, 500, 37], dtype=torch.long, device=dev), 5), (torch.tensor([981.0], dtype=f32, device=dev), 3)):
+        arg = t.reshape(-1).expand(batch)[:, None].float() * freq[None, :]
+        ref = torch.cat([torch.cos(arg), torch.sin(arg)], -1)
+        out = K.timestep_embedding(t, batch, freq)
+        assert out.shape == (batch, 2 * half) and out.dtype == f16
+        assert float((out.float() - ref).abs().max()) <= 1e-3            # one fp16 rounding of a value in [-1, 1]
+        frac_equal = float((out == ref.to(f16)).float().mean())
+        assert frac_equal > 0.99, frac_equal
 
 
 def case_loss_and_optimizer(dev, n=5000, seed=9):

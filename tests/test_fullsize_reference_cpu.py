@@ -19,11 +19,24 @@ from tests import full_cases as F
 pytestmark = pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="needs /root/reference (build container only)")
 
 
+def _param_norm_err(got, want):
+    """worst relative error of the per-parameter gradient norms.  Three biases that sit in front of a GroupNorm (conv_in.bias,
+    down_blocks.0.0.convnets.0.conv1.bias, ...downsamplers.0.conv.bias) have a mathematically ZERO gradient: their recorded norms are
+    2-5e-9 of rounding noise against a largest norm of 0.42 and change by 10-26 % with the summation order of the host's GEMM threads
+    (seen when this container was replaced in round 6) -- those are compared on the scale of the largest norm instead."""
+    want, got = want.double(), got.double()
+    big = want > 1e-6 * want.max()
+    err = float(((got - want).abs() / want)[big].max())
+    if bool((~big).any()):
+        err = max(err, float((got - want).abs()[~big].max() / want.max()))
+    return err
+
+
 def _compare(rec, fx, tol):
     errs = {"pred": F.rel(rec["pred"], fx["pred"]), "loss": abs(float(rec["loss"]) - float(fx["loss"])) / float(fx["loss"]),
             "grads_sample": F.rel(rec["grads_sample"], fx["grads_sample"]), "grads_sample2": F.rel(rec["grads_sample2"], fx["grads_sample2"]),
             "grads_norm": abs(float(rec["grads_norm"]) - float(fx["grads_norm"])) / float(fx["grads_norm"]),
-            "param_norms": float(((rec["grads_param_norms"] - fx["grads_param_norms"]).abs() / (fx["grads_param_norms"].abs() + 1e-12)).max())}
+            "param_norms": _param_norm_err(rec["grads_param_norms"], fx["grads_param_norms"])}
     for i in range(4):
         errs[f"control_{i}"] = F.rel(rec[f"control_{i}_sample"], fx[f"control_{i}_sample"])
         errs[f"control_{i}_s2"] = F.rel(rec[f"control_{i}_sample2"], fx[f"control_{i}_sample2"])
