@@ -99,6 +99,7 @@ class ConvUnpackJob(C.Structure):
 
 LORA_MAX_JOBS = 16
 LORA_WGRAD_MAX_JOBS = 32       # CLORA_LORA_WGRAD_MAX_JOBS
+WGRAD_JOBS_PER_LAUNCH = min(LORA_WGRAD_MAX_JOBS, max(1, int(os.environ.get("CLORA_WGRAD_JOBS", "32"))))   # A/B runs: 16 = the round-5 batching
 CONV_MAX_JOBS = 32
 _P, _I, _Z, _F = C.c_void_p, C.c_int, C.c_size_t, C.c_float
 _PROTOS = {
@@ -201,7 +202,7 @@ class Lib:
                     "CLORA_GN_BLOCKS": ("gn_blocks", None), "CLORA_EPI_TWO_PHASE": ("epi_two_phase", None),
                     "CLORA_LORA_DOWN_MODE": ("lora_down_mode", None), "CLORA_GN_UNROLL": ("gn_unroll", None),
                     "CLORA_EPI_HOIST": ("epi_hoist", None), "CLORA_GN_RESIDENT": ("gn_resident", None),
-                    "CLORA_DEFER_MAX_ROWS": ("defer_max_rows", None), "CLORA_SPLITK_TAIL": ("splitk_tail", None)}
+                    "CLORA_DEFER_MAX_ROWS": ("defer_max_rows", None)}
 
     def _options_from_env(self):
         for var, (name, names) in self._ENV_OPTIONS.items():

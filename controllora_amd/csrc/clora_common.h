@@ -78,15 +78,6 @@ __device__ __forceinline__ half4v clora_ds_read_tr16(const half_t* lptr) {
 #define CLORA_WAIT_LGKMCNT(n) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(n) : "memory")
 #define CLORA_SETPRIO(n) __builtin_amdgcn_s_setprio(n)
 #define CLORA_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
-// Agent-scope relaxed atomic accesses (sc1: stores write through, loads do not hit stale lines) -- data exchanged between blocks of ONE
-// launch.  The eight XCDs' L2s are not coherent with each other for plain accesses; the fences that would make them so (buffer_wbl2 /
-// buffer_inv over the whole L2, per wave) cost tens of microseconds per launch (profiles/r06_gn_sync_fences_ab.txt), these cost nothing
-// extra.  Protocol (splitk_tail in clora_gemm.hip): coherent stores -> s_waitcnt vmcnt(0) -> workgroup barrier -> ticket (atomic add);
-// the block that draws the last ticket reads with coherent loads.
-#define CLORA_ST_AGENT_F32(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-#define CLORA_LD_AGENT_F32(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-#define CLORA_TICKET_AGENT(p) __hip_atomic_fetch_add((p), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-#define CLORA_ST_AGENT_U32(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #endif
 
 __device__ __forceinline__ floatx4 mfma16(half8 a, half8 b, floatx4 c) {
@@ -159,7 +150,7 @@ __device__ __forceinline__ float wave_max(float v) {
 // The library's ONLY process-global state: the tuning knobs of clora_set_option (include/clora.h), one int each, defined in
 // clora_gemm.hip.  Results never depend on them.  The library itself reads no environment variable: the host layer
 // (controllora_amd/capi.py) forwards CLORA_* variables through clora_set_option when it loads the library.
-enum { CLORA_OPT_TILE_ORDER = 0, CLORA_OPT_LN_ROWS, CLORA_OPT_ATTN_FWD_WAVES, CLORA_OPT_ATTN_BWD_WAVES, CLORA_OPT_GN_BLOCKS, CLORA_OPT_EPI_TWO_PHASE, CLORA_OPT_LORA_DOWN_MODE, CLORA_OPT_GN_UNROLL, CLORA_OPT_EPI_HOIST, CLORA_OPT_GN_RESIDENT, CLORA_OPT_DEFER_MAX_ROWS, CLORA_OPT_SPLITK_TAIL, CLORA_OPT_COUNT };
+enum { CLORA_OPT_TILE_ORDER = 0, CLORA_OPT_LN_ROWS, CLORA_OPT_ATTN_FWD_WAVES, CLORA_OPT_ATTN_BWD_WAVES, CLORA_OPT_GN_BLOCKS, CLORA_OPT_EPI_TWO_PHASE, CLORA_OPT_LORA_DOWN_MODE, CLORA_OPT_GN_UNROLL, CLORA_OPT_EPI_HOIST, CLORA_OPT_GN_RESIDENT, CLORA_OPT_DEFER_MAX_ROWS, CLORA_OPT_COUNT };
 __attribute__((visibility("hidden"))) int clora_option(int id);
 // XCD assignment policy of the launches that follow ("tile_order"): 0 = launch-order defaults, 1 = n-major GEMM tiles (tests),
 // 2 = fewest distinct operand panels per XCD; non-zero also gives every XCD whole attention heads (clora_attn.hip attn_block_ids)

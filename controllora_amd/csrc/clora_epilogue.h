@@ -166,9 +166,6 @@ __device__ __forceinline__ void epi_chunk8_pre(float (&v)[8], int m, int n, cons
 
 // One 8-column chunk (n % 8 == 0) of row m of a split-K GEMM's output: fold the slabs (four slabs' loads in flight), epilogue, fp16,
 // + residual.  partial = [splits][M][N] fp32.
-// COH: the slabs were written by OTHER blocks of the SAME launch (splitk_tail, clora_gemm.hip): agent-scope coherent loads, one dword
-// each; the sums are formed in the same order, so the result has the same bits.
-template <bool COH = false>
 __device__ __forceinline__ half8 finish_chunk8(const float* partial, int splits, int M, int N, const clora_epilogue_t& epi, int m, int n) {
     float s[8];
 #pragma unroll
@@ -186,16 +183,8 @@ __device__ __forceinline__ half8 finish_chunk8(const float* partial, int splits,
         floatx4 a[4], b[4];                                  // L2 / HBM round trip per slab: up to 12 per output chunk)
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            if constexpr (COH) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    a[u][e] = CLORA_LD_AGENT_F32(q0 + (size_t)(z + u) * zs + e);
-                    b[u][e] = CLORA_LD_AGENT_F32(q0 + (size_t)(z + u) * zs + 4 + e);
-                }
-            } else {
-                a[u] = *reinterpret_cast<const floatx4*>(q0 + (size_t)(z + u) * zs);
-                b[u] = *reinterpret_cast<const floatx4*>(q0 + (size_t)(z + u) * zs + 4);
-            }
+            a[u] = *reinterpret_cast<const floatx4*>(q0 + (size_t)(z + u) * zs);
+            b[u] = *reinterpret_cast<const floatx4*>(q0 + (size_t)(z + u) * zs + 4);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u)
@@ -203,14 +192,8 @@ __device__ __forceinline__ half8 finish_chunk8(const float* partial, int splits,
             for (int e = 0; e < 4; ++e) { s[e] += a[u][e]; s[4 + e] += b[u][e]; }
     }
     for (; z < splits; ++z) {
-        floatx4 a, b;
-        if constexpr (COH) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { a[e] = CLORA_LD_AGENT_F32(q0 + (size_t)z * zs + e); b[e] = CLORA_LD_AGENT_F32(q0 + (size_t)z * zs + 4 + e); }
-        } else {
-            a = *reinterpret_cast<const floatx4*>(q0 + (size_t)z * zs);
-            b = *reinterpret_cast<const floatx4*>(q0 + (size_t)z * zs + 4);
-        }
+        const floatx4 a = *reinterpret_cast<const floatx4*>(q0 + (size_t)z * zs);
+        const floatx4 b = *reinterpret_cast<const floatx4*>(q0 + (size_t)z * zs + 4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) { s[e] += a[e]; s[4 + e] += b[e]; }
     }

@@ -32,49 +32,10 @@ struct GemmArgs {
     int two_phase;             // option "epi_two_phase" at launch time (A/B switch of the two-phase chunk loop)
     int hoist_on;              // option "epi_hoist" at launch time (0: the one-chunk-at-a-time epilogue on the 8-wave tiles too)
     int tiles_m, n_major;      // n_major: logical tile t = n * tiles_m + m (else m * tiles_n + n); see pick_tile_order
-    int fin_splits;            // > 1: the LAST block of an output tile to store its slab finishes the tile itself (splitk_tail), no finish launch
     int xg_s, xg_m, xg_n;      // > 0: XCD x owns the (split, m, n) RECTANGLE x -> (x / (xg_m * xg_n), (x / xg_n) % xg_m, x % xg_n) of an xg_s x xg_m x xg_n grid
     clora_conv_t conv;
     clora_epilogue_t epi;
 };
-
-// ---- split-K without a finish launch (round 6).  Every block of an output tile stores its fp32 slab, then takes a ticket from the
-// tile's counter; the block that draws the last ticket folds ALL slabs of the tile in slab order 0..S-1 and applies the epilogue
-// (finish_chunk8: the finish kernel's own arithmetic in the same order => the same bits, whichever block happens to be last).  Nobody
-// waits for anybody, so there is no residency requirement.  Counters: library-owned device words, zero at load, reset by the finishing
-// block; launches that use them must be ordered on one stream (include/clora.h, "splitk_tail").  Coherence between the XCDs' L2s without
-// the L2-wide fences (clora_common.h CLORA_ST_AGENT_F32): slab stores and the finishing block's slab loads are agent-scope accesses, the
-// stores are drained (vmcnt 0) before the workgroup barrier that precedes the ticket.
-constexpr int kSplitkTickets = 1 << 15;                          // output tiles per launch; more: the finish kernel
-__device__ unsigned g_splitk_tickets[kSplitkTickets];
-
-template <int BM, int BN, int NT>
-__device__ __forceinline__ void splitk_tail(const GemmArgs& p, int m0, int n0, int t, half_t* smem) {
-    if (p.fin_splits <= 1) return;
-    unsigned* s_ticket = reinterpret_cast<unsigned*>(smem);      // the operand ring is free after the barrier below (no LDS of its own:
-    CLORA_WAIT_VMCNT(0);                                         // the 256x160 patch tile uses all 160 KB)
-    __syncthreads();
-    const int tile = (m0 / BM) * p.tiles_n + n0 / BN;
-    if (t == 0) *s_ticket = CLORA_TICKET_AGENT(&g_splitk_tickets[tile]);
-    __syncthreads();
-    if (*s_ticket + 1 != (unsigned)p.fin_splits) return;         // block-uniform
-    if (t == 0) CLORA_ST_AGENT_U32(&g_splitk_tickets[tile], 0u); // the next launch finds zeros
-    constexpr int CPR = BN / 8;                                  // 8-column chunks per tile row (BN % 8 == 0)
-    for (int c = t; c < BM * CPR; c += NT) {
-        const int ml = c / CPR, m = m0 + ml, n = n0 + (c - ml * CPR) * 8;
-        if (m < p.M && n < p.N) st8(p.C + (size_t)m * p.ldc + n, finish_chunk8<true>(p.partial, p.fin_splits, p.M, p.N, p.epi, m, n));
-    }
-}
-
-// host: in-kernel finish for this launch?  The caller (clora_gemm_f16_ex) leaves fin_splits = 1 where it is allowed (0: the consumer folds
-// the slabs itself, clora_epilogue_t.defer); not beyond the ticket table; N % 8 == 0 is what every finish path needs.
-inline void plan_splitk_tail(GemmArgs& a, int BM, int BN, int splits) {
-    const bool allowed = a.fin_splits == 1;
-    a.fin_splits = 0;
-    if (!allowed || splits <= 1 || !clora_option(CLORA_OPT_SPLITK_TAIL) || (a.N & 7) || (a.ldc & 7)) return;
-    if ((long)clora_cdiv(a.M, BM) * clora_cdiv(a.N, BN) > kSplitkTickets) return;
-    a.fin_splits = splits;
-}
 
 template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
@@ -216,12 +177,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
                 for (int r = 0; r < 4; ++r) {
                     const int m = m0 + wm * FM * 16 + i * 16 + 4 * g + r;
                     const int n = n0 + wn * FN * 16 + j * 16 + li;
-                    if (m < p.M && n < p.N) {
-                        if (p.fin_splits > 1) CLORA_ST_AGENT_F32(&slab[(size_t)m * p.N + n], acc[i][j][r]);
-                        else slab[(size_t)m * p.N + n] = acc[i][j][r];
-                    }
+                    if (m < p.M && n < p.N) slab[(size_t)m * p.N + n] = acc[i][j][r];
                 }
-        splitk_tail<BM, BN, 256>(p, m0, n0, t, smem);
         return;
     }
 
@@ -322,12 +279,8 @@ __device__ __forceinline__ void dma_epilogue(const GemmArgs& p, floatx4 (&acc)[B
                 for (int r = 0; r < 4; ++r) {
                     const int m = m0 + wm * FM * 16 + i * 16 + 4 * g + r;
                     const int n = n0 + wn * FN * 16 + j * 16 + li;
-                    if (m < p.M && n < p.N) {
-                        if (p.fin_splits > 1) CLORA_ST_AGENT_F32(&slab[(size_t)m * p.N + n], acc[i][j][r]);
-                        else slab[(size_t)m * p.N + n] = acc[i][j][r];
-                    }
+                    if (m < p.M && n < p.N) slab[(size_t)m * p.N + n] = acc[i][j][r];
                 }
-        splitk_tail<BM, BN, NT>(p, m0, n0, t, smem);
         return;
     }
     // ---- fp32 accumulators -> LDS (64 rows per pass) -> per row-chunk: bias / time-embedding / rank-r
@@ -1578,7 +1531,7 @@ int conv_mode(const GemmArgs& a, int bk) {
 // panels of its range under either order.   "tile_order": 0 m-major always, 1 n-major always
 // (tests), 2 pick by the model, 3 (default since round 5: live PMC traffic 1.69x -> 1.59x of the algorithmic bytes, bit-identical
 // outputs) = 2 plus a per-XCD rectangle of tiles where whole divisors exist.
-int g_opts[CLORA_OPT_COUNT] = {3, 1, 0, 0, 512, 1, 1, 0, 1, 1, 4, 1};    // tile_order, ln_rows, attn_fwd_waves (0 = auto), attn_bwd_waves (0 = auto), gn_blocks, epi_two_phase, lora_down_mode, gn_unroll, epi_hoist, gn_resident, defer_max_rows, splitk_tail
+int g_opts[CLORA_OPT_COUNT] = {3, 1, 0, 0, 512, 1, 1, 0, 1, 1, 4};    // tile_order, ln_rows, attn_fwd_waves (0 = auto), attn_bwd_waves (0 = auto), gn_blocks, epi_two_phase, lora_down_mode, gn_unroll, epi_hoist, gn_resident, defer_max_rows
 int tile_order_mode() { return g_opts[CLORA_OPT_TILE_ORDER]; }
 
 double fabric_model_bytes(int tiles_m, int tiles_n, int splits, double a_panel, double b_panel, bool n_major) {
@@ -1636,7 +1589,6 @@ template <int BM, int BN, int WM, int WN, int NST = 3, int BK = 32, int FLAGS = 
 int launch_gemm(GemmArgs& a, int splits, hipStream_t s, bool dma) {
     a.tiles_n = clora_cdiv(a.N, BN);
     const int tiles_m = clora_cdiv(a.M, BM);
-    plan_splitk_tail(a, BM, BN, splits);
     pick_tile_order(a, BM, BN, splits, false);
     if (!dma) { a.n_major = 0; a.xg_s = a.xg_m = a.xg_n = 0; }      // the v1 loop decodes blockIdx directly
     const dim3 grid(tiles_m * a.tiles_n, splits);
@@ -1662,7 +1614,6 @@ int launch_gemm(GemmArgs& a, int splits, hipStream_t s, bool dma) {
 
 int launch_gemm_8p(GemmArgs& a, int splits, hipStream_t s) {
     a.tiles_n = clora_cdiv(a.N, 256);
-    plan_splitk_tail(a, 256, 256, splits);
     pick_tile_order(a, 256, 256, splits, false);
     const dim3 grid(clora_cdiv(a.M, 256) * a.tiles_n, splits);
     hipLaunchKernelGGL((gemm_8p_kernel<0>), grid, dim3(512), 0, s, a);
@@ -1691,7 +1642,6 @@ bool patch_eligible(const GemmArgs& a, int bm, int maxpp = 0) {
 template <int BM, int BN, int WM, int WN, int NST, int MAXPP_ = 0>
 int launch_patch(GemmArgs& a, int splits, hipStream_t s) {
     a.tiles_n = clora_cdiv(a.N, BN);
-    plan_splitk_tail(a, BM, BN, splits);
     pick_tile_order(a, BM, BN, splits, true);
     const dim3 grid(clora_cdiv(a.M, BM) * a.tiles_n, splits);
     hipLaunchKernelGGL((conv3x3_patch_kernel<BM, BN, WM, WN, NST, MAXPP_>), grid, dim3(WM * WN * 64), 0, s, a);
@@ -1706,7 +1656,6 @@ int finish_or_defer(GemmArgs& a, int splits, clora_deferred_t* defer, hipStream_
         defer->epi.defer = nullptr;
         return CLORA_OK;
     }
-    if (a.fin_splits > 1) return CLORA_OK;                       // the last block of every tile already did it (splitk_tail)
     const size_t chunks = (size_t)a.M * (a.N / 8);
     int blocks = (int)((chunks + 255) / 256);
     if (blocks > 2048) blocks = 2048;
@@ -1780,7 +1729,6 @@ extern "C" int clora_gemm_f16_ex(const clora_half* A, int lda, const clora_half*
         defer->splits = 0;                                   // until a split-K launch below says otherwise
         defer->partial = nullptr;
     }
-    a.fin_splits = defer ? 0 : 1;                            // 1 = a split-K launch may finish inside the kernel (plan_splitk_tail)
     if (a.epi.lora_t && (a.epi.lora_r <= 0 || a.epi.lora_seg <= 0 || (a.epi.lora_seg & 15))) return CLORA_ERR_ARG;
     if (a.epi.rowadd && a.epi.rows_per_batch <= 0) return CLORA_ERR_ARG;
     if (a.epi.residual && (a.epi.ldr & 7)) return CLORA_ERR_ARG;
@@ -1973,7 +1921,7 @@ extern "C" int clora_set_option(const char* name, int value) {
                                 {"gn_blocks", CLORA_OPT_GN_BLOCKS, 64, 1 << 16}, {"epi_two_phase", CLORA_OPT_EPI_TWO_PHASE, 0, 1},
                                 {"lora_down_mode", CLORA_OPT_LORA_DOWN_MODE, 0, 2}, {"gn_unroll", CLORA_OPT_GN_UNROLL, 0, 1},
                                 {"epi_hoist", CLORA_OPT_EPI_HOIST, 0, 1}, {"gn_resident", CLORA_OPT_GN_RESIDENT, 0, 1},
-                                {"defer_max_rows", CLORA_OPT_DEFER_MAX_ROWS, 0, 16}, {"splitk_tail", CLORA_OPT_SPLITK_TAIL, 0, 1}};
+                                {"defer_max_rows", CLORA_OPT_DEFER_MAX_ROWS, 0, 16}};
     for (const Opt& o : kOpts)
         if (!strcmp(name, o.name)) {
             if (value < o.lo || value > o.hi) return CLORA_ERR_ARG;

@@ -32,6 +32,8 @@ struct GnArgs {
     float* dbeta;
     int B, HW, C, G, nchunk, rows_per_chunk;
     int accumulate_params;   // dgamma / dbeta are += (they are the parameters' .grad) instead of written
+    int params_in_apply;     // bwd, trainable affine: the first cdiv(C, 32) blocks of the apply launch also fold chpart into dgamma / dbeta
+                             // (round 6: the hint encoder's 22 gn_bwd_params launches per step are gone)
     int nslab, CS;  // channel slabs (whole groups, multiple of 8 channels) = blockIdx.y: fills the chip at low resolution
     float eps;
     int fuse_silu;
@@ -331,12 +333,47 @@ __global__ __launch_bounds__(256) void gn_fwd_apply2_kernel(GnArgs p) {
     }
 }
 
+// ---- backward, trainable affine: dgamma[c] = sum_{b,chunk} a2, dbeta[c] = sum a1  (fixed order: 8 interleaved
+// partial sums per channel folded through LDS; one block = 32 channels)
+__device__ __forceinline__ void gn_bwd_params_block(const GnArgs& p, int blk, float* red) {     // red: 512 floats of LDS
+    const int t = threadIdx.x, cl = t & 31, part = t >> 5;
+    const int c = blk * 32 + cl;
+    float sa = 0.f, sb = 0.f;
+    if (c < p.C) {
+        const int n = p.B * p.nchunk;
+        int i = part;
+        for (; i + 56 < n; i += 64) {                            // 8 loads in flight (was one L2 round trip per partial, 64 of them)
+            float v0[8], v1[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const float* pp = p.chpart + ((size_t)(i + 8 * u) * p.C + c) * 2; v0[u] = pp[0]; v1[u] = pp[1]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { sa += v0[u]; sb += v1[u]; }
+        }
+        for (; i < n; i += 8) {
+            const float* pp = p.chpart + ((size_t)i * p.C + c) * 2;
+            sa += pp[0]; sb += pp[1];
+        }
+    }
+    red[t * 2] = sa; red[t * 2 + 1] = sb;
+    __syncthreads();
+    if (part == 0 && c < p.C) {
+        for (int q = 1; q < 8; ++q) { sa += red[(q * 32 + cl) * 2]; sb += red[(q * 32 + cl) * 2 + 1]; }
+        if (p.accumulate_params) { p.dbeta[c] += sa; p.dgamma[c] += sb; }
+        else { p.dbeta[c] = sa; p.dgamma[c] = sb; }
+    }
+}
+
 // ---- fused finalize + apply (backward): dx = k1*dyp + k2*x + k3 with per-channel coefficients in registers
 template <int NJ, int UF = 1>
 __global__ __launch_bounds__(256) void gn_bwd_apply2_kernel(GnArgs p) {
     __shared__ float gs[64 * 2];
     const int t = threadIdx.x, b = blockIdx.z, chunk = blockIdx.x, cb = blockIdx.y * p.CS;
     const int CH = p.CS / 8, cpg = p.C / p.G;
+    if (p.params_in_apply) {                                     // chpart was written by the partial launch before this one
+        __shared__ float pred[256 * 2];
+        const int lin = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        if (lin * 32 < p.C) gn_bwd_params_block(p, lin, pred);   // block-uniform
+    }
     gn_fold_groups(p, b, t, gs, 1.0f / ((float)p.HW * (float)cpg));
     __syncthreads();
     int rl, nrl, c0, cstep; bool active;
@@ -409,35 +446,9 @@ __global__ __launch_bounds__(256) void gn_bwd_apply2_kernel(GnArgs p) {
     }
 }
 
-// ---- backward, trainable affine: dgamma[c] = sum_{b,chunk} a2, dbeta[c] = sum a1  (fixed order: 8 interleaved
-// partial sums per channel folded through LDS; one block = 32 channels)
 __global__ __launch_bounds__(256) void gn_bwd_params_kernel(GnArgs p) {
     __shared__ float red[256 * 2];
-    const int t = threadIdx.x, cl = t & 31, part = t >> 5;
-    const int c = blockIdx.x * 32 + cl;
-    float sa = 0.f, sb = 0.f;
-    if (c < p.C) {
-        const int n = p.B * p.nchunk;
-        int i = part;
-        for (; i + 56 < n; i += 64) {                            // 8 loads in flight (was one L2 round trip per partial, 64 of them)
-            float v0[8], v1[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) { const float* pp = p.chpart + ((size_t)(i + 8 * u) * p.C + c) * 2; v0[u] = pp[0]; v1[u] = pp[1]; }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) { sa += v0[u]; sb += v1[u]; }
-        }
-        for (; i < n; i += 8) {
-            const float* pp = p.chpart + ((size_t)i * p.C + c) * 2;
-            sa += pp[0]; sb += pp[1];
-        }
-    }
-    red[t * 2] = sa; red[t * 2 + 1] = sb;
-    __syncthreads();
-    if (part == 0 && c < p.C) {
-        for (int q = 1; q < 8; ++q) { sa += red[(q * 32 + cl) * 2]; sb += red[(q * 32 + cl) * 2 + 1]; }
-        if (p.accumulate_params) { p.dbeta[c] += sa; p.dgamma[c] += sb; }
-        else { p.dbeta[c] = sa; p.dgamma[c] = sb; }
-    }
+    gn_bwd_params_block(p, blockIdx.x, red);
 }
 
 // ------------------------------------------------------------------------------------------ GroupNorm in ONE launch
@@ -1140,7 +1151,8 @@ extern "C" int clora_groupnorm_bwd_f16_ex(const clora_half* x, const clora_half*
     if (two) hipLaunchKernelGGL(gn_bwd_partial_kernel<2>, grid, dim3(256), 0, s, a);
     else if (clora_option(CLORA_OPT_GN_UNROLL)) hipLaunchKernelGGL((gn_bwd_partial_kernel<1, 2>), grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL(gn_bwd_partial_kernel<1>, grid, dim3(256), 0, s, a);
-    if (dgamma) hipLaunchKernelGGL(gn_bwd_params_kernel, dim3(clora_cdiv(C, 32)), dim3(256), 0, s, a);
+    a.params_in_apply = (dgamma && (long)a.nchunk * a.nslab * B >= clora_cdiv(C, 32)) ? 1 : 0;
+    if (dgamma && !a.params_in_apply) hipLaunchKernelGGL(gn_bwd_params_kernel, dim3(clora_cdiv(C, 32)), dim3(256), 0, s, a);
     if (two) hipLaunchKernelGGL(gn_bwd_apply2_kernel<2>, grid, dim3(256), 0, s, a);
     else if (clora_option(CLORA_OPT_GN_UNROLL)) hipLaunchKernelGGL((gn_bwd_apply2_kernel<1, 2>), grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL(gn_bwd_apply2_kernel<1>, grid, dim3(256), 0, s, a);

@@ -599,8 +599,8 @@ def lora_wgrad_multi(jobs, device):
         groups.setdefault(4 if j.R <= 4 else (8 if j.R <= 8 else 16), []).append(j)
     wsb = capi.lib().cdll.clora_lora_wgrad_workspace_bytes
     for _, js in groups.items():
-        for i in range(0, len(js), capi.LORA_WGRAD_MAX_JOBS):
-            chunk = js[i:i + capi.LORA_WGRAD_MAX_JOBS]
+        for i in range(0, len(js), capi.WGRAD_JOBS_PER_LAUNCH):
+            chunk = js[i:i + capi.WGRAD_JOBS_PER_LAUNCH]
             ws = workspace(sum(wsb(j.M, j.N, j.R) for j in chunk), device)
             arr = (capi.LoraWgradJob * len(chunk))(*chunk)
             _call("clora_lora_wgrad_multi_f16", arr, len(chunk), ptr(ws), ws.numel(), nbytes=sum(2.0 * j.M * j.N for j in chunk))
@@ -672,7 +672,7 @@ def lora_wgrad_flush():
         batches = []               # greedy packing: a batch never holds two jobs with the same destination
         for j in jobs:
             for b in batches:
-                if len(b[0]) < capi.LORA_WGRAD_MAX_JOBS and j.G not in b[1] and b[2] == (4 if j.R <= 4 else (8 if j.R <= 8 else 16)):
+                if len(b[0]) < capi.WGRAD_JOBS_PER_LAUNCH and j.G not in b[1] and b[2] == (4 if j.R <= 4 else (8 if j.R <= 8 else 16)):
                     b[0].append(j); b[1].add(j.G)
                     break
             else:

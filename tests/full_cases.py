@@ -190,26 +190,47 @@ def ddim_parity(o_unet, o_clora, p_unet, p_clora, dev, res, steps, guidance_scal
     uncond = torch.randn(nb, ctx_len, ctx_dim, generator=g).half().float()
     lat0 = torch.randn(nb, 4, L, L, generator=g).half().float()
     loop = oracle_ddim if sampler == "ddim" else oracle_dpm
-    ref, traj = loop(o_unet, o_clora, guide, cond, uncond, steps, guidance_scale, lat0)
-    floor = None
-    if fp16_floor:
-        floor = fp16_oracle_floor(o_unet, o_clora, guide, cond, uncond, steps, guidance_scale, lat0, ref, loop=loop)
+    # the oracle trajectory (and its fp16-regime floor) depend only on the case, not on how the product is driven (eager / graph): one
+    # oracle run per case and process (round 6: the two DPM parametrisations were 2 x 70 s of the same CPU loop on the GPU box)
+    key = (sampler, res, steps, float(guidance_scale), nb, ctx_dim, ctx_len, seed, bool(fp16_floor),
+           tuple(sorted(k for k, _ in o_clora.named_parameters()))[:4], float(sum(float(p.double().sum()) for p in o_clora.parameters())))
+    hit = _ORACLE_LOOPS.get(key)
+    if hit is None:
+        ref, traj = loop(o_unet, o_clora, guide, cond, uncond, steps, guidance_scale, lat0)
+        floor = None
+        if fp16_floor:
+            floor = fp16_oracle_floor(o_unet, o_clora, guide, cond, uncond, steps, guidance_scale, lat0, ref, loop=loop, dev=dev)
+        hit = _ORACLE_LOOPS[key] = (ref, floor)
+    ref, floor = hit
     kw = dict(graph=True) if graph else {}
     out = ddim_sample(p_unet, p_clora, guide.to(dev).half(), cond.to(dev).half(), uncond.to(dev).half(), steps=steps,
                       guidance_scale=guidance_scale, latents=lat0.to(dev).half(), sampler=sampler, **kw)
     return {"latents": rel(out, ref), "steps": steps, "latent_norm": float(ref.norm()), "fp16_oracle_vs_fp32_oracle": floor}
 
 
-def fp16_oracle_floor(o_unet, o_clora, guide, cond, uncond, steps, guidance_scale, lat0, ref, loop=None):
+_ORACLE_LOOPS = {}
+
+
+def fp16_oracle_floor(o_unet, o_clora, guide, cond, uncond, steps, guidance_scale, lat0, ref, loop=None, dev="cpu"):
     """What "fp16" costs ANY implementation: the same oracle loop with every module and tensor in fp16 (the arithmetic
     regime of the reference's own fp16 pipeline: fp16 storage of weights / activations / latents) against the fp32 oracle.
-    north_star's "within 1e-3 rel fp16" is read against this floor (SURVEY.md section 8c "Tolerance reading")."""
+    north_star's "within 1e-3 rel fp16" is read against this floor (SURVEY.md section 8c "Tolerance reading").
+    On a GPU box the fp16 oracle runs there (stock torch ops, the reference's own regime: fp16 storage, fp32 accumulation inside
+    the vendor kernels) -- the host's fp16 kernels made this loop 100 s of a 150 s test."""
     import copy
     from oracle.controllora_ref import map_processors_to_unet as omap
-    h_unet, h_clora = copy.deepcopy(o_unet).half(), copy.deepcopy(o_clora).half()
-    h_unet.set_attn_processor(omap(h_unet, h_clora))
-    out, _ = (loop or oracle_ddim)(h_unet, h_clora, guide.half(), cond.half(), uncond.half(), steps, guidance_scale, lat0.half())
-    return rel(out, ref)
+    def run(where):
+        h_unet, h_clora = copy.deepcopy(o_unet).half().to(where), copy.deepcopy(o_clora).half().to(where)
+        h_unet.set_attn_processor(omap(h_unet, h_clora))
+        mv = lambda t: t.half().to(where)
+        out, _ = (loop or oracle_ddim)(h_unet, h_clora, mv(guide), mv(cond), mv(uncond), steps, guidance_scale, mv(lat0))
+        return rel(out.float().cpu(), ref)
+    if torch.device(dev).type == "cuda":
+        try:
+            return run(dev)
+        except RuntimeError as e:                      # an oracle module that builds a tensor on the host: the host loop instead
+            print("NOTE fp16_oracle_floor: GPU run of the oracle failed, falling back to the host:", str(e).splitlines()[0][:200])
+    return run("cpu")
 
 
 def full_size_properties(dev, config_name="fill50k.json", res=512, batch=4):

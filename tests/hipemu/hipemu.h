@@ -18,7 +18,6 @@
 #include <cstring>
 #include <functional>
 
-#define CLORA_HIPEMU 1
 #define __global__
 #define __device__
 #define __host__
@@ -122,10 +121,6 @@ static inline hipemu_half4 hipemu_tr16(const void* p) {
 #define CLORA_WAIT_LGKMCNT(n) ((void)0)
 #define CLORA_SETPRIO(n) ((void)0)
 #define CLORA_SCHED_BARRIER() ((void)0)
-#define CLORA_ST_AGENT_F32(p, v) (*(p) = (v))
-#define CLORA_LD_AGENT_F32(p) (*(p))
-#define CLORA_TICKET_AGENT(p) ((*(p))++)
-#define CLORA_ST_AGENT_U32(p, v) (*(p) = (v))
 static inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }
 static inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v; return o; }
 static inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }

@@ -348,15 +348,6 @@ def test_kernels_are_bit_stable_run_to_run(family):
     for u, v_ in zip(a, b):
         assert torch.equal(u, v_), f"{family}: two identical launches differ in {int((u != v_).sum())} elements"
         assert bool(torch.isfinite(u.float()).all())
-    if family == "conv_patch_splitk":
-        # round 6: the last block of every tile finishes the split-K sum inside the GEMM launch ("splitk_tail", default) -- the finish
-        # kernel's own loads and arithmetic in slab order, so the separate finish launch gives the same bits
-        K.set_option("splitk_tail", 0)
-        try:
-            c = run()
-        finally:
-            K.set_option("splitk_tail", int(os.environ.get("CLORA_SPLITK_TAIL", "1")))
-        assert torch.equal(a[0], c[0])
 
 
 def test_every_plain_entry_of_the_tuned_table_is_exact_and_bit_stable():
