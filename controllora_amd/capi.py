@@ -202,7 +202,7 @@ class Lib:
                     "CLORA_GN_BLOCKS": ("gn_blocks", None), "CLORA_EPI_TWO_PHASE": ("epi_two_phase", None),
                     "CLORA_LORA_DOWN_MODE": ("lora_down_mode", None), "CLORA_GN_UNROLL": ("gn_unroll", None),
                     "CLORA_EPI_HOIST": ("epi_hoist", None), "CLORA_GN_RESIDENT": ("gn_resident", None),
-                    "CLORA_DEFER_MAX_ROWS": ("defer_max_rows", None)}
+                    "CLORA_DEFER_MAX_ROWS": ("defer_max_rows", None), "CLORA_WGRAD_PATCH": ("wgrad_patch", None)}
 
     def _options_from_env(self):
         for var, (name, names) in self._ENV_OPTIONS.items():

@@ -1495,6 +1495,181 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_kernel(WgradArgs p) {
             }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Weight gradient of the hint encoder's LARGE-map 3x3 convolutions (512^2 / 256^2 / 128^2, 32 or 64 input channels; round 6).
+// conv_wgrad_kernel above gathers X once per 64-column k tile and re-reads dY for every one of them: at 512^2 x 32 channels that is
+// 1.3 GB of L2 -> LDS traffic for two 67 MB tensors (96 us; the launch is L2-bandwidth bound at 8 % MFMA busy).  Here a block owns a
+// column strip of TW output pixels and walks down its rows; per output row it stages, ONCE, the three input rows of the strip as a
+// halo patch (3 x (TW + 2) pixels, all CIN channels) and the row's dY (TW x N) by LDS-DMA, double buffered, and forms ALL 9 x CIN
+// columns of dW from them: dY crosses L2 -> LDS once, X three times (the rows above / below are re-staged for the next row).
+//   * LDS planes of 16 channels: [pixel][16] halves (32 bytes per pixel, contiguous): the reduction index (pixels) is the MFMA k index,
+//     both operands are fetched with ds_read_b64_tr_b16 exactly as in conv_wgrad_kernel; for tap (ky, kx) the B operand of k-step s is
+//     the plane at pixel ky * PW + kx + 32 s -- consecutive output pixels are consecutive patch pixels, so a tap is an address offset;
+//   * waves = (CIN / 16 input-channel blocks) x 2 output-channel halves, each wave: 9 taps x NFW fragments of accumulators;
+//   * the bias gradient is one more MFMA per k-step against an all-ones operand (registers); fp32 atomics into the gather-ordered
+//     staging buffer like conv_wgrad_kernel (same destination layout).
+struct WgradPatchArgs {
+    const half_t* dY;
+    const half_t* X;
+    float* dW;
+    float* db;
+    int N, K, H, W, nimg, nseg, rows_per_block, row_chunks;      // H, W: OUTPUT rows / columns per image
+    int Hin, Win;
+};
+
+//   * STRIDE 2 (the downsamplers: 3x3, stride 2, zero row / column at the bottom / right only -- F.pad(0, 1, 0, 1)): output row yo reads
+//     input rows 2 yo .. 2 yo + 2 and input columns 2 x0 .. 2 x0 + 2 TW; a patch row holds the EVEN columns (TW + 1 of them) followed by
+//     the ODD ones (the DMA's per-lane source address de-interleaves for free), so that tap kx is again an address offset:
+//     kx = 0 -> even[m], kx = 1 -> odd[m], kx = 2 -> even[m + 1].
+template <int CIN, int NFW, int TW, int STRIDE = 1>
+__global__ __launch_bounds__(CIN / 16 * 128) void conv_wgrad_patch_kernel(WgradPatchArgs p) {
+    constexpr int WC = CIN / 16, NW = WC * 2, NP = 2 * NFW;
+    constexpr int PW = STRIDE == 1 ? TW + 2 : 2 * TW + 1, PPIX = 3 * PW;
+    constexpr int P_NI = (PPIX * 2 + 63) / 64;                   // DMA wave-instructions per patch plane (64 chunks of 16 bytes each)
+    constexpr int PLANE = P_NI * 512;                            // halves
+    constexpr int Y_NI = TW * 2 / 64, YPLANE = TW * 16;
+    constexpr int BUF = WC * PLANE + NP * YPLANE;
+    constexpr int NI = WC * P_NI + NP * Y_NI, NIW = (NI + NW - 1) / NW;
+    constexpr int KS = TW / 32;
+    static_assert((2 * BUF + 512) * 2 <= 160 * 1024, "LDS per workgroup");
+    __shared__ __attribute__((aligned(16))) half_t smem[2 * BUF + 512];      // two buffers + one dump slot for surplus DMA instructions
+    const int t = threadIdx.x, w = t >> 6, l = t & 63, g = l >> 4, li = l & 15;
+    const int cb = w >> 1, wn = w & 1;                           // this wave's input-channel block and output-channel half
+    const half_t* zero_page = reinterpret_cast<const half_t*>(g_clora_zero16);
+
+    // ---- which strip: block -> (image, column segment, row chunk)
+    int bid = blockIdx.x;
+    const int rc = bid % p.row_chunks; bid /= p.row_chunks;
+    const int seg = bid % p.nseg, img = bid / p.nseg;
+    const int x0 = seg * TW, y_beg = rc * p.rows_per_block;
+    const int y_end = (y_beg + p.rows_per_block < p.H) ? y_beg + p.rows_per_block : p.H;
+
+    // ---- loader: DMA instruction i = w + NW * j of an output row; per lane: kind, source offset relative to the row, destination
+    int kind[NIW], soff[NIW], doff[NIW];                         // kind: -1 zero page always, 0..2 patch row, 3 dY
+#pragma unroll
+    for (int j = 0; j < NIW; ++j) {
+        const int i = w + NW * j;
+        kind[j] = -1; soff[j] = 0; doff[j] = 2 * BUF;            // surplus instruction: zero page into the dump slot
+        if (i < WC * P_NI) {
+            const int pl = i / P_NI, pi = i - pl * P_NI;
+            const int c = pi * 64 + l, pp = c >> 1, h = c & 1;
+            doff[j] = pl * PLANE + pi * 512;
+            if (pp < PPIX) {
+                const int pr = pp / PW, pc = pp - pr * PW;
+                if constexpr (STRIDE == 1) {
+                    const int x = x0 - 1 + pc;
+                    if (x >= 0 && x < p.W) { kind[j] = pr; soff[j] = ((pr - 1) * p.W + (pc - 1)) * CIN + pl * 16 + h * 8; }
+                } else {
+                    const int dx = pc <= TW ? 2 * pc : 2 * (pc - TW - 1) + 1;       // input column relative to 2 x0
+                    if (2 * x0 + dx < p.Win) { kind[j] = pr; soff[j] = (pr * p.Win + dx) * CIN + pl * 16 + h * 8; }
+                }
+            }
+        } else if (i < NI) {
+            const int q = i - WC * P_NI, nb = q / Y_NI, yi = q - nb * Y_NI;
+            const int c = yi * 64 + l, m = c >> 1, h = c & 1;
+            doff[j] = WC * PLANE + nb * YPLANE + yi * 512;
+            if (nb * 16 + h * 8 < p.N) { kind[j] = 3; soff[j] = m * p.N + nb * 16 + h * 8; }
+        }
+    }
+    auto issue_row = [&](int y, int buf) {
+        half_t* dst = smem + buf * BUF;
+        const bool live = y < y_end;
+        const size_t row = ((size_t)img * p.H + (live ? y : y_beg)) * p.W + x0;       // first output pixel of the row segment
+#pragma unroll
+        for (int j = 0; j < NIW; ++j) {
+            const half_t* src = zero_page;
+            if (live && kind[j] >= 0) {
+                if (kind[j] == 3) src = p.dY + row * p.N + soff[j];
+                else if constexpr (STRIDE == 1) {
+                    const int yy = y - 1 + kind[j];
+                    if (yy >= 0 && yy < p.H) src = p.X + (ptrdiff_t)row * CIN + soff[j];
+                } else {
+                    if (2 * y + kind[j] < p.Hin) src = p.X + (((size_t)img * p.Hin + 2 * y) * p.Win + 2 * x0) * CIN + soff[j];
+                }
+            }
+            half_t* d = (doff[j] == 2 * BUF) ? smem + 2 * BUF : dst + doff[j];
+            CLORA_GLDS16(src, d);
+        }
+    };
+
+    // ---- fragments: transpose reads of [4 pixels][16 channels] blocks (32 bytes per pixel), as in conv_wgrad_kernel
+    const int troff = (g * 8 + (li >> 2)) * 16 + (l & 3) * 4;
+    floatx4 acc[9][NFW], accb[NFW];
+#pragma unroll
+    for (int f = 0; f < NFW; ++f) {
+        accb[f] = zero4f();
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) acc[tap][f] = zero4f();
+    }
+    const half8 ones = {(half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f};
+
+    issue_row(y_beg, 0);
+    for (int y = y_beg; y < y_end; ++y) {
+        const int buf = (y - y_beg) & 1;
+        issue_row(y + 1, buf ^ 1);                               // (past the strip: zero-page instructions, the count stays the same)
+        CLORA_WAIT_VMCNT(NIW);                                   // everything but the row just issued has landed: row y
+        CLORA_RAW_BARRIER();
+        const half_t* P = smem + buf * BUF + cb * PLANE;
+        const half_t* Y = smem + buf * BUF + WC * PLANE + (wn * NFW) * YPLANE;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            half8 af[NFW];
+#pragma unroll
+            for (int f = 0; f < NFW; ++f) {
+                const half_t* q = Y + f * YPLANE + s * 512 + troff;
+                const half4v lo = CLORA_DS_READ_TR16(q), hi = CLORA_DS_READ_TR16(q + 64);
+                af[f] = half8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+            if (cb == 0) {                                       // wave-uniform: the bias gradient rides with channel block 0
+#pragma unroll
+                for (int f = 0; f < NFW; ++f) accb[f] = mfma16(af[f], ones, accb[f]);
+            }
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int ky = tap / 3, kx = tap - ky * 3;
+                const int koff = STRIDE == 1 ? kx : (kx == 1 ? TW + 1 : kx / 2);
+                const half_t* q = P + (ky * PW + koff + s * 32) * 16 + troff;
+                const half4v lo = CLORA_DS_READ_TR16(q), hi = CLORA_DS_READ_TR16(q + 64);
+                const half8 bf = half8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+                for (int f = 0; f < NFW; ++f) acc[tap][f] = mfma16(af[f], bf, acc[tap][f]);
+            }
+        }
+        CLORA_RAW_BARRIER();                                     // row y consumed by every wave: its buffer is the target of the next issue
+    }
+    CLORA_WAIT_VMCNT(0);
+#pragma unroll
+    for (int f = 0; f < NFW; ++f)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = (wn * NFW + f) * 16 + 4 * g + r;
+            if (n < p.N) {
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) atomicAdd(p.dW + (size_t)n * p.K + tap * CIN + cb * 16 + li, acc[tap][f][r]);
+                if (cb == 0 && li == 0 && p.db) atomicAdd(p.db + n, accb[f][r]);
+            }
+        }
+}
+
+template <int CIN, int NFW, int TW, int STRIDE = 1>
+int launch_wgrad_patch(WgradPatchArgs& a, hipStream_t s) {
+    a.nseg = a.W / TW;
+    const long strips = (long)a.nimg * a.nseg;
+    // Every block adds its whole N x (K + 1) result with fp32 atomics, ~6 ns each on MI355X (block-count sweep, profiles/r06_wgrad_patch_sweep.txt:
+    // 512^2 32->32 takes 76 / 74 / 103 / 167 us at 256 / 512 / 1024 / 2048 blocks): as many blocks as keep the launch under ~4.7 M atomics,
+    // between 64 and 512 (A/B: "wgrad_patch" >= 64 forces the count)
+    long target = 4700000L / ((long)a.N * (a.K + 1));
+    target = target < 64 ? 64 : (target > 512 ? 512 : target);
+    if (clora_option(CLORA_OPT_WGRAD_PATCH) >= 64) target = clora_option(CLORA_OPT_WGRAD_PATCH);
+    long rpb = ((long)a.H * strips + target - 1) / target;
+    if (rpb < 4) rpb = 4;
+    if (rpb > a.H) rpb = a.H;
+    a.rows_per_block = (int)rpb;
+    a.row_chunks = clora_cdiv(a.H, rpb);
+    hipLaunchKernelGGL((conv_wgrad_patch_kernel<CIN, NFW, TW, STRIDE>), dim3((unsigned)(strips * a.row_chunks)), dim3(CIN / 16 * 128), 0, s, a);
+    return clora_check_launch();
+}
+
 // fp32 master weight [Co][Ci][ks][ks] of a trainable conv -> the two fp16 GEMM operands of this step in one launch:
 // fwd [Co][ks*ks][Cip] (gather order ky,kx,ci; channels zero-padded to Cip) and, optionally, dgrad [Cip][ks*ks][Cop].
 __global__ __launch_bounds__(256) void conv_weight_pack_kernel(const float* w, int Co, int Ci, int taps, int Cip, int Cop,
@@ -1531,7 +1706,7 @@ int conv_mode(const GemmArgs& a, int bk) {
 // panels of its range under either order.   "tile_order": 0 m-major always, 1 n-major always
 // (tests), 2 pick by the model, 3 (default since round 5: live PMC traffic 1.69x -> 1.59x of the algorithmic bytes, bit-identical
 // outputs) = 2 plus a per-XCD rectangle of tiles where whole divisors exist.
-int g_opts[CLORA_OPT_COUNT] = {3, 1, 0, 0, 512, 1, 1, 0, 1, 1, 4};    // tile_order, ln_rows, attn_fwd_waves (0 = auto), attn_bwd_waves (0 = auto), gn_blocks, epi_two_phase, lora_down_mode, gn_unroll, epi_hoist, gn_resident, defer_max_rows
+int g_opts[CLORA_OPT_COUNT] = {3, 1, 0, 0, 512, 1, 1, 0, 1, 1, 4, 1};    // tile_order, ln_rows, attn_fwd_waves (0 = auto), attn_bwd_waves (0 = auto), gn_blocks, epi_two_phase, lora_down_mode, gn_unroll, epi_hoist, gn_resident, defer_max_rows, wgrad_patch
 int tile_order_mode() { return g_opts[CLORA_OPT_TILE_ORDER]; }
 
 double fabric_model_bytes(int tiles_m, int tiles_n, int splits, double a_panel, double b_panel, bool n_major) {
@@ -1921,7 +2096,7 @@ extern "C" int clora_set_option(const char* name, int value) {
                                 {"gn_blocks", CLORA_OPT_GN_BLOCKS, 64, 1 << 16}, {"epi_two_phase", CLORA_OPT_EPI_TWO_PHASE, 0, 1},
                                 {"lora_down_mode", CLORA_OPT_LORA_DOWN_MODE, 0, 2}, {"gn_unroll", CLORA_OPT_GN_UNROLL, 0, 1},
                                 {"epi_hoist", CLORA_OPT_EPI_HOIST, 0, 1}, {"gn_resident", CLORA_OPT_GN_RESIDENT, 0, 1},
-                                {"defer_max_rows", CLORA_OPT_DEFER_MAX_ROWS, 0, 16}};
+                                {"defer_max_rows", CLORA_OPT_DEFER_MAX_ROWS, 0, 16}, {"wgrad_patch", CLORA_OPT_WGRAD_PATCH, 0, 8192}};
     for (const Opt& o : kOpts)
         if (!strcmp(name, o.name)) {
             if (value < o.lo || value > o.hi) return CLORA_ERR_ARG;
@@ -2005,6 +2180,35 @@ extern "C" int clora_conv_wgrad_f16(const clora_half* dY, int ldy, const clora_h
         a.conv = clora_conv_t();
         a.conv.enabled = 0;
         if (ldx & 7) return CLORA_ERR_ARG;
+    }
+    // the large-map 3x3 stride-1 pad-1 convolutions of the hint encoder: patch-staged kernel (conv_wgrad_patch_kernel)
+    if (conv && conv->enabled && clora_option(CLORA_OPT_WGRAD_PATCH) && oihw_ci == 0 && ldy == N) {
+        const clora_conv_t& c = *conv;
+        const bool s1 = c.ksize == 3 && c.mul == 1 && c.kmul == 1 && c.off == -1 && c.shift == 0 && c.need_even == 0 && c.Hout == c.Hin &&
+                        c.Wout == c.Win && c.lim_h == c.Hin && c.lim_w == c.Win && c.Hout > 0 && (M % (c.Hout * c.Wout)) == 0 &&
+                        (long)M * (c.Cin > N ? c.Cin : N) < (1L << 31);
+        // ... and its stride-2 downsamplers (F.pad(0, 1, 0, 1) then stride 2: conv_fwd_desc(asym_pad))
+        const bool s2 = c.ksize == 3 && c.mul == 2 && c.kmul == 1 && c.off == 0 && c.shift == 0 && c.need_even == 0 && c.Hin == 2 * c.Hout &&
+                        c.Win == 2 * c.Wout && c.lim_h == c.Hin && c.lim_w == c.Win && c.Hout > 0 && (M % (c.Hout * c.Wout)) == 0 &&
+                        (long)M * 4 * (c.Cin > N ? c.Cin : N) < (1L << 31);
+        if ((s1 || s2) && (c.Cin == 32 || c.Cin == 64) && N <= 64) {
+            WgradPatchArgs q;
+            q.dY = (const half_t*)dY; q.X = (const half_t*)X; q.dW = dW; q.db = db; q.N = N; q.K = K; q.H = c.Hout; q.W = c.Wout;
+            q.Hin = c.Hin; q.Win = c.Win;
+            q.nimg = M / (c.Hout * c.Wout);
+            hipStream_t s = (hipStream_t)stream;
+            if (s2) {
+                if (c.Cin == 32 && N <= 32 && (c.Wout % 64) == 0) return launch_wgrad_patch<32, 1, 64, 2>(q, s);
+                if (c.Cin == 32 && N <= 64 && (c.Wout % 64) == 0) return launch_wgrad_patch<32, 2, 64, 2>(q, s);
+                if (c.Cin == 64 && N <= 64 && (c.Wout % 64) == 0) return launch_wgrad_patch<64, 2, 64, 2>(q, s);
+            } else {
+            if (c.Cin == 32 && N <= 32 && (c.Wout % 128) == 0) return launch_wgrad_patch<32, 1, 128>(q, s);
+            if (c.Cin == 32 && N <= 64 && (c.Wout % 128) == 0) return launch_wgrad_patch<32, 2, 128>(q, s);
+            if (c.Cin == 32 && N <= 64 && (c.Wout % 64) == 0) return launch_wgrad_patch<32, 2, 64>(q, s);
+            if (c.Cin == 64 && N <= 64 && (c.Wout % 64) == 0) return launch_wgrad_patch<64, 2, 64>(q, s);
+            // (64 -> 128 channels at 128^2: 74 K results per block; 56 us at 64 blocks against 57 for the gather kernel -- stays there)
+            }
+        }
     }
     a.tiles_n = clora_cdiv(N, 64);
     a.tiles_k = clora_cdiv(K + (db ? 8 : 0), 64);

@@ -246,6 +246,37 @@ def case_conv(dev, Bn, H, W, Ci, Co, stride=1, pad=1, ups=False, asym=False, see
             assert float(stage.abs().max()) == 0.0
 
 
+def case_conv_wgrad_patch(dev, Bn, H, W, Ci, Co, seed=21, stride=1):
+    """Round 6 (conv_wgrad_patch_kernel): the weight / bias gradient of a large-map 3x3 stride-1 pad-1 convolution with 32 or 64 input
+    channels (the hint encoder's 512^2 / 256^2 / 128^2 stages, reference models.py:470-543 ConvBlock2D / SimpleDownEncoderBlock2D under
+    loss.backward(), train...:786) on the patch-staged kernel vs fp32 torch autograd, and vs the gather kernel it replaces there
+    ("wgrad_patch" 0) -- same products, another summation order (fp32 atomics in both)."""
+    g = torch.Generator().manual_seed(seed)
+    x = rnd((Bn, Ci, H, W), dev, g)
+    w = rnd((Co, Ci, 3, 3), dev, g, 1 / math.sqrt(9 * Ci))
+    Ho, Wo = (H, W) if stride == 1 else (H // 2, W // 2)              # stride 2: the downsamplers' F.pad(0, 1, 0, 1) + stride 2 (H, W even)
+    dy = rnd((Bn, Co, Ho, Wo), dev, g)
+    w32 = w.float().clone().requires_grad_(True)
+    (F.conv2d(x.float(), w32, padding=1) if stride == 1 else F.conv2d(F.pad(x.float(), (0, 1, 0, 1)), w32, stride=2)).backward(dy.float())
+    xn = x.permute(0, 2, 3, 1).contiguous().reshape(-1, Ci)
+    dyn = dy.permute(0, 2, 3, 1).contiguous().reshape(-1, Co)
+    cd, Ho2, Wo2 = K.conv_fwd_desc(H, W, Ci, 3, stride, 1 if stride == 1 else 0, asym_pad=stride == 2)
+    assert (Ho2, Wo2) == (Ho, Wo)
+    M = Bn * Ho * Wo
+    want_w, want_b = w32.grad.permute(0, 2, 3, 1).reshape(Co, 9 * Ci), dy.float().sum((0, 2, 3))
+    dW, db = K.conv_wgrad(dyn, xn, M, Co, 9 * Ci, cd, with_bias=True)
+    assert rel(dW, want_w) < 1e-4 and rel(db, want_b) < 1e-4, (rel(dW, want_w), rel(db, want_b))
+    no_outliers(dW, want_w, "conv_wgrad_patch dW")
+    K.set_option("wgrad_patch", 0)
+    try:
+        dW0, db0 = K.conv_wgrad(dyn, xn, M, Co, 9 * Ci, cd, with_bias=True)
+    finally:
+        K.set_option("wgrad_patch", int(os.environ.get("CLORA_WGRAD_PATCH", "1")))
+    assert rel(dW, dW0) < 2e-5 and rel(db, db0) < 2e-5
+    dW2 = K.conv_wgrad(dyn, xn, M, Co, 9 * Ci, cd)                      # without the bias gradient
+    assert rel(dW2, want_w) < 1e-4
+
+
 def case_conv_patch_upsampled(dev, Bn, H, W, Ci, Co, tile_cfg, seed=13):
     """conv3x3_patch_kernel on conv(nearest-2x(x)) (Upsample2D): the patch lives at the output resolution"""
     from controllora_amd.ops import conv_k_order

@@ -29,6 +29,17 @@ def test_conv_fwd_dgrad_wgrad(kw):
     KC.case_conv("cpu", 2, 12, 10, 16, 24, **kw)
 
 
+@pytest.mark.parametrize("Bn,H,W,Ci,Co", [(1, 3, 128, 32, 32), (2, 5, 64, 32, 64), (1, 2, 64, 64, 64), (1, 3, 64, 64, 48), (1, 2, 128, 32, 64)])
+def test_conv_wgrad_patch_kernel(Bn, H, W, Ci, Co):
+    KC.case_conv_wgrad_patch("cpu", Bn, H, W, Ci, Co)
+
+
+@pytest.mark.parametrize("Bn,H,W,Ci,Co", [(1, 6, 128, 32, 32), (2, 4, 128, 32, 64), (1, 4, 128, 64, 64), (1, 2, 256, 32, 16)])
+def test_conv_wgrad_patch_kernel_stride2(Bn, H, W, Ci, Co):
+    """the downsamplers (reference models.py SimpleDownEncoderBlock2D: F.pad(0, 1, 0, 1) + 3x3 stride 2); H, W = INPUT size"""
+    KC.case_conv_wgrad_patch("cpu", Bn, H, W, Ci, Co, stride=2)
+
+
 def test_conv_small_channels():
     KC.case_conv("cpu", 1, 16, 16, 8, 32)       # hint-encoder conv_in shape class (3 -> padded 8 channels)
 
@@ -181,6 +192,12 @@ def test_gemm_rings_zero_latency_dma(tile, zero_latency_dma):
 def test_conv_patch_zero_latency_dma(tile, zero_latency_dma):
     KC.case_conv_patch("cpu", 2, 8, 8, 128, 64, tile)
     KC.case_conv_patch_upsampled("cpu", 1, 4, 4, 64, 64, tile) if tile in (71, 72, 76) else None
+
+
+def test_conv_wgrad_patch_zero_latency_dma(zero_latency_dma):
+    """the double-buffered row loop of conv_wgrad_patch_kernel when every copy lands at issue (a row staged into a buffer that a slower
+    wave still reads would corrupt that wave's operands)"""
+    KC.case_conv_wgrad_patch("cpu", 1, 4, 64, 32, 64)
 
 
 @pytest.mark.parametrize("B,H,Nq,Nk,D", [(1, 2, 70, 300, 40), (1, 2, 640, 77, 40), (1, 1, 150, 200, 64)])

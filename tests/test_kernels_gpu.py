@@ -40,6 +40,17 @@ def test_conv_unet_shape():
     KC.case_conv(DEV, 1, 32, 32, 320, 640)
 
 
+@pytest.mark.parametrize("Bn,H,W,Ci,Co", [(4, 512, 512, 32, 32), (4, 256, 256, 32, 64), (4, 128, 128, 64, 64), (2, 37, 192, 64, 64), (1, 5, 128, 32, 16)])
+def test_conv_wgrad_patch_kernel(Bn, H, W, Ci, Co):
+    KC.case_conv_wgrad_patch(DEV, Bn, H, W, Ci, Co)
+
+
+@pytest.mark.parametrize("Bn,H,W,Ci,Co", [(4, 512, 512, 32, 32), (4, 256, 256, 64, 64), (2, 38, 384, 32, 64), (1, 6, 128, 64, 24)])
+def test_conv_wgrad_patch_kernel_stride2(Bn, H, W, Ci, Co):
+    """the downsamplers (reference models.py SimpleDownEncoderBlock2D: F.pad(0, 1, 0, 1) + 3x3 stride 2); H, W = INPUT size"""
+    KC.case_conv_wgrad_patch(DEV, Bn, H, W, Ci, Co, stride=2)
+
+
 def test_conv_small_channels():
     KC.case_conv(DEV, 1, 64, 64, 8, 32)
 

@@ -8,7 +8,7 @@ mkdir -p gpurun_out
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 python tools/box_calib.py 2>&1 | grep BOX_CALIB | tee gpurun_out/r06_box_calib_$TAG.txt
-( time timeout 1800 python -m pytest tests -m gpu -q -s -p no:cacheprovider ) > gpurun_out/r06_gputest_$TAG.log 2>&1
+( time timeout 1800 python -m pytest tests -m gpu -q -s -p no:cacheprovider --durations=12 ) > gpurun_out/r06_gputest_$TAG.log 2>&1
 echo "pytest rc=$?" >> gpurun_out/r06_gputest_$TAG.log
 grep -E "passed|failed|rc=|^FAILED|^ERROR|NOTE " gpurun_out/r06_gputest_$TAG.log | cut -c1-300 | tail -8
 timeout 300 python __graft_entry__.py --smoke 2>&1 | tail -1 | tee gpurun_out/r06_smoke_$TAG.txt
