@@ -106,6 +106,7 @@ _PROTOS = {
     "clora_gemm_f16": [_P, _I, _P, _P, _I, _I, _I, _I, C.POINTER(ConvDesc), C.POINTER(Epilogue), _I, _P, _Z, _P],
     "clora_gemm_f16_ex": [_P, _I, _P, _P, _I, _I, _I, _I, C.POINTER(ConvDesc), C.POINTER(Epilogue), _I, _I, _P, _Z, _P],
     "clora_conv_patch_eligible": [_I, C.POINTER(ConvDesc), _I],
+    "clora_conv_strip_eligible": [_I, _I, C.POINTER(ConvDesc)],
     "clora_set_option": [C.c_char_p, _I],
     "clora_conv_wgrad_f16": [_P, _I, _P, _I, _P, _P, _I, _I, _I, C.POINTER(ConvDesc), _I, _P],
     "clora_conv_weight_pack_f32": [_P, _I, _I, _I, _I, _I, _P, _P, _P],
@@ -202,7 +203,7 @@ class Lib:
                     "CLORA_GN_BLOCKS": ("gn_blocks", None), "CLORA_EPI_TWO_PHASE": ("epi_two_phase", None),
                     "CLORA_LORA_DOWN_MODE": ("lora_down_mode", None), "CLORA_GN_UNROLL": ("gn_unroll", None),
                     "CLORA_EPI_HOIST": ("epi_hoist", None), "CLORA_GN_RESIDENT": ("gn_resident", None),
-                    "CLORA_DEFER_MAX_ROWS": ("defer_max_rows", None), "CLORA_WGRAD_PATCH": ("wgrad_patch", None)}
+                    "CLORA_DEFER_MAX_ROWS": ("defer_max_rows", None), "CLORA_WGRAD_PATCH": ("wgrad_patch", None), "CLORA_STRIP_BLOCKS": ("strip_blocks", None)}
 
     def _options_from_env(self):
         for var, (name, names) in self._ENV_OPTIONS.items():

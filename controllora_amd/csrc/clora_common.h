@@ -150,7 +150,7 @@ __device__ __forceinline__ float wave_max(float v) {
 // The library's ONLY process-global state: the tuning knobs of clora_set_option (include/clora.h), one int each, defined in
 // clora_gemm.hip.  Results never depend on them.  The library itself reads no environment variable: the host layer
 // (controllora_amd/capi.py) forwards CLORA_* variables through clora_set_option when it loads the library.
-enum { CLORA_OPT_TILE_ORDER = 0, CLORA_OPT_LN_ROWS, CLORA_OPT_ATTN_FWD_WAVES, CLORA_OPT_ATTN_BWD_WAVES, CLORA_OPT_GN_BLOCKS, CLORA_OPT_EPI_TWO_PHASE, CLORA_OPT_LORA_DOWN_MODE, CLORA_OPT_GN_UNROLL, CLORA_OPT_EPI_HOIST, CLORA_OPT_GN_RESIDENT, CLORA_OPT_DEFER_MAX_ROWS, CLORA_OPT_WGRAD_PATCH, CLORA_OPT_COUNT };
+enum { CLORA_OPT_TILE_ORDER = 0, CLORA_OPT_LN_ROWS, CLORA_OPT_ATTN_FWD_WAVES, CLORA_OPT_ATTN_BWD_WAVES, CLORA_OPT_GN_BLOCKS, CLORA_OPT_EPI_TWO_PHASE, CLORA_OPT_LORA_DOWN_MODE, CLORA_OPT_GN_UNROLL, CLORA_OPT_EPI_HOIST, CLORA_OPT_GN_RESIDENT, CLORA_OPT_DEFER_MAX_ROWS, CLORA_OPT_WGRAD_PATCH, CLORA_OPT_STRIP_BLOCKS, CLORA_OPT_COUNT };
 __attribute__((visibility("hidden"))) int clora_option(int id);
 // XCD assignment policy of the launches that follow ("tile_order"): 0 = launch-order defaults, 1 = n-major GEMM tiles (tests),
 // 2 = fewest distinct operand panels per XCD; non-zero also gives every XCD whole attention heads (clora_attn.hip attn_block_ids)

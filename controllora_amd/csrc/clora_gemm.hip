@@ -1670,6 +1670,170 @@ int launch_wgrad_patch(WgradPatchArgs& a, hipStream_t s) {
     return clora_check_launch();
 }
 
+// ------------------------------------------------------------------------------------------------
+// Forward / dgrad of the same large-map convolutions (tile_cfg 61, round 6): 3x3, stride 1, pad 1, CIN = 32 or 64 input channels, at
+// most 64 output channels, K order (tap, channel) (kchunk 0) -- the hint encoder's 512^2 / 256^2 convolutions and their dgrads.  The
+// implicit GEMM gathers every input pixel nine times through L2 -> LDS (600 MB for two 67 MB tensors at 512^2 x 32: 95 us); the
+// 64-channel-slab patch kernel cannot take 32 channels.  Same strip walk as conv_wgrad_patch_kernel: a block owns a TW-pixel column
+// strip, stages per output row the three input rows as a halo patch of 16-channel planes (double buffered LDS-DMA) and multiplies it
+// with the WHOLE weight operand, which lives in registers (9 taps x CIN/32 k-steps x N/16 fragments: 72-144 VGPRs, loaded once).
+// D = W . patch^T: rows = output channels, columns = pixels, so a lane holds four consecutive channels of one pixel (8-byte stores);
+// the B operand of pixel group mf / tap (ky, kx) / k-step ks is a ds_read_b128 at plane 2 ks + (g >> 1), pixel (ky' PW + kx' + 16 mf + li),
+// half g & 1 -- conflict free for the hardware's ds_read_b128 lane groups at this 32-byte pixel pitch.  Epilogue: bias only.
+struct StripArgs {
+    const half_t* X;
+    const half_t* Wt;        // [N][9 * CIN], column = tap * CIN + channel
+    half_t* C;
+    const float* bias;
+    int N, ldc, H, W, nimg, nseg, rows_per_block, row_chunks;
+    int off, kmul;           // input offset of tap k: off + k * kmul  (forward -1 / +1, dgrad +1 / -1)
+};
+
+template <int CIN, int NF, int TW>
+__global__ __launch_bounds__(256) void conv3x3_strip_kernel(StripArgs p) {
+    constexpr int WC = CIN / 16, NW = 4, KSTEPS = CIN / 32;
+    constexpr int PW = TW + 2, PPIX = 3 * PW;
+    constexpr int P_NI = (PPIX * 2 + 63) / 64, PLANE = P_NI * 512;
+    constexpr int BUF = WC * PLANE;
+    constexpr int NI = WC * P_NI, NIW = (NI + NW - 1) / NW;
+    constexpr int MF = TW / 16 / NW;                             // 16-pixel groups per wave
+    static_assert(MF >= 1 && (2 * BUF + 512) * 2 <= 160 * 1024, "strip geometry");
+    __shared__ __attribute__((aligned(16))) half_t smem[2 * BUF + 512];
+    const int t = threadIdx.x, w = t >> 6, l = t & 63, g = l >> 4, li = l & 15;
+    const half_t* zero_page = reinterpret_cast<const half_t*>(g_clora_zero16);
+
+    int bid = blockIdx.x;
+    const int rc = bid % p.row_chunks; bid /= p.row_chunks;
+    const int seg = bid % p.nseg, img = bid / p.nseg;
+    const int x0 = seg * TW, y_beg = rc * p.rows_per_block;
+    const int y_end = (y_beg + p.rows_per_block < p.H) ? y_beg + p.rows_per_block : p.H;
+
+    // ---- the weight operand: A fragments, lane (row n = li, k-group g) holds 8 consecutive channels of one tap
+    half8 wf[9][KSTEPS][NF];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks)
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+                const int n = f * 16 + li;
+                wf[tap][ks][f] = (n < p.N) ? ld8(p.Wt + (size_t)n * (9 * CIN) + tap * CIN + ks * 32 + g * 8) : zero8();
+            }
+    float bias[NF][4];
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = f * 16 + 4 * g + r;
+            bias[f][r] = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+        }
+
+    // ---- patch loader (conv_wgrad_patch_kernel's, stride 1)
+    int kind[NIW], soff[NIW], doff[NIW];
+#pragma unroll
+    for (int j = 0; j < NIW; ++j) {
+        const int i = w + NW * j;
+        kind[j] = -1; soff[j] = 0; doff[j] = 2 * BUF;
+        if (i < NI) {
+            const int pl = i / P_NI, pi = i - pl * P_NI;
+            const int c = pi * 64 + l, pp = c >> 1, h = c & 1;
+            doff[j] = pl * PLANE + pi * 512;
+            if (pp < PPIX) {
+                const int pr = pp / PW, pc = pp - pr * PW;
+                const int x = x0 - 1 + pc;
+                if (x >= 0 && x < p.W) { kind[j] = pr; soff[j] = ((pr - 1) * p.W + (pc - 1)) * CIN + pl * 16 + h * 8; }
+            }
+        }
+    }
+    auto issue_row = [&](int y, int buf) {
+        half_t* dst = smem + buf * BUF;
+        const bool live = y < y_end;
+        const size_t row = ((size_t)img * p.H + (live ? y : y_beg)) * p.W + x0;
+#pragma unroll
+        for (int j = 0; j < NIW; ++j) {
+            const half_t* src = zero_page;
+            if (live && kind[j] >= 0) {
+                const int yy = y - 1 + kind[j];
+                if (yy >= 0 && yy < p.H) src = p.X + (ptrdiff_t)row * CIN + soff[j];
+            }
+            half_t* d = (doff[j] == 2 * BUF) ? smem + 2 * BUF : dst + doff[j];
+            CLORA_GLDS16(src, d);
+        }
+    };
+
+    const int rd = (g >> 1) * PLANE + (g & 1) * 8;               // this lane's plane (of a 32-channel k-step) and half
+    issue_row(y_beg, 0);
+    for (int y = y_beg; y < y_end; ++y) {
+        const int buf = (y - y_beg) & 1;
+        issue_row(y + 1, buf ^ 1);
+        CLORA_WAIT_VMCNT(NIW);
+        CLORA_RAW_BARRIER();
+        const half_t* P = smem + buf * BUF + rd;
+        floatx4 acc[NF][MF];
+#pragma unroll
+        for (int f = 0; f < NF; ++f)
+#pragma unroll
+            for (int m = 0; m < MF; ++m) acc[f][m] = floatx4{bias[f][0], bias[f][1], bias[f][2], bias[f][3]};
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap - ky * 3;
+            const int pp0 = (1 + p.off + ky * p.kmul) * PW + (1 + p.off + kx * p.kmul) + (w * MF) * 16 + li;
+#pragma unroll
+            for (int ks = 0; ks < KSTEPS; ++ks) {
+                half8 bf[MF];
+#pragma unroll
+                for (int m = 0; m < MF; ++m) bf[m] = ld8(P + ks * 2 * PLANE + (pp0 + m * 16) * 16);
+#pragma unroll
+                for (int m = 0; m < MF; ++m)
+#pragma unroll
+                    for (int f = 0; f < NF; ++f) acc[f][m] = mfma16(wf[tap][ks][f], bf[m], acc[f][m]);
+            }
+        }
+        // rows of D = output channels 4 g + r of fragment f, column = pixel: four consecutive channels of one pixel per lane
+        const size_t orow = ((size_t)img * p.H + y) * p.W + x0 + (w * MF) * 16 + li;
+#pragma unroll
+        for (int m = 0; m < MF; ++m)
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+                const int n = f * 16 + 4 * g;
+                if (n < p.N) {
+                    half4v o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = (half_t)acc[f][m][r];
+                    st4(p.C + (orow + m * 16) * p.ldc + n, o);
+                }
+            }
+        CLORA_RAW_BARRIER();
+    }
+    CLORA_WAIT_VMCNT(0);
+}
+
+template <int CIN, int NF, int TW>
+int launch_strip(StripArgs& a, hipStream_t s) {
+    a.nseg = a.W / TW;
+    const long strips = (long)a.nimg * a.nseg;
+    const long target = clora_option(CLORA_OPT_STRIP_BLOCKS);    // blocks aimed at ("strip_blocks")
+    long rpb = ((long)a.H * strips + target - 1) / target;
+    if (rpb < 8) rpb = 8;                                        // (a block first loads the whole weight operand: at least eight rows of work;
+    if (rpb > a.H) rpb = a.H;                                    //  sweep on MI355X, profiles/r06_conv_strip_bench.txt: 512^2 34 us at 512 blocks
+    a.rows_per_block = (int)rpb;                                 //  against 48 / 39 / 45 at 256 / 1024 / 2048; 256^2 23 us at 8 rows against 29 at 4)
+    a.row_chunks = clora_cdiv(a.H, rpb);
+    hipLaunchKernelGGL((conv3x3_strip_kernel<CIN, NF, TW>), dim3((unsigned)(strips * a.row_chunks)), dim3(256), 0, s, a);
+    return clora_check_launch();
+}
+
+// which instantiation (CIN * 100 + NF) takes this convolution, or 0 (everything else stays on the implicit GEMM / patch kernels)
+int strip_plan(int M, int N, const clora_conv_t& c) {
+    if (!c.enabled || c.ksize != 3 || c.mul != 1 || c.shift != 0 || c.need_even != 0 || c.kchunk != 0) return 0;
+    if (!((c.kmul == 1 && c.off == -1) || (c.kmul == -1 && c.off == 1))) return 0;
+    if (c.Hout != c.Hin || c.Wout != c.Win || c.lim_h != c.Hin || c.lim_w != c.Win || c.Hout <= 0 || (c.Wout % 128)) return 0;
+    if ((M % (c.Hout * c.Wout)) || (long)M * 64 >= (1L << 31) || (N & 3)) return 0;
+    if (c.Cin == 32 && N <= 32) return 3202;
+    if (c.Cin == 32 && N <= 64) return 3204;
+    if (c.Cin == 64 && N <= 32) return 6402;
+    return 0;
+}
+
 // fp32 master weight [Co][Ci][ks][ks] of a trainable conv -> the two fp16 GEMM operands of this step in one launch:
 // fwd [Co][ks*ks][Cip] (gather order ky,kx,ci; channels zero-padded to Cip) and, optionally, dgrad [Cip][ks*ks][Cop].
 __global__ __launch_bounds__(256) void conv_weight_pack_kernel(const float* w, int Co, int Ci, int taps, int Cip, int Cop,
@@ -1706,7 +1870,7 @@ int conv_mode(const GemmArgs& a, int bk) {
 // panels of its range under either order.   "tile_order": 0 m-major always, 1 n-major always
 // (tests), 2 pick by the model, 3 (default since round 5: live PMC traffic 1.69x -> 1.59x of the algorithmic bytes, bit-identical
 // outputs) = 2 plus a per-XCD rectangle of tiles where whole divisors exist.
-int g_opts[CLORA_OPT_COUNT] = {3, 1, 0, 0, 512, 1, 1, 0, 1, 1, 4, 1};    // tile_order, ln_rows, attn_fwd_waves (0 = auto), attn_bwd_waves (0 = auto), gn_blocks, epi_two_phase, lora_down_mode, gn_unroll, epi_hoist, gn_resident, defer_max_rows, wgrad_patch
+int g_opts[CLORA_OPT_COUNT] = {3, 1, 0, 0, 512, 1, 1, 0, 1, 1, 4, 1, 512};    // tile_order, ln_rows, attn_fwd_waves (0 = auto), attn_bwd_waves (0 = auto), gn_blocks, epi_two_phase, lora_down_mode, gn_unroll, epi_hoist, gn_resident, defer_max_rows, wgrad_patch, strip_blocks
 int tile_order_mode() { return g_opts[CLORA_OPT_TILE_ORDER]; }
 
 double fabric_model_bytes(int tiles_m, int tiles_n, int splits, double a_panel, double b_panel, bool n_major) {
@@ -1916,6 +2080,22 @@ extern "C" int clora_gemm_f16_ex(const clora_half* A, int lda, const clora_half*
         split_k = 1;                                     // the fused activation lives in the main kernel's epilogue only
     }
     hipStream_t s = (hipStream_t)stream;
+    //   61 = conv3x3_strip_kernel (the hint encoder's large-map 3x3 convolutions and their dgrads: 32 / 64 input channels, <= 64 output
+    //        channels, kchunk 0, bias-only epilogue, C rows 8-byte aligned); anything it cannot take falls back to the library's own choice
+    if (tile_cfg == 61) {
+        const int plan = (a.conv.enabled && split_k <= 1 && !defer && !a.epi.rowadd && !a.epi.residual && !a.epi.lora_t && !a.epi.geglu &&
+                          !a.epi.ln_out && C && (ldc & 3) == 0 && K == 9 * a.conv.Cin)
+                             ? strip_plan(M, N, a.conv) : 0;
+        if (plan) {
+            StripArgs q;
+            q.X = a.A; q.Wt = a.B; q.C = a.C; q.bias = a.epi.bias; q.N = N; q.ldc = ldc; q.H = a.conv.Hout; q.W = a.conv.Wout;
+            q.nimg = M / (a.conv.Hout * a.conv.Wout); q.off = a.conv.off; q.kmul = a.conv.kmul;
+            if (plan == 3202) return launch_strip<32, 2, 128>(q, s);
+            if (plan == 3204) return launch_strip<32, 4, 128>(q, s);
+            return launch_strip<64, 2, 128>(q, s);
+        }
+        tile_cfg = 0;
+    }
     // split_k: 0 = automatic (bounded by the workspace the caller provided), >= 1 = forced
     int tile = 0, splits = 1;
     const int ws_cap = workspace ? (int)(workspace_bytes / ((size_t)M * N * sizeof(float))) : 1;
@@ -2096,7 +2276,7 @@ extern "C" int clora_set_option(const char* name, int value) {
                                 {"gn_blocks", CLORA_OPT_GN_BLOCKS, 64, 1 << 16}, {"epi_two_phase", CLORA_OPT_EPI_TWO_PHASE, 0, 1},
                                 {"lora_down_mode", CLORA_OPT_LORA_DOWN_MODE, 0, 2}, {"gn_unroll", CLORA_OPT_GN_UNROLL, 0, 1},
                                 {"epi_hoist", CLORA_OPT_EPI_HOIST, 0, 1}, {"gn_resident", CLORA_OPT_GN_RESIDENT, 0, 1},
-                                {"defer_max_rows", CLORA_OPT_DEFER_MAX_ROWS, 0, 16}, {"wgrad_patch", CLORA_OPT_WGRAD_PATCH, 0, 8192}};
+                                {"defer_max_rows", CLORA_OPT_DEFER_MAX_ROWS, 0, 16}, {"wgrad_patch", CLORA_OPT_WGRAD_PATCH, 0, 8192}, {"strip_blocks", CLORA_OPT_STRIP_BLOCKS, 64, 16384}};
     for (const Opt& o : kOpts)
         if (!strcmp(name, o.name)) {
             if (value < o.lo || value > o.hi) return CLORA_ERR_ARG;
@@ -2106,6 +2286,10 @@ extern "C" int clora_set_option(const char* name, int value) {
             return CLORA_OK;
         }
     return CLORA_ERR_ARG;
+}
+
+extern "C" int clora_conv_strip_eligible(int M, int N, const clora_conv_t* conv) {
+    return (conv && strip_plan(M, N, *conv)) ? 1 : 0;
 }
 
 extern "C" int clora_conv_patch_eligible(int M, const clora_conv_t* conv, int tile_cfg) {

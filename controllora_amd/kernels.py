@@ -140,6 +140,7 @@ def workspace(nbytes: int, device) -> torch.Tensor:
 
 
 _ws_retired = []
+CONV_STRIP = os.environ.get("CLORA_CONV_STRIP", "1") != "0"       # "0": the large-map hint-encoder convolutions stay on the implicit GEMM (A/B)
 WIDE_TILE_CFGS = (1, 4, 7, 8, 9, 21, 31, 41, 53, 56, 58, 59)      # tile_cfg values whose tiles are >= 128 columns wide (GEGLU-forward epilogue)
 GEMM_WS_BYTES = 256 << 20   # split-K slab budget handed to the library's launch planner
 
@@ -221,6 +222,9 @@ def gemm(A: torch.Tensor, Bw: torch.Tensor, M: int, N: int, K: int, *, lda: Opti
             assert lora_t_in.dtype == f32 and lora_t_in.stride(1) == 1
             e.lora_t_in, e.ldt_in, e.lora_t_in_rows, e.lora_t_in_mask = ptr(lora_t_in), lora_t_in.stride(0), int(lora_t_in_rows), int(lora_t_in_mask)
         split_k = 1
+    if (CONV_STRIP and conv is not None and split_k == 0 and tile_cfg == 0 and not geglu and rowadd is None and residual is None
+            and lora_t is None and not defer and ln is None and capi.lib().cdll.clora_conv_strip_eligible(M, N, C.byref(conv))):
+        tile_cfg, split_k = 61, 1            # the hint encoder's large-map 3x3 convolutions: strip kernel (include/clora.h)
     if _tuned and split_k == 0 and tile_cfg == 0:
         hit = globals()["_tuned"](M, N, K, conv)
         if hit is not None:

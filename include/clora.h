@@ -176,6 +176,14 @@ int clora_gemm_f16_ex(const clora_half* A, int lda, const clora_half* B, clora_h
  * reference op is the same F.conv2d of upstream ResnetBlock2D; tuner / tests use this to know what they time. */
 int clora_conv_patch_eligible(int M, const clora_conv_t* conv, int tile_cfg);
 
+/* 1 when clora_gemm_f16_ex(..., tile_cfg = 61) can run `conv` with N output columns on the strip kernel (round 6): 3x3, stride 1, pad 1
+ * or its dgrad, kchunk 0, 32 input channels and <= 64 output channels or 64 and <= 32, image rows a multiple of 128 pixels wide -- the
+ * hint encoder's 512^2 / 256^2 convolutions (reference models.py:470-543: F.conv2d of ConvBlock2D / SimpleDownEncoderBlock2D and its
+ * autograd dgrad); additionally the launch must be bias-only (no row add / residual / adapter / GEGLU / LayerNorm / split-K), else
+ * tile_cfg 61 falls back to the library's own choice.  A column strip of 128 pixels walks down the image: the three input rows are
+ * staged once per output row (not once per filter tap) and the whole weight operand stays in registers. */
+int clora_conv_strip_eligible(int M, int N, const clora_conv_t* conv);
+
 /* Tuning knobs, no reference counterpart: results never depend on them (bit-identical outputs, tests/test_kernels_*.py; the two
  * exceptions re-partition an fp32 sum: "lora_down_mode" (the sum over K) -- bit-identical per mode, equal to ~1e-7 relative across
  * modes, tests/test_kernels_gpu.py::test_lora_down_launch_modes -- and "gn_resident" (the GroupNorm statistics) -- bit-identical per
@@ -210,6 +218,13 @@ int clora_conv_patch_eligible(int M, const clora_conv_t* conv, int tile_cfg);
  *                     most this many rows (default 4: the 8x8 / 16x16 maps, where it is faster than finish + plain); above it -- and in
  *                     the LayerNorm backward unless the value is 16 -- the library runs the plain finish pass first.  0 = never fold.
  *                     Bit-identical results at every setting.
+ *   "wgrad_patch"     1 (default) = clora_conv_wgrad_f16 runs the large-map 3x3 convolutions with 32 or 64 input channels and at most 64
+ *                     output channels (stride 1 pad 1, and stride 2 with the zero row / column at the bottom / right: the hint encoder's
+ *                     512^2 / 256^2 / 128^2 stages; gather-ordered destination, oihw_ci == 0) on the patch-staged kernel: dY and the input
+ *                     rows are staged once per output row instead of once per 64-column k tile; 0 = always the gather kernel; >= 64 = as 1
+ *                     with that many blocks (A/B of the atomics volume).  fp32 atomics in both kernels: equal to ~1e-6 relative.
+ *   "strip_blocks"    number of blocks the strip convolution kernel (tile_cfg 61, clora_conv_strip_eligible) aims at (default 512,
+ *                     64 .. 16384): a block walks H * strips / blocks (at least 8) output rows of its column strip.
  * Unknown names / values: CLORA_ERR_ARG. */
 int clora_set_option(const char* name, int value);
 

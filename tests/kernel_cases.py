@@ -277,6 +277,47 @@ def case_conv_wgrad_patch(dev, Bn, H, W, Ci, Co, seed=21, stride=1):
     assert rel(dW2, want_w) < 1e-4
 
 
+def case_conv_strip(dev, Bn, H, W, Ci, Co, seed=22):
+    """Round 6 (conv3x3_strip_kernel, tile_cfg 61): forward (+ bias) and dgrad of a large-map 3x3 stride-1 pad-1 convolution with 32 / 64
+    channels (the hint encoder's 512^2 / 256^2 stages, reference models.py:470-543) through the default launch path -- kernels.gemm picks
+    the strip kernel where clora_conv_strip_eligible says so -- vs fp32 torch, and vs the implicit GEMM it replaces there."""
+    import ctypes
+    from controllora_amd import capi
+    g = torch.Generator().manual_seed(seed)
+    x = rnd((Bn, Ci, H, W), dev, g)
+    w = rnd((Co, Ci, 3, 3), dev, g, 1 / math.sqrt(9 * Ci))
+    bias = rnd((Co,), dev, g, dtype=f32)
+    xin = x.float().clone().requires_grad_(True)
+    y = F.conv2d(xin, w.float(), bias.float(), padding=1)
+    dy = rnd((Bn, Co, H, W), dev, g)
+    y.backward(dy.float())
+    xn = x.permute(0, 2, 3, 1).contiguous().reshape(-1, Ci)
+    wp = w.permute(0, 2, 3, 1).contiguous().reshape(Co, 9 * Ci)
+    cd, _, _ = K.conv_fwd_desc(H, W, Ci, 3, 1, 1)
+    M = Bn * H * W
+    lib = capi.lib().cdll
+    assert lib.clora_conv_strip_eligible(M, Co, ctypes.byref(cd)) == 1
+    out = K.gemm(xn, wp, M, Co, 9 * Ci, conv=cd, bias=bias)
+    want = y.detach().permute(0, 2, 3, 1).reshape(M, Co)
+    assert rel(out, want) < 6e-4, rel(out, want)
+    no_outliers(out, want, "conv_strip fwd")
+    ref = K.gemm(xn, wp, M, Co, 9 * Ci, conv=cd, bias=bias, tile_cfg=2, split_k=1)         # the implicit GEMM on the same operands
+    assert rel(out, ref) < 3e-4
+    assert torch.equal(out, K.gemm(xn, wp, M, Co, 9 * Ci, conv=cd, bias=bias))             # bit-stable
+    wd = w.permute(1, 2, 3, 0).contiguous().reshape(Ci, 9 * Co)
+    dyn = dy.permute(0, 2, 3, 1).contiguous().reshape(-1, Co)
+    cdd = K.conv_dgrad_desc(H, W, Co, H, W, 3, 1, 1)
+    wantd = xin.grad.permute(0, 2, 3, 1).reshape(-1, Ci)
+    if lib.clora_conv_strip_eligible(M, Ci, ctypes.byref(cdd)) == 1:
+        dx = K.gemm(dyn, wd, M, Ci, 9 * Co, conv=cdd)
+        assert rel(dx, wantd) < 6e-4, rel(dx, wantd)
+        no_outliers(dx, wantd, "conv_strip dgrad")
+    # a launch the strip kernel cannot take (residual in the epilogue) falls back to the library's own choice under tile_cfg 61
+    res = rnd((M, Co), dev, g)
+    fb = K.gemm(xn, wp, M, Co, 9 * Ci, conv=cd, bias=bias, residual=res, tile_cfg=61, split_k=1)
+    assert rel(fb, want.float().cpu() + res.float().cpu()) < 6e-4
+
+
 def case_conv_patch_upsampled(dev, Bn, H, W, Ci, Co, tile_cfg, seed=13):
     """conv3x3_patch_kernel on conv(nearest-2x(x)) (Upsample2D): the patch lives at the output resolution"""
     from controllora_amd.ops import conv_k_order

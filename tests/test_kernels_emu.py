@@ -40,6 +40,11 @@ def test_conv_wgrad_patch_kernel_stride2(Bn, H, W, Ci, Co):
     KC.case_conv_wgrad_patch("cpu", Bn, H, W, Ci, Co, stride=2)
 
 
+@pytest.mark.parametrize("Bn,H,W,Ci,Co", [(1, 3, 128, 32, 32), (2, 2, 128, 32, 64), (1, 2, 128, 64, 32), (1, 5, 256, 32, 24)])
+def test_conv_strip_kernel(Bn, H, W, Ci, Co):
+    KC.case_conv_strip("cpu", Bn, H, W, Ci, Co)
+
+
 def test_conv_small_channels():
     KC.case_conv("cpu", 1, 16, 16, 8, 32)       # hint-encoder conv_in shape class (3 -> padded 8 channels)
 

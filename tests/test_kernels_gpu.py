@@ -51,6 +51,11 @@ def test_conv_wgrad_patch_kernel_stride2(Bn, H, W, Ci, Co):
     KC.case_conv_wgrad_patch(DEV, Bn, H, W, Ci, Co, stride=2)
 
 
+@pytest.mark.parametrize("Bn,H,W,Ci,Co", [(4, 512, 512, 32, 32), (4, 256, 256, 32, 64), (2, 37, 384, 64, 32), (1, 5, 128, 32, 24)])
+def test_conv_strip_kernel(Bn, H, W, Ci, Co):
+    KC.case_conv_strip(DEV, Bn, H, W, Ci, Co)
+
+
 def test_conv_small_channels():
     KC.case_conv(DEV, 1, 64, 64, 8, 32)
 
