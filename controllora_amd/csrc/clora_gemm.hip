@@ -1808,6 +1808,120 @@ __global__ __launch_bounds__(256) void conv3x3_strip_kernel(StripArgs p) {
     CLORA_WAIT_VMCNT(0);
 }
 
+// The 8-channel case (the hint encoder's conv_in: 3 image channels zero-padded to 8, 16 bytes per pixel; 85 us on the implicit GEMM at
+// 512^2 for a 16 MB input and a 67 MB output): K = 9 taps x 8 channels = 72 = three MFMA k-steps of FOUR taps each (the last one holds
+// tap 8 and three zero taps).  Lane group g of k-step ks owns tap 4 ks + g: the B operand is one ds_read_b128 at THAT tap's patch offset
+// (a per-lane constant), the A operand the matching 8 weights (zero for taps >= 9).  One 8-channel plane, one DMA chunk per pixel.
+template <int NF, int TW>
+__global__ __launch_bounds__(256) void conv3x3_strip8_kernel(StripArgs p) {
+    constexpr int NW = 4, CIN = 8, KT = 3;
+    constexpr int PW = TW + 2, PPIX = 3 * PW;
+    constexpr int P_NI = (PPIX + 63) / 64, BUF = P_NI * 512;     // 64 pixels (chunks of 16 bytes) per DMA wave-instruction
+    constexpr int NIW = (P_NI + NW - 1) / NW;
+    constexpr int MF = TW / 16 / NW;
+    __shared__ __attribute__((aligned(16))) half_t smem[2 * BUF + 512];
+    const int t = threadIdx.x, w = t >> 6, l = t & 63, g = l >> 4, li = l & 15;
+    const half_t* zero_page = reinterpret_cast<const half_t*>(g_clora_zero16);
+
+    int bid = blockIdx.x;
+    const int rc = bid % p.row_chunks; bid /= p.row_chunks;
+    const int seg = bid % p.nseg, img = bid / p.nseg;
+    const int x0 = seg * TW, y_beg = rc * p.rows_per_block;
+    const int y_end = (y_beg + p.rows_per_block < p.H) ? y_beg + p.rows_per_block : p.H;
+
+    half8 wf[KT][NF];
+    int toff[KT];                                                // patch offset (pixels) of this lane group's tap in k-step ks
+#pragma unroll
+    for (int ks = 0; ks < KT; ++ks) {
+        const int tap = ks * 4 + g;
+        const int ky = tap / 3, kx = tap - ky * 3;
+        toff[ks] = tap < 9 ? (1 + p.off + ky * p.kmul) * PW + (1 + p.off + kx * p.kmul) : 0;
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+            const int n = f * 16 + li;
+            wf[ks][f] = (tap < 9 && n < p.N) ? ld8(p.Wt + (size_t)n * (9 * CIN) + tap * CIN) : zero8();
+        }
+    }
+    float bias[NF][4];
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = f * 16 + 4 * g + r;
+            bias[f][r] = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+        }
+
+    int kind[NIW], soff[NIW], doff[NIW];
+#pragma unroll
+    for (int j = 0; j < NIW; ++j) {
+        const int i = w + NW * j;
+        kind[j] = -1; soff[j] = 0; doff[j] = 2 * BUF;
+        if (i < P_NI) {
+            const int pp = i * 64 + l;
+            doff[j] = i * 512;
+            if (pp < PPIX) {
+                const int pr = pp / PW, pc = pp - pr * PW;
+                const int x = x0 - 1 + pc;
+                if (x >= 0 && x < p.W) { kind[j] = pr; soff[j] = ((pr - 1) * p.W + (pc - 1)) * CIN; }
+            }
+        }
+    }
+    auto issue_row = [&](int y, int buf) {
+        half_t* dst = smem + buf * BUF;
+        const bool live = y < y_end;
+        const size_t row = ((size_t)img * p.H + (live ? y : y_beg)) * p.W + x0;
+#pragma unroll
+        for (int j = 0; j < NIW; ++j) {
+            const half_t* src = zero_page;
+            if (live && kind[j] >= 0) {
+                const int yy = y - 1 + kind[j];
+                if (yy >= 0 && yy < p.H) src = p.X + (ptrdiff_t)row * CIN + soff[j];
+            }
+            half_t* d = (doff[j] == 2 * BUF) ? smem + 2 * BUF : dst + doff[j];
+            CLORA_GLDS16(src, d);
+        }
+    };
+
+    issue_row(y_beg, 0);
+    for (int y = y_beg; y < y_end; ++y) {
+        const int buf = (y - y_beg) & 1;
+        issue_row(y + 1, buf ^ 1);
+        CLORA_WAIT_VMCNT(NIW);
+        CLORA_RAW_BARRIER();
+        const half_t* P = smem + buf * BUF;
+        floatx4 acc[NF][MF];
+#pragma unroll
+        for (int f = 0; f < NF; ++f)
+#pragma unroll
+            for (int m = 0; m < MF; ++m) acc[f][m] = floatx4{bias[f][0], bias[f][1], bias[f][2], bias[f][3]};
+#pragma unroll
+        for (int ks = 0; ks < KT; ++ks) {
+            half8 bf[MF];
+#pragma unroll
+            for (int m = 0; m < MF; ++m) bf[m] = ld8(P + (toff[ks] + (w * MF + m) * 16 + li) * CIN);
+#pragma unroll
+            for (int m = 0; m < MF; ++m)
+#pragma unroll
+                for (int f = 0; f < NF; ++f) acc[f][m] = mfma16(wf[ks][f], bf[m], acc[f][m]);
+        }
+        const size_t orow = ((size_t)img * p.H + y) * p.W + x0 + (w * MF) * 16 + li;
+#pragma unroll
+        for (int m = 0; m < MF; ++m)
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+                const int n = f * 16 + 4 * g;
+                if (n < p.N) {
+                    half4v o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = (half_t)acc[f][m][r];
+                    st4(p.C + (orow + m * 16) * p.ldc + n, o);
+                }
+            }
+        CLORA_RAW_BARRIER();
+    }
+    CLORA_WAIT_VMCNT(0);
+}
+
 template <int CIN, int NF, int TW>
 int launch_strip(StripArgs& a, hipStream_t s) {
     a.nseg = a.W / TW;
@@ -1822,12 +1936,28 @@ int launch_strip(StripArgs& a, hipStream_t s) {
     return clora_check_launch();
 }
 
+template <int NF, int TW>
+int launch_strip8(StripArgs& a, hipStream_t s) {
+    a.nseg = a.W / TW;
+    const long strips = (long)a.nimg * a.nseg;
+    const long target = clora_option(CLORA_OPT_STRIP_BLOCKS);
+    long rpb = ((long)a.H * strips + target - 1) / target;
+    if (rpb < 8) rpb = 8;
+    if (rpb > a.H) rpb = a.H;
+    a.rows_per_block = (int)rpb;
+    a.row_chunks = clora_cdiv(a.H, rpb);
+    hipLaunchKernelGGL((conv3x3_strip8_kernel<NF, TW>), dim3((unsigned)(strips * a.row_chunks)), dim3(256), 0, s, a);
+    return clora_check_launch();
+}
+
 // which instantiation (CIN * 100 + NF) takes this convolution, or 0 (everything else stays on the implicit GEMM / patch kernels)
 int strip_plan(int M, int N, const clora_conv_t& c) {
     if (!c.enabled || c.ksize != 3 || c.mul != 1 || c.shift != 0 || c.need_even != 0 || c.kchunk != 0) return 0;
     if (!((c.kmul == 1 && c.off == -1) || (c.kmul == -1 && c.off == 1))) return 0;
     if (c.Hout != c.Hin || c.Wout != c.Win || c.lim_h != c.Hin || c.lim_w != c.Win || c.Hout <= 0 || (c.Wout % 128)) return 0;
     if ((M % (c.Hout * c.Wout)) || (long)M * 64 >= (1L << 31) || (N & 3)) return 0;
+    if (c.Cin == 8 && N <= 32) return 802;
+    if (c.Cin == 8 && N <= 64) return 804;
     if (c.Cin == 32 && N <= 32) return 3202;
     if (c.Cin == 32 && N <= 64) return 3204;
     if (c.Cin == 64 && N <= 32) return 6402;
@@ -2090,6 +2220,8 @@ extern "C" int clora_gemm_f16_ex(const clora_half* A, int lda, const clora_half*
             StripArgs q;
             q.X = a.A; q.Wt = a.B; q.C = a.C; q.bias = a.epi.bias; q.N = N; q.ldc = ldc; q.H = a.conv.Hout; q.W = a.conv.Wout;
             q.nimg = M / (a.conv.Hout * a.conv.Wout); q.off = a.conv.off; q.kmul = a.conv.kmul;
+            if (plan == 802) return launch_strip8<2, 128>(q, s);
+            if (plan == 804) return launch_strip8<4, 128>(q, s);
             if (plan == 3202) return launch_strip<32, 2, 128>(q, s);
             if (plan == 3204) return launch_strip<32, 4, 128>(q, s);
             return launch_strip<64, 2, 128>(q, s);

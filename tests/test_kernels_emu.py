@@ -40,7 +40,7 @@ def test_conv_wgrad_patch_kernel_stride2(Bn, H, W, Ci, Co):
     KC.case_conv_wgrad_patch("cpu", Bn, H, W, Ci, Co, stride=2)
 
 
-@pytest.mark.parametrize("Bn,H,W,Ci,Co", [(1, 3, 128, 32, 32), (2, 2, 128, 32, 64), (1, 2, 128, 64, 32), (1, 5, 256, 32, 24)])
+@pytest.mark.parametrize("Bn,H,W,Ci,Co", [(1, 3, 128, 32, 32), (2, 2, 128, 32, 64), (1, 2, 128, 64, 32), (1, 5, 256, 32, 24), (2, 3, 128, 8, 32), (1, 2, 128, 8, 48)])
 def test_conv_strip_kernel(Bn, H, W, Ci, Co):
     KC.case_conv_strip("cpu", Bn, H, W, Ci, Co)
 

@@ -51,7 +51,7 @@ def test_conv_wgrad_patch_kernel_stride2(Bn, H, W, Ci, Co):
     KC.case_conv_wgrad_patch(DEV, Bn, H, W, Ci, Co, stride=2)
 
 
-@pytest.mark.parametrize("Bn,H,W,Ci,Co", [(4, 512, 512, 32, 32), (4, 256, 256, 32, 64), (2, 37, 384, 64, 32), (1, 5, 128, 32, 24)])
+@pytest.mark.parametrize("Bn,H,W,Ci,Co", [(4, 512, 512, 32, 32), (4, 256, 256, 32, 64), (2, 37, 384, 64, 32), (1, 5, 128, 32, 24), (4, 512, 512, 8, 32), (1, 6, 256, 8, 64)])
 def test_conv_strip_kernel(Bn, H, W, Ci, Co):
     KC.case_conv_strip(DEV, Bn, H, W, Ci, Co)
 

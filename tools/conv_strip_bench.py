@@ -18,7 +18,7 @@ def timeit(fn, iters=10, warm=2):
         best = min(best, e0.elapsed_time(e1) / iters * 1e3)
     return best
 B = 4
-for H, Ci, Co, what in [(512, 32, 32, "fwd / dgrad 32->32"), (256, 32, 64, "fwd 32->64"), (256, 64, 32, "dgrad of 32->64")]:
+for H, Ci, Co, what in [(512, 8, 32, "conv_in fwd 3(8)->32"), (512, 32, 32, "fwd / dgrad 32->32"), (256, 32, 64, "fwd 32->64"), (256, 64, 32, "dgrad of 32->64")]:
     M = B * H * H
     x = torch.randn(M, Ci, device=dev).half()
     w = (torch.randn(Co, 9 * Ci, device=dev) / (9 * Ci) ** 0.5).half()
