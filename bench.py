@@ -731,6 +731,8 @@ def main():
                               "spread_pct": round((max(window_ms) - min(window_ms)) / min(window_ms) * 100, 2)},
             "calibration": calib,
             "loss": round(loss, 5), "steps_skipped_by_scaler": skipped,
+            # in-launch exchanges of the one-launch GroupNorm kernels that gave up (include/clora.h clora_groupnorm_*_team): must be 0
+            "gn_team_errors": K.gn_team_errors(dev),
             "roofline": roofline, "ddim50": ddim, "full_step_with_vae_clip": full, "cpu_baseline": cpu}))
     trainer.close()
     if world > 1:

@@ -16,7 +16,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CLORA_LIB_PATH") or os.path.join(_HERE, "_build", "libclora.so")   # override: A/B of kernel builds
 
-ABI_VERSION = 3                          # CLORA_ABI_VERSION of include/clora.h
+ABI_VERSION = 4                          # CLORA_ABI_VERSION of include/clora.h
 OK, ERR_ARG, ERR_LAUNCH, ERR_WORKSPACE = 0, -1, -2, -3
 _ERR = {ERR_ARG: "bad argument", ERR_LAUNCH: "kernel launch failed", ERR_WORKSPACE: "workspace too small"}
 
@@ -120,6 +120,8 @@ _PROTOS = {
     "clora_groupnorm_bwd_f16": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _Z, _P],
     "clora_groupnorm_fwd_f16_ex": [_P, _P, _I, C.POINTER(Deferred), _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P, _Z, _P],
     "clora_groupnorm_bwd_f16_ex": [_P, _P, C.POINTER(Deferred), _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _Z, _P],
+    "clora_groupnorm_fwd_f16_team": [_P, _P, _I, C.POINTER(Deferred), _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P, _Z, _P, _Z, _P],
+    "clora_groupnorm_bwd_f16_team": [_P, _P, C.POINTER(Deferred), _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _Z, _P, _Z, _P],
     "clora_layernorm_bwd_f16_ex": [_P, _P, C.POINTER(Deferred), _P, _P, _P, _I, _I, _F, _P],
     "clora_finish_deferred": [C.POINTER(Deferred), _P],
     "clora_gemm_ln_fusable": [_I, _I, _I, _I, _I],
@@ -162,6 +164,7 @@ _PROTOS = {
     "clora_abi_version": [],
     "clora_clock_probe": [_P, _I, _I, _P],
     "clora_groupnorm_workspace_bytes": [_I, _I, _I, _I, _I, _I],
+    "clora_groupnorm_team_state_bytes": [],
     "clora_lora_wgrad_workspace_bytes": [_I, _I, _I],
     "clora_rank_gram_ws_bytes": [_I, _I],
 }
@@ -192,6 +195,7 @@ class Lib:
             fn.restype = C.c_int
         self.cdll.clora_build_info.restype = C.c_char_p
         self.cdll.clora_groupnorm_workspace_bytes.restype = C.c_size_t
+        self.cdll.clora_groupnorm_team_state_bytes.restype = C.c_size_t
         self.cdll.clora_lora_wgrad_workspace_bytes.restype = C.c_size_t
         self.cdll.clora_rank_gram_ws_bytes.restype = C.c_size_t
         self._options_from_env()
@@ -203,7 +207,8 @@ class Lib:
                     "CLORA_GN_BLOCKS": ("gn_blocks", None), "CLORA_EPI_TWO_PHASE": ("epi_two_phase", None),
                     "CLORA_LORA_DOWN_MODE": ("lora_down_mode", None), "CLORA_GN_UNROLL": ("gn_unroll", None),
                     "CLORA_EPI_HOIST": ("epi_hoist", None), "CLORA_GN_RESIDENT": ("gn_resident", None),
-                    "CLORA_DEFER_MAX_ROWS": ("defer_max_rows", None), "CLORA_WGRAD_PATCH": ("wgrad_patch", None), "CLORA_STRIP_BLOCKS": ("strip_blocks", None)}
+                    "CLORA_DEFER_MAX_ROWS": ("defer_max_rows", None), "CLORA_WGRAD_PATCH": ("wgrad_patch", None), "CLORA_STRIP_BLOCKS": ("strip_blocks", None),
+                    "CLORA_GN_TEAM": ("gn_team", None)}
 
     def _options_from_env(self):
         for var, (name, names) in self._ENV_OPTIONS.items():

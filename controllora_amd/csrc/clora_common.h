@@ -78,6 +78,18 @@ __device__ __forceinline__ half4v clora_ds_read_tr16(const half_t* lptr) {
 #define CLORA_WAIT_LGKMCNT(n) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(n) : "memory")
 #define CLORA_SETPRIO(n) __builtin_amdgcn_s_setprio(n)
 #define CLORA_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
+// words that workgroups of ONE launch exchange (GroupNorm team kernels, clora_norm.hip): relaxed agent-scope accesses = sc1 global
+// loads / write-through stores (bypass the per-CU L1; cdna_hip_programming.md Guideline 16 form R2: the datum carries its own tag)
+typedef __attribute__((address_space(1))) unsigned long long clora_gu64;
+typedef __attribute__((address_space(1))) unsigned clora_gu32;
+#define CLORA_LD_AGENT_U64(p) __hip_atomic_load((clora_gu64*)(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define CLORA_ST_AGENT_U64(p, v) __hip_atomic_store((clora_gu64*)(p), (unsigned long long)(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define CLORA_LD_AGENT_U32(p) __hip_atomic_load((clora_gu32*)(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define CLORA_ST_AGENT_U32(p, v) __hip_atomic_store((clora_gu32*)(p), (unsigned)(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define CLORA_SLEEP() __builtin_amdgcn_s_sleep(1)
+#endif
+#ifndef CLORA_SEQUENTIAL_BLOCKS
+#define CLORA_SEQUENTIAL_BLOCKS 0
 #endif
 
 __device__ __forceinline__ floatx4 mfma16(half8 a, half8 b, floatx4 c) {
@@ -150,7 +162,7 @@ __device__ __forceinline__ float wave_max(float v) {
 // The library's ONLY process-global state: the tuning knobs of clora_set_option (include/clora.h), one int each, defined in
 // clora_gemm.hip.  Results never depend on them.  The library itself reads no environment variable: the host layer
 // (controllora_amd/capi.py) forwards CLORA_* variables through clora_set_option when it loads the library.
-enum { CLORA_OPT_TILE_ORDER = 0, CLORA_OPT_LN_ROWS, CLORA_OPT_ATTN_FWD_WAVES, CLORA_OPT_ATTN_BWD_WAVES, CLORA_OPT_GN_BLOCKS, CLORA_OPT_EPI_TWO_PHASE, CLORA_OPT_LORA_DOWN_MODE, CLORA_OPT_GN_UNROLL, CLORA_OPT_EPI_HOIST, CLORA_OPT_GN_RESIDENT, CLORA_OPT_DEFER_MAX_ROWS, CLORA_OPT_WGRAD_PATCH, CLORA_OPT_STRIP_BLOCKS, CLORA_OPT_COUNT };
+enum { CLORA_OPT_TILE_ORDER = 0, CLORA_OPT_LN_ROWS, CLORA_OPT_ATTN_FWD_WAVES, CLORA_OPT_ATTN_BWD_WAVES, CLORA_OPT_GN_BLOCKS, CLORA_OPT_EPI_TWO_PHASE, CLORA_OPT_LORA_DOWN_MODE, CLORA_OPT_GN_UNROLL, CLORA_OPT_EPI_HOIST, CLORA_OPT_GN_RESIDENT, CLORA_OPT_DEFER_MAX_ROWS, CLORA_OPT_WGRAD_PATCH, CLORA_OPT_STRIP_BLOCKS, CLORA_OPT_GN_TEAM, CLORA_OPT_COUNT };
 __attribute__((visibility("hidden"))) int clora_option(int id);
 // XCD assignment policy of the launches that follow ("tile_order"): 0 = launch-order defaults, 1 = n-major GEMM tiles (tests),
 // 2 = fewest distinct operand panels per XCD; non-zero also gives every XCD whole attention heads (clora_attn.hip attn_block_ids)

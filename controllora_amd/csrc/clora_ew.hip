@@ -395,7 +395,7 @@ extern "C" int clora_clock_probe(unsigned long long* out, int blocks, int iters,
     hipLaunchKernelGGL(clock_probe_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, out, iters);
     return clora_check_launch();
 }
-extern "C" int clora_abi_version(void) { return CLORA_ABI_VERSION; }   // include/clora.h (3: clora_epilogue_t.defer, round 6)
+extern "C" int clora_abi_version(void) { return CLORA_ABI_VERSION; }   // include/clora.h (3: clora_epilogue_t.defer; 4: clora_groupnorm_*_team, round 6)
 extern "C" const char* clora_build_info(void) { return "libclora gfx950 (v_mfma_f32_16x16x32_f16), ABI 2"; }
 
 // ------------------------------------------------------------------------------------------------

@@ -2000,7 +2000,7 @@ int conv_mode(const GemmArgs& a, int bk) {
 // panels of its range under either order.   "tile_order": 0 m-major always, 1 n-major always
 // (tests), 2 pick by the model, 3 (default since round 5: live PMC traffic 1.69x -> 1.59x of the algorithmic bytes, bit-identical
 // outputs) = 2 plus a per-XCD rectangle of tiles where whole divisors exist.
-int g_opts[CLORA_OPT_COUNT] = {3, 1, 0, 0, 512, 1, 1, 0, 1, 1, 4, 1, 512};    // tile_order, ln_rows, attn_fwd_waves (0 = auto), attn_bwd_waves (0 = auto), gn_blocks, epi_two_phase, lora_down_mode, gn_unroll, epi_hoist, gn_resident, defer_max_rows, wgrad_patch, strip_blocks
+int g_opts[CLORA_OPT_COUNT] = {3, 1, 0, 0, 512, 1, 1, 0, 1, 1, 4, 1, 512, 2};    // tile_order, ln_rows, attn_fwd_waves (0 = auto), attn_bwd_waves (0 = auto), gn_blocks, epi_two_phase, lora_down_mode, gn_unroll, epi_hoist, gn_resident, defer_max_rows, wgrad_patch, strip_blocks, gn_team
 int tile_order_mode() { return g_opts[CLORA_OPT_TILE_ORDER]; }
 
 double fabric_model_bytes(int tiles_m, int tiles_n, int splits, double a_panel, double b_panel, bool n_major) {
@@ -2408,7 +2408,8 @@ extern "C" int clora_set_option(const char* name, int value) {
                                 {"gn_blocks", CLORA_OPT_GN_BLOCKS, 64, 1 << 16}, {"epi_two_phase", CLORA_OPT_EPI_TWO_PHASE, 0, 1},
                                 {"lora_down_mode", CLORA_OPT_LORA_DOWN_MODE, 0, 2}, {"gn_unroll", CLORA_OPT_GN_UNROLL, 0, 1},
                                 {"epi_hoist", CLORA_OPT_EPI_HOIST, 0, 1}, {"gn_resident", CLORA_OPT_GN_RESIDENT, 0, 1},
-                                {"defer_max_rows", CLORA_OPT_DEFER_MAX_ROWS, 0, 16}, {"wgrad_patch", CLORA_OPT_WGRAD_PATCH, 0, 8192}, {"strip_blocks", CLORA_OPT_STRIP_BLOCKS, 64, 16384}};
+                                {"defer_max_rows", CLORA_OPT_DEFER_MAX_ROWS, 0, 16}, {"wgrad_patch", CLORA_OPT_WGRAD_PATCH, 0, 8192}, {"strip_blocks", CLORA_OPT_STRIP_BLOCKS, 64, 16384},
+                                {"gn_team", CLORA_OPT_GN_TEAM, 0, 2}};
     for (const Opt& o : kOpts)
         if (!strcmp(name, o.name)) {
             if (value < o.lo || value > o.hi) return CLORA_ERR_ARG;

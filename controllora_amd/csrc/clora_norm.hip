@@ -45,7 +45,18 @@ struct GnArgs {
     const float* fin_partial;   // deferred split-K producer of x (fwd) / dy (bwd): slabs [fin_splits][B*HW][C] + its epilogue
     int fin_splits;
     clora_epilogue_t fin_epi;
+    // team kernels (one launch for the 64x64 / 32x32 maps): the caller's persistent exchange state (clora_groupnorm_team_state_bytes)
+    unsigned long long* tm_gran;   // [kTeamUnits][kTeamMembers][kTeamGran] 8-byte {epoch, fp32 bits} granules
+    unsigned* tm_gen;              // [kTeamUnits] epoch of the last completed exchange of a unit
+    unsigned* tm_err;              // sticky: an exchange gave up (a member never published)
+    int tm_nb, tm_rpb;             // members per unit, rows per member
+    int tm_probe;                  // emulator only (blocks run one after the other): publish, do not gather
+    unsigned tm_spin;
 };
+
+constexpr int kTeamUnits = 32, kTeamMembers = 256, kTeamGran = 64, kTeamBlocks = 256, kTeamNT = 512;
+constexpr size_t kTeamHeader = 4096;                     // bytes: error word at 0, generation words at 256
+constexpr size_t kTeamStateBytes = kTeamHeader + (size_t)kTeamUnits * kTeamMembers * kTeamGran * 8;
 
 // where a thread's 8-channel chunk (first channel ch0, a multiple of 8; Ca % 8 == 0) of the input lives: base pointer at row 0 of batch
 // element 0 and the row pitch in halves -- one tensor, or the two halves of a channel concatenation
@@ -660,6 +671,226 @@ __global__ __launch_bounds__(NT) void gn_bwd_resident_kernel(GnArgs p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------ GroupNorm in ONE launch, large maps
+// The 64x64 / 32x32 maps do not fit one block per (batch element, slab), and the two-launch scheme reads x twice and pays two ramp-ups
+// (7.4 + 12.0 us forward, 10.7 + 12.7 us backward per 64x64x320 map inside the train step).  Here a TEAM of tm_nb blocks shares a
+// (batch element, slab) UNIT, every member keeps its rows in registers (the resident kernels' thread map), and the members exchange
+// their per-group partial sums INSIDE the launch: 2 * gps fp32 values per member, each published as one 8-byte {epoch, value} granule
+// by a relaxed agent-scope (write-through, sc1) store and swept by every member with sc1 loads until all tags carry the epoch
+// (cdna_hip_programming.md Guideline 16, form R2: the datum is its own flag -- no fence, no L2 write-back, placement independent).
+// The epoch of a unit is its generation word + 1, read by every member BEFORE it publishes and advanced by the unit's last member
+// AFTER it has seen every member's granules (so after every member has read it): tags of a slot only ever grow, nothing is zeroed
+// between launches and nothing depends on a per-launch argument (graph replay freezes those).  The members are folded in a fixed
+// order: results are deterministic.  256 blocks of 512 threads = one per CU must be co-resident (checked by the planner against the
+// device's CU count); the sweep is bounded and a give-up is recorded in the state's error word (clora_groupnorm_team_errors).
+template <int NT>
+__device__ __forceinline__ bool gn_team_exchange(const GnArgs& p, int u, int m, unsigned epoch, int GK, float* vals, float* gat, float scale) {
+    const int t = threadIdx.x;
+    unsigned long long* ubase = p.tm_gran + (size_t)u * kTeamMembers * kTeamGran;
+    if (t < GK) CLORA_ST_AGENT_U64(ubase + (size_t)m * kTeamGran + t, ((unsigned long long)epoch << 32) | __float_as_uint(vals[t]));
+    if (p.tm_probe) return false;
+    const int P = NT / GK, gk = t % GK, pi = t / GK;
+    float acc = 0.f;
+    bool fail = false;
+    if (pi < P) {
+        unsigned long long x[8];
+        unsigned spins = 0;
+        for (;;) {
+            bool ok = true;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int mm = pi + k * P;
+                x[k] = 0;
+                if (mm < p.tm_nb) {
+                    x[k] = CLORA_LD_AGENT_U64(ubase + (size_t)mm * kTeamGran + gk);
+                    ok = ok && (unsigned)(x[k] >> 32) == epoch;
+                }
+            }
+            if (ok) break;
+            if (++spins > p.tm_spin) { fail = true; break; }
+            CLORA_SLEEP();
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (pi + k * P < p.tm_nb) acc += __uint_as_float((unsigned)x[k]);
+    }
+    gat[t] = acc;
+    if (fail) atomicOr(p.tm_err, 1u);
+    __syncthreads();
+    if (t < GK) {
+        float sacc = 0.f;
+        for (int pp = 0; pp < P; ++pp) sacc += gat[pp * GK + t];
+        vals[t] = sacc * scale;
+    }
+    __syncthreads();
+    if (m == p.tm_nb - 1 && t == 0) CLORA_ST_AGENT_U32(p.tm_gen + u, epoch);
+    return true;
+}
+
+template <int NT, int NPT>
+__global__ __launch_bounds__(NT) void gn_fwd_team_kernel(GnArgs p) {
+    __shared__ float red[NT * 16];
+    __shared__ float chs[NT * 2];
+    __shared__ float mr[64 * 2];
+    __shared__ float gat[NT];
+    __shared__ unsigned s_epoch;
+    const int t = threadIdx.x;
+    const int U = p.B * p.nslab, u = blockIdx.x % U, m = blockIdx.x / U;
+    const int b = u / p.nslab, cb = (u - b * p.nslab) * p.CS;
+    if (t == 0) s_epoch = CLORA_LD_AGENT_U32(p.tm_gen + u) + 1u;
+    const int CH = p.CS / 8, cpg = p.C / p.G, gps = p.G / p.nslab;
+    const int nrl = NT / CH, rl = t / CH, c0 = t - rl * CH;
+    const bool active = rl < nrl;
+    const int r0 = m * p.tm_rpb;
+    const int r_end = (r0 + p.tm_rpb < p.HW) ? r0 + p.tm_rpb : p.HW;
+    const GnCol col = gn_in_col(p, cb + (active ? c0 : 0) * 8);
+    const size_t brow = (size_t)b * p.HW;
+    const floatx4* gp = reinterpret_cast<const floatx4*>(p.gamma + cb + (active ? c0 : 0) * 8);
+    const floatx4* bp = reinterpret_cast<const floatx4*>(p.beta + cb + (active ? c0 : 0) * 8);
+    const floatx4 ga = gp[0], gb = gp[1], ba = bp[0], bb = bp[1];
+    half8 v[NPT];
+    float s[8], q[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
+    if (active) {
+#pragma unroll
+        for (int k = 0; k < NPT; ++k) {
+            const int r = r0 + rl + k * nrl;
+            v[k] = ld8(col.p + (brow + (size_t)(r < r_end ? r : (r0 < p.HW ? r0 : 0))) * col.pitch);
+        }
+#pragma unroll
+        for (int k = 0; k < NPT; ++k) {
+            const bool ok = r0 + rl + k * nrl < r_end;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float f = ok ? (float)v[k][e] : 0.f; s[e] += f; q[e] += f * f; }
+        }
+    }
+    gn_res_reduce<NT>(red, chs, s, q, t, p.CS, cpg, gps, rl, nrl, c0, active, nullptr, mr, 1.0f);
+    if (!gn_team_exchange<NT>(p, u, m, s_epoch, gps * 2, mr, gat, 1.0f / ((float)p.HW * (float)cpg))) return;
+    if (t < gps) {                                               // (E[x], E[x^2]) -> (mean, rstd)
+        const float mean = mr[t * 2];
+        float var = mr[t * 2 + 1] - mean * mean;
+        var = var < 0.f ? 0.f : var;
+        const float rstd = rsqrtf(var + p.eps);
+        mr[t * 2 + 1] = rstd;
+        if (m == 0) {
+            float* st = p.stats + ((size_t)b * p.G + (cb / cpg) + t) * 2;
+            st[0] = mean; st[1] = rstd;
+        }
+    }
+    __syncthreads();
+    if (!active) return;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int cl = c0 * 8 + e, g = cl / cpg;
+        sc[e] = mr[g * 2 + 1] * (e < 4 ? ga[e & 3] : gb[e & 3]);
+        sh[e] = (e < 4 ? ba[e & 3] : bb[e & 3]) - mr[g * 2] * sc[e];
+    }
+    half_t* ybase = p.y + (size_t)b * p.HW * p.C + cb + c0 * 8;
+#pragma unroll
+    for (int k = 0; k < NPT; ++k) {
+        const int r = r0 + rl + k * nrl;
+        half8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float yv = (float)v[k][e] * sc[e] + sh[e];
+            if (p.fuse_silu) yv = silu_f(yv);
+            o[e] = (half_t)yv;
+        }
+        if (r < r_end) {
+            st8(ybase + (size_t)r * p.C, o);
+            if (p.xcopy) st8(p.xcopy + (size_t)b * p.HW * p.C + cb + c0 * 8 + (size_t)r * p.C, v[k]);
+        }
+    }
+}
+
+template <int NT, int NPT>
+__global__ __launch_bounds__(NT) void gn_bwd_team_kernel(GnArgs p) {
+    __shared__ float red[NT * 16];
+    __shared__ float chs[NT * 2];
+    __shared__ float gs[64 * 2];
+    __shared__ float gat[NT];
+    __shared__ unsigned s_epoch;
+    const int t = threadIdx.x;
+    const int U = p.B * p.nslab, u = blockIdx.x % U, m = blockIdx.x / U;
+    const int b = u / p.nslab, cb = (u - b * p.nslab) * p.CS;
+    if (t == 0) s_epoch = CLORA_LD_AGENT_U32(p.tm_gen + u) + 1u;
+    const int CH = p.CS / 8, cpg = p.C / p.G, gps = p.G / p.nslab;
+    const int nrl = NT / CH, rl = t / CH, c0 = t - rl * CH;
+    const bool active = rl < nrl;
+    const int r0 = m * p.tm_rpb;
+    const int r_end = (r0 + p.tm_rpb < p.HW) ? r0 + p.tm_rpb : p.HW;
+    const size_t boff = (size_t)b * p.HW * p.C + cb + (active ? c0 : 0) * 8;
+    float mean[8], rstd[8], sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int ch = cb + (active ? c0 : 0) * 8 + e;
+        const float* st = p.stats + ((size_t)b * p.G + ch / cpg) * 2;
+        mean[e] = st[0]; rstd[e] = st[1];
+        sc[e] = rstd[e] * p.gamma[ch];
+        sh[e] = p.beta[ch] - mean[e] * sc[e];
+    }
+    half8 xv[NPT], gv[NPT];
+    float a1[8], a2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { a1[e] = 0.f; a2[e] = 0.f; }
+    if (active) {
+#pragma unroll
+        for (int k = 0; k < NPT; ++k) {
+            const int r = r0 + rl + k * nrl;
+            const size_t off = boff + (size_t)(r < r_end ? r : (r0 < p.HW ? r0 : 0)) * p.C;
+            xv[k] = ld8(p.x + off);
+            gv[k] = ld8(p.dy + off);
+        }
+#pragma unroll
+        for (int k = 0; k < NPT; ++k) {
+            const bool ok = r0 + rl + k * nrl < r_end;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float xf = (float)xv[k][e];
+                const float xh = (xf - mean[e]) * rstd[e];
+                float d = ok ? (float)gv[k][e] : 0.f;
+                if (p.fuse_silu) d *= dsilu_f(xf * sc[e] + sh[e]);
+                a1[e] += d;
+                a2[e] += d * xh;
+            }
+        }
+    }
+    gn_res_reduce<NT>(red, chs, a1, a2, t, p.CS, cpg, gps, rl, nrl, c0, active, p.gamma + cb, gs, 1.0f);
+    if (!gn_team_exchange<NT>(p, u, m, s_epoch, gps * 2, gs, gat, 1.0f / ((float)p.HW * (float)cpg))) return;
+    if (!active) return;
+    float k2[8], k3[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int g = (c0 * 8 + e) / cpg;
+        k2[e] = -rstd[e] * rstd[e] * gs[g * 2 + 1];
+        k3[e] = -k2[e] * mean[e] - rstd[e] * gs[g * 2];
+    }
+    const bool has_res = p.dres != nullptr;
+    const GnColW dxc = gn_dx_col(p, cb + c0 * 8);
+#pragma unroll
+    for (int k = 0; k < NPT; ++k) {
+        const int r = r0 + rl + k * nrl;
+        if (!(r < r_end)) continue;
+        const size_t off = boff + (size_t)r * p.C;
+        half8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float xf = (float)xv[k][e];
+            float d = (float)gv[k][e];
+            if (p.fuse_silu) d *= dsilu_f(xf * sc[e] + sh[e]);
+            o[e] = (half_t)(sc[e] * d + k2[e] * xf + k3[e]);
+        }
+        if (has_res) {
+            const half8 rv = ld8(p.dres + off);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (half_t)((float)o[e] + (float)rv[e]);
+        }
+        st8(dxc.p + ((size_t)b * p.HW + r) * dxc.pitch, o);
+    }
+}
+
 // ------------------------------------------------------------------------------------------ LayerNorm
 struct LnArgs {
     const half_t* x;
@@ -1012,6 +1243,61 @@ GnResident gn_resident_plan(GnArgs& a, bool bwd, bool params) {
     return none;
 }
 
+// Team variant (gn_*_team_kernel): how many slabs, members and rows per thread, or 0.  The unit count B * nslab must divide the 256
+// blocks of the launch; slabs are whole groups, 8-channel aligned, at most 512 channels (one reduction thread per channel); among the
+// feasible splits the one with the most slabs whose row segments are still >= 320 bytes (fewest granules to gather), else the fewest.
+int gn_team_plan(GnArgs& a, bool bwd, bool params, void* state, size_t state_bytes) {
+    if (!state || state_bytes < kTeamStateBytes || params || !clora_option(CLORA_OPT_GN_TEAM) || a.HW < 1024) return 0;
+    static int cus = -1;
+    if (cus < 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
+        cus = n;
+    }
+    if (cus < kTeamBlocks) return 0;                         // one block per CU must be resident: the members wait for each other
+    const int cpg = a.C / a.G;
+    int unit = 1;
+    while ((unit * cpg) & 7) ++unit;
+    if (a.G % unit) return 0;
+    const int nunits = a.G / unit;
+    int pick = 0, pick_npt = 0;
+    for (int d = 1; d <= nunits; ++d) {
+        if (nunits % d) continue;
+        const int U = a.B * d;
+        if (U > kTeamUnits || (kTeamBlocks % U)) continue;
+        const int NB = kTeamBlocks / U, CS = a.C / d, CH = CS / 8, gps = a.G / d, GK = 2 * gps;
+        if (NB < 2 || CS > kTeamNT || GK > kTeamGran || gps * 8 > kTeamNT) continue;
+        if (NB > 8 * (kTeamNT / GK)) continue;             // the sweep holds at most 8 granules per thread
+        const int nrl = kTeamNT / CH, rpb = clora_cdiv(a.HW, NB), npt = clora_cdiv(rpb, nrl);
+        if (npt > (bwd ? 8 : 16)) continue;               // backward: x and dy in registers (16 rows of both spill at 256 VGPRs)
+        if (!pick || CS >= 160) { pick = d; pick_npt = npt; }
+        if (CS < 160) break;
+    }
+    if (!pick) return 0;
+    a.nslab = pick; a.CS = a.C / pick; a.nchunk = 1; a.rows_per_chunk = a.HW;
+    a.tm_nb = kTeamBlocks / (a.B * pick); a.tm_rpb = clora_cdiv(a.HW, a.tm_nb);
+    a.tm_err = (unsigned*)state; a.tm_gen = (unsigned*)((char*)state + 256);
+    a.tm_gran = (unsigned long long*)((char*)state + kTeamHeader);
+    a.tm_spin = 1u << 16; a.tm_probe = 0;
+    return pick_npt <= 4 ? 4 : (pick_npt <= 8 ? 8 : 16);
+}
+
+template <bool BWD>
+void gn_team_launch(GnArgs& a, int npt, hipStream_t s) {
+    const dim3 grid(kTeamBlocks), block(kTeamNT);
+    for (int pass = CLORA_SEQUENTIAL_BLOCKS ? 0 : 1; pass < 2; ++pass) {
+        a.tm_probe = pass == 0;
+        if (BWD) {
+            if (npt == 4) hipLaunchKernelGGL((gn_bwd_team_kernel<kTeamNT, 4>), grid, block, 0, s, a);
+            else hipLaunchKernelGGL((gn_bwd_team_kernel<kTeamNT, 8>), grid, block, 0, s, a);
+        } else {
+            if (npt == 4) hipLaunchKernelGGL((gn_fwd_team_kernel<kTeamNT, 4>), grid, block, 0, s, a);
+            else if (npt == 8) hipLaunchKernelGGL((gn_fwd_team_kernel<kTeamNT, 8>), grid, block, 0, s, a);
+            else hipLaunchKernelGGL((gn_fwd_team_kernel<kTeamNT, 16>), grid, block, 0, s, a);
+        }
+    }
+}
+
 int ew_blocks(size_t n) {
     size_t b = (n + 255) / 256;
     return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
@@ -1036,9 +1322,11 @@ bool deferred_fits(const clora_deferred_t* d, int M, int C) {
 }
 }  // namespace
 
-extern "C" int clora_groupnorm_fwd_f16_ex(const clora_half* x, const clora_half* x2, int Ca, const clora_deferred_t* src, clora_half* xcopy,
-                                          clora_half* y, const float* gamma, const float* beta, float* stats, int B, int HW, int C,
-                                          int G, float eps, int fuse_silu, void* workspace, size_t workspace_bytes, void* stream) {
+namespace {
+int gn_fwd_impl(const clora_half* x, const clora_half* x2, int Ca, const clora_deferred_t* src, clora_half* xcopy,
+                clora_half* y, const float* gamma, const float* beta, float* stats, int B, int HW, int C,
+                int G, float eps, int fuse_silu, void* team_state, size_t team_state_bytes, void* workspace, size_t workspace_bytes,
+                void* stream) {
     if (!y || !gamma || !beta || !stats) return CLORA_ERR_ARG;
     if (B <= 0 || HW <= 0 || C <= 0 || G <= 0 || G > 64 || (C % G) || (C & 7) || C > 4096) return CLORA_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
@@ -1061,6 +1349,14 @@ extern "C" int clora_groupnorm_fwd_f16_ex(const clora_half* x, const clora_half*
     if (deferred && !deferred_here) {                            // finish first, then the plain passes over src->C
         const int rc = clora_finish_deferred(src, stream);
         if (rc != CLORA_OK) return rc;
+    }
+    if (!deferred_here && (!res.nt || (clora_option(CLORA_OPT_GN_TEAM) >= 2 && HW >= 1024))) {   // large maps: one launch, a team per unit
+        GnArgs ta = a;
+        const int npt = gn_team_plan(ta, false, false, team_state, team_state_bytes);
+        if (npt) {
+            gn_team_launch<false>(ta, npt, s);
+            return clora_check_launch();
+        }
     }
     if (res.nt) {
         const dim3 rgrid(1, a.nslab, B);
@@ -1097,6 +1393,23 @@ extern "C" int clora_groupnorm_fwd_f16_ex(const clora_half* x, const clora_half*
     }
     return clora_check_launch();
 }
+}  // namespace
+
+extern "C" size_t clora_groupnorm_team_state_bytes(void) { return kTeamStateBytes; }
+
+extern "C" int clora_groupnorm_fwd_f16_ex(const clora_half* x, const clora_half* x2, int Ca, const clora_deferred_t* src, clora_half* xcopy,
+                                          clora_half* y, const float* gamma, const float* beta, float* stats, int B, int HW, int C,
+                                          int G, float eps, int fuse_silu, void* workspace, size_t workspace_bytes, void* stream) {
+    return gn_fwd_impl(x, x2, Ca, src, xcopy, y, gamma, beta, stats, B, HW, C, G, eps, fuse_silu, nullptr, 0, workspace, workspace_bytes, stream);
+}
+
+extern "C" int clora_groupnorm_fwd_f16_team(const clora_half* x, const clora_half* x2, int Ca, const clora_deferred_t* src, clora_half* xcopy,
+                                            clora_half* y, const float* gamma, const float* beta, float* stats, int B, int HW, int C,
+                                            int G, float eps, int fuse_silu, void* team_state, size_t team_state_bytes, void* workspace,
+                                            size_t workspace_bytes, void* stream) {
+    return gn_fwd_impl(x, x2, Ca, src, xcopy, y, gamma, beta, stats, B, HW, C, G, eps, fuse_silu, team_state, team_state_bytes, workspace,
+                       workspace_bytes, stream);
+}
 
 extern "C" int clora_groupnorm_fwd_f16(const clora_half* x, clora_half* y, const float* gamma, const float* beta,
                                        float* stats, int B, int HW, int C, int G, float eps, int fuse_silu,
@@ -1105,10 +1418,11 @@ extern "C" int clora_groupnorm_fwd_f16(const clora_half* x, clora_half* y, const
                                       workspace_bytes, stream);
 }
 
-extern "C" int clora_groupnorm_bwd_f16_ex(const clora_half* x, const clora_half* dy, const clora_deferred_t* dy_src, const clora_half* dres,
-                                          clora_half* dx, clora_half* dx2, int Ca, const float* gamma, const float* beta,
-                                          const float* stats, float* dgamma, float* dbeta, int B, int HW, int C, int G, int fuse_silu,
-                                          int accumulate_params, void* workspace, size_t workspace_bytes, void* stream) {
+namespace {
+int gn_bwd_impl(const clora_half* x, const clora_half* dy, const clora_deferred_t* dy_src, const clora_half* dres,
+                clora_half* dx, clora_half* dx2, int Ca, const float* gamma, const float* beta,
+                const float* stats, float* dgamma, float* dbeta, int B, int HW, int C, int G, int fuse_silu,
+                int accumulate_params, void* team_state, size_t team_state_bytes, void* workspace, size_t workspace_bytes, void* stream) {
     if (!x || !dx || !gamma || !beta || !stats || ((dgamma == nullptr) != (dbeta == nullptr))) return CLORA_ERR_ARG;
     if (B <= 0 || HW <= 0 || C <= 0 || G <= 0 || G > 64 || (C % G) || (C & 7) || C > 4096) return CLORA_ERR_ARG;
     if (dx2 && (Ca <= 0 || Ca >= C || (Ca & 7))) return CLORA_ERR_ARG;
@@ -1129,6 +1443,14 @@ extern "C" int clora_groupnorm_bwd_f16_ex(const clora_half* x, const clora_half*
     if (deferred && !deferred_here) {
         const int rc = clora_finish_deferred(dy_src, stream);
         if (rc != CLORA_OK) return rc;
+    }
+    if (!deferred_here && (!res.nt || (clora_option(CLORA_OPT_GN_TEAM) >= 2 && HW >= 1024))) {
+        GnArgs ta = a;
+        const int npt = gn_team_plan(ta, true, dgamma != nullptr, team_state, team_state_bytes);
+        if (npt) {
+            gn_team_launch<true>(ta, npt, s);
+            return clora_check_launch();
+        }
     }
     if (res.nt) {
         const dim3 rgrid(1, a.nslab, B);
@@ -1157,6 +1479,24 @@ extern "C" int clora_groupnorm_bwd_f16_ex(const clora_half* x, const clora_half*
     else if (clora_option(CLORA_OPT_GN_UNROLL)) hipLaunchKernelGGL((gn_bwd_apply2_kernel<1, 2>), grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL(gn_bwd_apply2_kernel<1>, grid, dim3(256), 0, s, a);
     return clora_check_launch();
+}
+}  // namespace
+
+extern "C" int clora_groupnorm_bwd_f16_ex(const clora_half* x, const clora_half* dy, const clora_deferred_t* dy_src, const clora_half* dres,
+                                          clora_half* dx, clora_half* dx2, int Ca, const float* gamma, const float* beta,
+                                          const float* stats, float* dgamma, float* dbeta, int B, int HW, int C, int G, int fuse_silu,
+                                          int accumulate_params, void* workspace, size_t workspace_bytes, void* stream) {
+    return gn_bwd_impl(x, dy, dy_src, dres, dx, dx2, Ca, gamma, beta, stats, dgamma, dbeta, B, HW, C, G, fuse_silu, accumulate_params, nullptr, 0,
+                       workspace, workspace_bytes, stream);
+}
+
+extern "C" int clora_groupnorm_bwd_f16_team(const clora_half* x, const clora_half* dy, const clora_deferred_t* dy_src, const clora_half* dres,
+                                            clora_half* dx, clora_half* dx2, int Ca, const float* gamma, const float* beta,
+                                            const float* stats, float* dgamma, float* dbeta, int B, int HW, int C, int G, int fuse_silu,
+                                            int accumulate_params, void* team_state, size_t team_state_bytes, void* workspace,
+                                            size_t workspace_bytes, void* stream) {
+    return gn_bwd_impl(x, dy, dy_src, dres, dx, dx2, Ca, gamma, beta, stats, dgamma, dbeta, B, HW, C, G, fuse_silu, accumulate_params, team_state,
+                       team_state_bytes, workspace, workspace_bytes, stream);
 }
 
 extern "C" int clora_groupnorm_bwd_f16(const clora_half* x, const clora_half* dy, const clora_half* dres, clora_half* dx, const float* gamma,

@@ -411,6 +411,34 @@ def attn_bwd(q, k, v, o, dO, lse, B, H, Nq, Nk, D, scale, dq, dk, dv):
 
 
 # ------------------------------------------------------------------ norms
+_gn_team = {}
+
+
+def _dev_key(device) -> str:
+    d = torch.device(device)
+    if d.type == "cuda" and d.index is None:
+        d = torch.device("cuda", torch.cuda.current_device())
+    return str(d)
+
+
+def gn_team_state(device) -> torch.Tensor:
+    """the persistent exchange state of the one-launch GroupNorm of the large maps (clora_groupnorm_*_team, include/clora.h): one per
+    device (= per stream here), zeroed once, never freed (captured graphs hold its address).  Word 0 is the kernels' sticky error flag
+    (gn_team_errors)."""
+    key = _dev_key(device)
+    st = _gn_team.get(key)
+    if st is None:
+        st = torch.zeros(capi.lib().cdll.clora_groupnorm_team_state_bytes(), dtype=torch.uint8, device=device)
+        _gn_team[key] = st
+    return st
+
+
+def gn_team_errors(device) -> int:
+    """non-zero if an in-launch exchange of a team GroupNorm kernel ever gave up on this device (its output was invalid)"""
+    st = _gn_team.get(_dev_key(device))
+    return 0 if st is None else int(st[:4].view(torch.int32).item())
+
+
 def _gn_ws(B, HW, Cc, G, device, bwd, params):
     n = capi.lib().cdll.clora_groupnorm_workspace_bytes(B, HW, Cc, G, int(bwd), int(params))
     if n == 0:
@@ -432,9 +460,10 @@ def groupnorm_fwd(x, gamma, beta, G, eps, silu, x2=None):
         capi.lib().call("clora_finish_deferred", C.byref(src), capi.stream())
         src = None
     ws = _gn_ws(B, HW, Cc, G, x.device, False, False)
-    _call("clora_groupnorm_fwd_f16_ex", ptr(x, f16), ptr(x2, f16) if x2 is not None else None, Ca if x2 is not None else 0,
+    team = gn_team_state(x.device)
+    _call("clora_groupnorm_fwd_f16_team", ptr(x, f16), ptr(x2, f16) if x2 is not None else None, Ca if x2 is not None else 0,
           C.byref(src) if src is not None else None, ptr(xcat) if xcat is not None else None, ptr(y), ptr(gamma, f32), ptr(beta, f32),
-          ptr(stats), B, HW, Cc, G, float(eps), int(silu), ptr(ws), ws.numel())
+          ptr(stats), B, HW, Cc, G, float(eps), int(silu), ptr(team), team.numel(), ptr(ws), ws.numel())
     return (y, stats, xcat) if x2 is not None else (y, stats)
 
 
@@ -459,11 +488,12 @@ def groupnorm_bwd(x, dy, gamma, beta, stats, G, silu, want_param_grads=False, gr
         db = torch.empty(Cc, dtype=f32, device=x.device)
     ws = _gn_ws(B, HW, Cc, G, x.device, True, want_param_grads)
     assert dres is None or (dres.shape == x.shape and dres.is_contiguous())
-    _call("clora_groupnorm_bwd_f16_ex", ptr(x, f16), ptr(dy, f16), C.byref(dy_src) if dy_src is not None else None,
+    team = gn_team_state(x.device)
+    _call("clora_groupnorm_bwd_f16_team", ptr(x, f16), ptr(dy, f16), C.byref(dy_src) if dy_src is not None else None,
           ptr(dres, f16) if dres is not None else None, ptr(dx), ptr(dx2) if dx2 is not None else None, int(split_at),
           ptr(gamma, f32), ptr(beta, f32), ptr(stats, f32),
           ptr(dg, f32) if dg is not None else None, ptr(db, f32) if db is not None else None, B, HW, Cc, G, int(silu),
-          int(grads_into is not None), ptr(ws), ws.numel())
+          int(grads_into is not None), ptr(team), team.numel(), ptr(ws), ws.numel())
     if split_at:
         dx = (dx, dx2)
     return (dx, None, None) if grads_into is not None else (dx, dg, db)

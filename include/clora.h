@@ -214,6 +214,10 @@ int clora_conv_strip_eligible(int M, int N, const clora_conv_t* conv);
  *   "gn_resident"     1 = GroupNorm passes whose (batch element, channel slab) fits in a block's registers run as ONE launch (statistics
  *                     and apply from the same registers: the 8x8 / 16x16 / 32x32 feature maps of the UNet); 0 = always the two-launch
  *                     partial + apply scheme.  Frozen affine only; same arithmetic, a different (still fixed) summation order.
+ *   "gn_team"         the one-launch GroupNorm of the large maps (clora_groupnorm_*_team, needs the caller's team state): 2 (default) =
+ *                     wherever the team plan applies (HW >= 1024); 1 = only where the two-launch scheme would run otherwise (the
+ *                     one-block-per-slab kernels of "gn_resident" keep the 32x32 forward); 0 = never.  Same arithmetic, a different
+ *                     (fixed) summation order.  Same-box A/B of the train step: 21.79 / 21.58 / 21.49 ms at 0 / 1 / 2.
  *   "defer_max_rows"  a deferred split-K GEMM (clora_deferred_t) is folded inside the one-launch GroupNorm kernels whose threads own at
  *                     most this many rows (default 4: the 8x8 / 16x16 maps, where it is faster than finish + plain); above it -- and in
  *                     the LayerNorm backward unless the value is 16 -- the library runs the plain finish pass first.  0 = never fold.
@@ -323,6 +327,26 @@ int clora_groupnorm_bwd_f16_ex(const clora_half* x, const clora_half* dy, const 
                                clora_half* dx, clora_half* dx2, int Ca, const float* gamma, const float* beta, const float* stats,
                                float* dgamma, float* dbeta, int B, int HW, int C, int G, int fuse_silu, int accumulate_params,
                                void* workspace, size_t workspace_bytes, void* stream);
+
+/* ABI 4 -- the same two calls with a TEAM STATE: a caller-owned device buffer of clora_groupnorm_team_state_bytes() bytes, zeroed ONCE
+ * when it is allocated and then handed unchanged to every call on ONE stream (calls that may run concurrently need separate states).
+ * With it the 64x64 / 32x32 maps of the UNet (HW >= 1024, frozen affine: dgamma == NULL; B * slabs dividing 256, see gn_team_plan)
+ * run as ONE launch instead of statistics + apply: 256 workgroups, one per compute unit, each keeping its rows in registers; the
+ * workgroups that share a (batch element, channel slab) exchange their partial group sums through the state inside the launch
+ * (8-byte {epoch, value} words, write-through stores and L1-bypassing loads; no fences, nothing to zero between launches, safe
+ * under hipGraph replay).  Shapes the plan does not take, a NULL / short state, a device with fewer than 256 compute units or
+ * option "gn_team" = 0 fall through to the `_ex` behaviour.  Results are deterministic (members folded in a fixed order) and equal
+ * the two-launch results up to the order of the fp32 sums.  The first 32-bit word of the state is a sticky error flag: non-zero
+ * after a launch whose exchange gave up (a member was not resident within the bounded wait) -- its output is then invalid. */
+size_t clora_groupnorm_team_state_bytes(void);
+int clora_groupnorm_fwd_f16_team(const clora_half* x, const clora_half* x2, int Ca, const clora_deferred_t* src, clora_half* xcopy,
+                                 clora_half* y, const float* gamma, const float* beta, float* stats, int B, int HW, int C, int G,
+                                 float eps, int fuse_silu, void* team_state, size_t team_state_bytes, void* workspace,
+                                 size_t workspace_bytes, void* stream);
+int clora_groupnorm_bwd_f16_team(const clora_half* x, const clora_half* dy, const clora_deferred_t* dy_src, const clora_half* dres,
+                                 clora_half* dx, clora_half* dx2, int Ca, const float* gamma, const float* beta, const float* stats,
+                                 float* dgamma, float* dbeta, int B, int HW, int C, int G, int fuse_silu, int accumulate_params,
+                                 void* team_state, size_t team_state_bytes, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- row softmax  y[r,:] = softmax(scale * x[r,:])  (fp32 max/sum; cols % 8 == 0, cols <= 8192, scale > 0; in place
  * allowed).  Normalises the materialised scores of the VAE's single-head d=512 attention (upstream AutoencoderKL
@@ -496,7 +520,7 @@ int clora_clock_probe(unsigned long long* out, int blocks, int iters, void* stre
 
 /* library info: clora_abi_version() changes whenever a struct of this header changes layout (2: round 4's clora_epilogue_t /
  * clora_lora_down_job_t fields; 3: round 6's clora_epilogue_t.defer); a host built against another version must refuse the library */
-#define CLORA_ABI_VERSION 3
+#define CLORA_ABI_VERSION 4
 int clora_abi_version(void);
 const char* clora_build_info(void);
 

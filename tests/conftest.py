@@ -34,3 +34,15 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture(autouse=True)
+def _no_groupnorm_team_exchange_gave_up(request):
+    """every GPU test: the one-launch GroupNorm kernels exchange partial sums between workgroups inside a launch with a bounded wait;
+    a wait that gave up leaves a sticky flag in the caller-owned state (controllora_amd.kernels.gn_team_errors) -- never, in any test"""
+    yield
+    if "gpu" in request.keywords:
+        import torch
+        from controllora_amd import kernels as K
+        for d in range(torch.cuda.device_count()):
+            assert K.gn_team_errors(f"cuda:{d}") == 0, "a GroupNorm team kernel's in-launch exchange gave up"

@@ -121,12 +121,24 @@ static inline hipemu_half4 hipemu_tr16(const void* p) {
 #define CLORA_WAIT_LGKMCNT(n) ((void)0)
 #define CLORA_SETPRIO(n) ((void)0)
 #define CLORA_SCHED_BARRIER() ((void)0)
+#define CLORA_LD_AGENT_U64(p) (*(const volatile unsigned long long*)(p))
+#define CLORA_ST_AGENT_U64(p, v) (*(volatile unsigned long long*)(p) = (unsigned long long)(v))
+#define CLORA_LD_AGENT_U32(p) (*(const volatile unsigned*)(p))
+#define CLORA_ST_AGENT_U32(p, v) (*(volatile unsigned*)(p) = (unsigned)(v))
+#define CLORA_SLEEP() ((void)0)
+// the emulator runs the blocks of a grid one after the other: kernels whose blocks wait for each other (GroupNorm team kernels) are
+// launched twice by their host code, the first time publish-only
+#define CLORA_SEQUENTIAL_BLOCKS 1
+enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 0 };
+static inline int hipGetDevice(int* d) { *d = 0; return 0; }
+static inline int hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int) { *v = 256; return 0; }
 static inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }
 static inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v; return o; }
 static inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
 static inline unsigned atomicMax(unsigned* p, unsigned v) { unsigned o = *p; if (v > o) *p = v; return o; }
 static inline unsigned atomicOr(unsigned* p, unsigned v) { unsigned o = *p; *p = o | v; return o; }
 static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
+static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
 static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 static inline float __frcp_rn(float x) { return 1.0f / x; }
 

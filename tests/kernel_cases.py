@@ -566,6 +566,19 @@ def case_groupnorm(dev, B, HW, C, G, silu, eps=1e-5, seed=4, train_params=False)
         assert rel(out, out0) < 2e-4 and rel(stats, stats0) < 1e-5 and rel(dx2, dx0) < 3e-4
         out1, stats1 = K.groupnorm_fwd(x, gamma, beta, G, eps, silu)             # bit-stable
         assert torch.equal(out1, out) and torch.equal(stats1, stats)
+        # the team kernels of the large maps (one launch, in-launch exchange of the partial sums) against the scheme they replace;
+        # repeated calls walk the exchange epochs of the persistent state: bit-stable, and no exchange ever gave up
+        K.set_option("gn_team", 0)
+        try:
+            out_t0, stats_t0 = K.groupnorm_fwd(x, gamma, beta, G, eps, silu)
+            dx_t0, _, _ = K.groupnorm_bwd(x, dy, gamma, beta, stats_t0, G, silu, dres=dres)
+        finally:
+            K.set_option("gn_team", int(os.environ.get("CLORA_GN_TEAM", "2")))
+        assert rel(out, out_t0) < 2e-4 and rel(stats, stats_t0) < 1e-5 and rel(dx2, dx_t0) < 3e-4
+        for _ in range(2):
+            dx3, _, _ = K.groupnorm_bwd(x, dy, gamma, beta, stats, G, silu, dres=dres)
+            assert torch.equal(dx3, dx2)
+        assert K.gn_team_errors(x.device) == 0
 
 
 def case_groupnorm_concat(dev, B, HW, Ca, Cb, G, silu, eps=1e-5, seed=11):

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     assert len(syms) >= 25
     missing = [s for s in syms if not hasattr(cdll, s)]
     assert not missing, missing
-    assert cdll.clora_abi_version() == 3
+    assert cdll.clora_abi_version() == 4
 
 
 def test_binding_covers_the_header():

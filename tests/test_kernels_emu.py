@@ -235,7 +235,9 @@ def test_attention_rising_maxima(D):
                                                  # one-launch (register-resident) plan: 5 / 10 / 15 chunk slabs, 256 and 512 threads, row counts
                                                  # below / not a multiple of the row lanes, a slab of four 10-channel groups, 4-channel groups
                                                  (2, 64, 1280, 32, True, False), (1, 256, 2560, 32, True, False), (2, 130, 1920, 32, False, False),
-                                                 (1, 600, 640, 32, True, False), (2, 20, 320, 32, True, False), (1, 97, 128, 32, True, False)])
+                                                 (1, 600, 640, 32, True, False), (2, 20, 320, 32, True, False), (1, 97, 128, 32, True, False),
+                                                 # team plan (HW >= 1024, B * slabs dividing 256): 2 / 4 / 8 slabs, ragged member row ranges
+                                                 (1, 1024, 320, 32, True, False), (2, 1030, 64, 8, False, False), (1, 1100, 640, 32, True, False)])
 def test_groupnorm(B, HW, C, G, silu, train):
     KC.case_groupnorm("cpu", B, HW, C, G, silu, train_params=train)
 

@@ -181,7 +181,11 @@ def test_attention_rising_maxima(Nq, Nk, D):
                                                  # the UNet's one-launch shapes (bs 4 / 8 / inference batch 32) + ragged row counts
                                                  (4, 64, 1280, 32, True, False), (4, 256, 2560, 32, True, False), (4, 256, 1920, 32, True, False),
                                                  (8, 1024, 640, 32, True, False), (4, 1024, 1280, 32, True, False), (32, 256, 1280, 32, True, False),
-                                                 (2, 1000, 640, 32, False, False), (3, 130, 1920, 32, True, False)])
+                                                 (2, 1000, 640, 32, False, False), (3, 130, 1920, 32, True, False),
+                                                 # team plan: the train step's 64x64 / 32x32 maps (bs 4, bs 8), batch 1 / 2, ragged rows
+                                                 (4, 4096, 320, 32, True, False), (4, 4096, 640, 32, True, False), (4, 4096, 960, 32, True, False),
+                                                 (4, 1024, 320, 32, True, False), (4, 1024, 960, 32, True, False), (8, 4096, 320, 32, True, False),
+                                                 (1, 4096, 320, 32, False, False), (2, 1500, 640, 32, True, False)])
 def test_groupnorm(B, HW, C, G, silu, train):
     KC.case_groupnorm(DEV, B, HW, C, G, silu, train_params=train)
 
@@ -411,3 +415,50 @@ def test_attention_forward_block_widths(waves, B, H, Nq, Nk, D):
         KC.case_attention(DEV, B, H, Nq, Nk, D)
     finally:
         K_.set_option("attn_fwd_waves", 0)
+
+
+def test_groupnorm_team_exchange_under_graph_replay_and_changing_geometry():
+    """The team kernels' in-launch exchange (include/clora.h clora_groupnorm_*_team) with everything that could expose a stale word:
+    launches of four geometries (8 / 16 / 32 units, 32 / 16 / 8 / 64 members) interleaved so that granule slots are re-used by units
+    whose epochs differ, 40 launch pairs captured in ONE hipGraph and replayed (frozen arguments: the epoch must come from the state),
+    consumers that have just read the same lines (L1-warm), a GEMM between the launches so that workgroups start unevenly.  Every
+    replay must give the bits of the first eager pass, which in turn agree with the two-launch scheme; no exchange may give up."""
+    g = torch.Generator().manual_seed(5)
+    f32 = torch.float32
+    shapes = [(4, 4096, 320), (4, 1024, 640), (8, 1024, 320), (2, 4096, 320), (4, 1024, 1280)]
+    data = []
+    for B, HW, C in shapes:
+        x, dy = KC.rnd((B, HW, C), DEV, g), KC.rnd((B, HW, C), DEV, g)
+        gamma, beta = 1 + 0.2 * KC.rnd((C,), DEV, g, dtype=f32), 0.2 * KC.rnd((C,), DEV, g, dtype=f32)
+        data.append((x, dy, gamma, beta))
+    A, W = KC.rnd((4096, 640), DEV, g), KC.rnd((640, 640), DEV, g)
+
+    def one_pass():
+        outs = []
+        for rep in range(4):
+            for x, dy, gamma, beta in data:
+                y, st = K.groupnorm_fwd(x, gamma, beta, 32, 1e-5, True)
+                K.gemm(A, W, 4096, 640, 640)
+                dx, _, _ = K.groupnorm_bwd(x, dy, gamma, beta, st, 32, True)
+                if rep == 3:
+                    outs += [y, st, dx]
+        return outs
+
+    K.set_option("gn_team", 0)
+    try:
+        ref = one_pass()
+    finally:
+        K.set_option("gn_team", int(os.environ.get("CLORA_GN_TEAM", "2")))
+    first = one_pass()
+    for a, b in zip(first, ref):
+        assert KC.rel(a, b) < 3e-4
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        captured = one_pass()
+    for _ in range(5):
+        graph.replay()
+        torch.cuda.synchronize()
+        for a, b in zip(captured, first):
+            assert torch.equal(a, b)
+    assert K.gn_team_errors(DEV) == 0
