@@ -2409,7 +2409,7 @@ extern "C" int clora_set_option(const char* name, int value) {
                                 {"lora_down_mode", CLORA_OPT_LORA_DOWN_MODE, 0, 2}, {"gn_unroll", CLORA_OPT_GN_UNROLL, 0, 1},
                                 {"epi_hoist", CLORA_OPT_EPI_HOIST, 0, 1}, {"gn_resident", CLORA_OPT_GN_RESIDENT, 0, 1},
                                 {"defer_max_rows", CLORA_OPT_DEFER_MAX_ROWS, 0, 16}, {"wgrad_patch", CLORA_OPT_WGRAD_PATCH, 0, 8192}, {"strip_blocks", CLORA_OPT_STRIP_BLOCKS, 64, 16384},
-                                {"gn_team", CLORA_OPT_GN_TEAM, 0, 2}};
+                                {"gn_team", CLORA_OPT_GN_TEAM, 0, 4}};
     for (const Opt& o : kOpts)
         if (!strcmp(name, o.name)) {
             if (value < o.lo || value > o.hi) return CLORA_ERR_ARG;

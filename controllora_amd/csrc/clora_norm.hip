@@ -1247,7 +1247,11 @@ GnResident gn_resident_plan(GnArgs& a, bool bwd, bool params) {
 // blocks of the launch; slabs are whole groups, 8-channel aligned, at most 512 channels (one reduction thread per channel); among the
 // feasible splits the one with the most slabs whose row segments are still >= 320 bytes (fewest granules to gather), else the fewest.
 int gn_team_plan(GnArgs& a, bool bwd, bool params, void* state, size_t state_bytes) {
-    if (!state || state_bytes < kTeamStateBytes || params || !clora_option(CLORA_OPT_GN_TEAM) || a.HW < 1024) return 0;
+    // smallest map by option level (measured, profiles/r06_gn_team_bench.txt): 1, 2 = 32x32 forward / 16x16 backward (the backward gains
+    // at 16x16 on every width, the forward only above 1280 channels); 3 = 16x16 both; 4 = 8x8 both (slower than one block per slab)
+    const int level = clora_option(CLORA_OPT_GN_TEAM);
+    const int min_hw = level >= 4 ? 64 : ((level == 3 || (bwd && level == 2)) ? 256 : 1024);
+    if (!state || state_bytes < kTeamStateBytes || params || !level || a.HW < min_hw) return 0;
     static int cus = -1;
     if (cus < 0) {
         int dev = 0, n = 0;
@@ -1350,7 +1354,10 @@ int gn_fwd_impl(const clora_half* x, const clora_half* x2, int Ca, const clora_d
         const int rc = clora_finish_deferred(src, stream);
         if (rc != CLORA_OK) return rc;
     }
-    if (!deferred_here && (!res.nt || (clora_option(CLORA_OPT_GN_TEAM) >= 2 && HW >= 1024))) {   // large maps: one launch, a team per unit
+    // large maps: one launch, a team per unit.  Shapes whose one-block-per-slab plan can fold a deferred producer keep that plan whether
+    // or not this call's input is deferred (deferring never changes the bits)
+    const bool fold_shape = res.nt && res.npt <= clora_option(CLORA_OPT_DEFER_MAX_ROWS);
+    if (!fold_shape && (!res.nt || clora_option(CLORA_OPT_GN_TEAM) >= 2)) {
         GnArgs ta = a;
         const int npt = gn_team_plan(ta, false, false, team_state, team_state_bytes);
         if (npt) {
@@ -1444,7 +1451,8 @@ int gn_bwd_impl(const clora_half* x, const clora_half* dy, const clora_deferred_
         const int rc = clora_finish_deferred(dy_src, stream);
         if (rc != CLORA_OK) return rc;
     }
-    if (!deferred_here && (!res.nt || (clora_option(CLORA_OPT_GN_TEAM) >= 2 && HW >= 1024))) {
+    const bool fold_shape = res.nt && res.npt <= clora_option(CLORA_OPT_DEFER_MAX_ROWS);      // see the forward
+    if (!fold_shape && (!res.nt || clora_option(CLORA_OPT_GN_TEAM) >= 2)) {
         GnArgs ta = a;
         const int npt = gn_team_plan(ta, true, dgamma != nullptr, team_state, team_state_bytes);
         if (npt) {

@@ -215,9 +215,11 @@ int clora_conv_strip_eligible(int M, int N, const clora_conv_t* conv);
  *                     and apply from the same registers: the 8x8 / 16x16 / 32x32 feature maps of the UNet); 0 = always the two-launch
  *                     partial + apply scheme.  Frozen affine only; same arithmetic, a different (still fixed) summation order.
  *   "gn_team"         the one-launch GroupNorm of the large maps (clora_groupnorm_*_team, needs the caller's team state): 2 (default) =
- *                     wherever the team plan applies (HW >= 1024); 1 = only where the two-launch scheme would run otherwise (the
- *                     one-block-per-slab kernels of "gn_resident" keep the 32x32 forward); 0 = never.  Same arithmetic, a different
- *                     (fixed) summation order.  Same-box A/B of the train step: 21.79 / 21.58 / 21.49 ms at 0 / 1 / 2.
+ *                     wherever the team plan applies, forward at HW >= 1024, backward at HW >= 256; 1 = only where the two-launch
+ *                     scheme would run otherwise (the one-block-per-slab kernels of "gn_resident" keep the 32x32 forward and the
+ *                     16x16 maps); 3 / 4 = both directions down to HW >= 256 / 64 (A/B settings); 0 = never.  Shapes whose
+ *                     one-block-per-slab plan may fold a deferred producer ("defer_max_rows") always keep that plan.  Same arithmetic,
+ *                     a different (fixed) summation order.  Same-box A/B of the train step: 21.79 / 21.58 / 21.49 ms at 0 / 1 / 2.
  *   "defer_max_rows"  a deferred split-K GEMM (clora_deferred_t) is folded inside the one-launch GroupNorm kernels whose threads own at
  *                     most this many rows (default 4: the 8x8 / 16x16 maps, where it is faster than finish + plain); above it -- and in
  *                     the LayerNorm backward unless the value is 16 -- the library runs the plain finish pass first.  0 = never fold.
