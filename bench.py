@@ -456,6 +456,9 @@ def main():
     ap.add_argument("--no-ddim", action="store_true", help="skip the secondary inference measurement")
     ap.add_argument("--no-graph", action="store_true", help="issue the step eagerly instead of replaying hipGraphs")
     ap.add_argument("--ddim-batch", type=int, default=16)
+    ap.add_argument("--mix-lora", default="none", choices=["none", "pre", "post", "both"],
+                    help="after the DDIM line: inject a plain rank-4 LoRACrossAttnProcessor into every control processor as pre / post "
+                         "LoRA (the arrangement of the reference's mix_lora_and_control_lora.py:109-123) and time the same sampler again")
     ap.add_argument("--config", default="fill50k.json", help="ControlLoRA config under configs/ (BASELINE configs[1] = fill50k.json; "
                     "mpii-pose-v2.json with --batch 8 is BASELINE configs[3])")
     ap.add_argument("--no-full-step", action="store_true", help="skip the secondary 'whole reference step' line (VAE + CLIP inside)")
@@ -590,6 +593,36 @@ def main():
         dt = time.perf_counter() - t1
         ddim = {"metric": f"50-step DDIM latency {args.res}^2 bs{nb} (CFG 9.0, UNet batch {2 * nb}, control batch 1)",
                 "latency_s": round(dt, 3), "images_per_s": round(nb / dt, 3), "finite": bool(torch.isfinite(out.float()).all())}
+        if args.mix_lora != "none":
+            # reference mix_lora_and_control_lora.py:109-123: one more LoRA per attention site, chained before / after the control
+            # adapter (models.py:232-243, 249-265, 276-282); the product runs chained sites on its generic (unfused) path
+            from controllora_amd import models as M
+            torch.manual_seed(11)
+            n_sites = 0
+            for procs in clora.lora_layers:
+                for proc in procs:
+                    other = M.LoRACrossAttnProcessor(proc.hidden_size, proc.cross_attention_dim, rank=4).to(dev)
+                    for q in other.parameters():
+                        q.requires_grad_(False)
+                        torch.nn.init.normal_(q, std=0.02)        # a trained LoRA: non-zero up matrices
+                    if args.mix_lora in ("pre", "both"):
+                        proc.inject_pre_lora(other)
+                    if args.mix_lora in ("post", "both"):
+                        proc.inject_post_lora(other)
+                    n_sites += 1
+            ddim_sample(unet, clora, batch["guide"][:1], cond, uncond, steps=2, latents=lat0)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            out2 = ddim_sample(unet, clora, batch["guide"][:1], cond, uncond, steps=50, guidance_scale=9.0, latents=lat0)
+            torch.cuda.synchronize()
+            dt2 = time.perf_counter() - t1
+            ddim["mix_lora"] = {"arrangement": args.mix_lora, "sites": n_sites, "latency_s": round(dt2, 3),
+                                "images_per_s": round(nb / dt2, 3), "finite": bool(torch.isfinite(out2.float()).all()),
+                                "differs_from_unmixed": bool((out2.float() - out.float()).abs().max() > 0)}
+            for procs in clora.lora_layers:
+                for proc in procs:
+                    proc.pre_loras.clear(); proc.post_loras.clear()
+            del out2
         del out, cond, uncond, lat0
         torch.cuda.empty_cache()
 
