@@ -343,7 +343,12 @@ def test_pipeline_prompt_to_image_on_the_emulator():
     a = pipe("red circle", guide[:1], num_samples=2, ddim_steps=2, scale=5.0, seed=5)
     assert a.shape == (2, 64, 64, 3) and a.dtype == torch.uint8
     b = pipe("red circle", guide, num_samples=2, ddim_steps=2, scale=5.0, seed=5)          # one guide per image
-    assert b.shape == a.shape and torch.equal(a[0], b[0]) and not torch.equal(a[1], b[1])   # image 0 sees the same guide both times
+    # image 0 sees the same guide both times, image 1 does not.  Not bit-equal: the hint encoder runs at control batch 1 vs 2 and the
+    # GroupNorm team plan (like the GEMM launch table) partitions its fp32 sums by the problem size -- a uint8 level here and there
+    d0 = (a[0].int() - b[0].int()).abs().float()
+    d1 = (a[1].int() - b[1].int()).abs().float()
+    # (measured: image 0 differs by <= 2 levels, 0.18 on average; image 1 by 5.9 on average, up to 40)
+    assert b.shape == a.shape and d0.max() <= 3 and d0.mean() < 0.5 and d1.mean() > 10 * d0.mean() and d1.max() > 20
     with pytest.raises(ValueError):
         pipe("red circle", torch.rand(3, 3, 64, 64), num_samples=2, ddim_steps=2, seed=5)
 

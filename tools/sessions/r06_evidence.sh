@@ -12,7 +12,7 @@ python tools/box_calib.py 2>&1 | grep BOX_CALIB | tee gpurun_out/r06_box_calib_$
 echo "pytest rc=$?" >> gpurun_out/r06_gputest_$TAG.log
 grep -E "passed|failed|rc=|^FAILED|^ERROR|NOTE " gpurun_out/r06_gputest_$TAG.log | cut -c1-300 | tail -8
 timeout 300 python __graft_entry__.py --smoke 2>&1 | tail -1 | tee gpurun_out/r06_smoke_$TAG.txt
-( time timeout 1200 python bench.py --trace-out gpurun_out/r06_kernel_stats_$TAG.json ) > gpurun_out/r06_bench_$TAG.log 2>&1
+( time timeout 1200 python bench.py --mix-lora post --trace-out gpurun_out/r06_kernel_stats_$TAG.json ) > gpurun_out/r06_bench_$TAG.log 2>&1
 grep '^{' gpurun_out/r06_bench_$TAG.log > gpurun_out/r06_bench_$TAG.json
 head -c 400 gpurun_out/r06_bench_$TAG.json; echo
 ( time timeout 900 python bench.py --config mpii-pose-v2.json --batch 8 --no-ddim --no-cpu-baseline --no-full-step --no-pmc --trace-out gpurun_out/r06_kernel_stats_v2_$TAG.json ) > gpurun_out/r06_bench_v2_$TAG.log 2>&1
