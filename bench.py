@@ -766,6 +766,8 @@ def main():
             "loss": round(loss, 5), "steps_skipped_by_scaler": skipped,
             # in-launch exchanges of the one-launch GroupNorm kernels that gave up (include/clora.h clora_groupnorm_*_team): must be 0
             "gn_team_errors": K.gn_team_errors(dev),
+            # compensated residual trunk (kernels.TrunkLo): "infer" = the samplers / validation only (the train step above is unaffected)
+            "trunk_lo": K.TRUNK_LO_MODE,
             "roofline": roofline, "ddim50": ddim, "full_step_with_vae_clip": full, "cpu_baseline": cpu}))
     trainer.close()
     if world > 1:

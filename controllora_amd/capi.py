@@ -40,7 +40,8 @@ class Epilogue(C.Structure):
                 ("geglu", C.c_int), ("geglu_f", C.c_int), ("geglu_h", C.c_void_p), ("geglu_y", C.c_void_p),
                 ("lora_dpack", C.c_void_p), ("lora_t_in", C.c_void_p), ("ldt_in", C.c_int), ("lora_t_in_rows", C.c_int),
                 ("lora_t_in_mask", C.c_uint), ("defer", C.c_void_p),
-                ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p), ("ln_out", C.c_void_p), ("ln_eps", C.c_float)]
+                ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p), ("ln_out", C.c_void_p), ("ln_eps", C.c_float),
+                ("residual_lo", C.c_void_p), ("c_lo", C.c_void_p)]                                              # compensated trunk
 
 
 class Deferred(C.Structure):

@@ -166,7 +166,8 @@ __device__ __forceinline__ void epi_chunk8_pre(float (&v)[8], int m, int n, cons
 
 // One 8-column chunk (n % 8 == 0) of row m of a split-K GEMM's output: fold the slabs (four slabs' loads in flight), epilogue, fp16,
 // + residual.  partial = [splits][M][N] fp32.
-__device__ __forceinline__ half8 finish_chunk8(const float* partial, int splits, int M, int N, const clora_epilogue_t& epi, int m, int n) {
+__device__ __forceinline__ half8 finish_chunk8(const float* partial, int splits, int M, int N, const clora_epilogue_t& epi, int m, int n,
+                                              half8* lo_out = nullptr) {
     float s[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) s[e] = 0.f;
@@ -176,8 +177,9 @@ __device__ __forceinline__ half8 finish_chunk8(const float* partial, int splits,
     // round trips after the fold)
     EpiOps ops;
     epi_issue(ops, m, n, epi);
-    half8 rr = zero8();
+    half8 rr = zero8(), rl = zero8();
     if (epi.residual) rr = ld8((const half_t*)epi.residual + (size_t)m * epi.ldr + n);
+    if (epi.residual_lo) rl = ld8((const half_t*)epi.residual_lo + (size_t)m * epi.ldr + n);
     int z = 0;
     for (; z + 4 <= splits; z += 4) {                        // four slabs' loads in flight (a load -> wait -> add loop paid one
         floatx4 a[4], b[4];                                  // L2 / HBM round trip per slab: up to 12 per output chunk)
@@ -201,6 +203,15 @@ __device__ __forceinline__ half8 finish_chunk8(const float* partial, int splits,
     half8 v;
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = (half_t)s[e];
+    if (epi.residual_lo || lo_out) {                          // compensated trunk (clora_epilogue_t.residual_lo / c_lo)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float sum = s[e] + (float)rr[e] + (float)rl[e];
+            v[e] = (half_t)sum;
+            if (lo_out) (*lo_out)[e] = (half_t)(sum - (float)v[e]);
+        }
+        return v;
+    }
     if (epi.residual) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = CLORA_RES_ADD(s[e], v[e], rr[e]);

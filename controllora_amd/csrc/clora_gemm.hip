@@ -204,7 +204,18 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
         const int m = m0 + ml, n = n0 + nc * 8;
         if (m < p.M && n < p.N) {
             half8 v = ld8(Cs + ml * C_LD + nc * 8);
-            if (p.epi.residual) {
+            if (p.epi.residual_lo || p.epi.c_lo) {            // compensated trunk (this round-1 kernel rounds the branch first)
+                half8 rr = zero8(), rl = zero8(), lo;
+                if (p.epi.residual) rr = ld8((const half_t*)p.epi.residual + (size_t)m * p.epi.ldr + n);
+                if (p.epi.residual_lo) rl = ld8((const half_t*)p.epi.residual_lo + (size_t)m * p.epi.ldr + n);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float sum = (float)v[e] + (float)rr[e] + (float)rl[e];
+                    v[e] = (half_t)sum;
+                    lo[e] = (half_t)(sum - (float)v[e]);
+                }
+                if (p.epi.c_lo) st8((half_t*)p.epi.c_lo + (size_t)m * p.ldc + n, lo);
+            } else if (p.epi.residual) {
                 const half8 rr = ld8((const half_t*)p.epi.residual + (size_t)m * p.epi.ldr + n);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)rr[e]);
@@ -332,7 +343,8 @@ __device__ __forceinline__ void dma_epilogue(const GemmArgs& p, floatx4 (&acc)[B
                        ((p.epi.ldt | ((n / p.epi.lora_seg) * 4)) & 3) == 0 && (p.epi.lora_u_tr ? (p.epi.ldu & 3) == 0 : p.epi.ldu == 4);
     // `two`: this thread takes the two-phase chunk loop -- adapter launches it can hoist, and launches without an adapter
     // (proj_in / proj_out / FF2 and the dgrads: bias and / or residual only)
-    const bool two = TWO_PHASE && p.two_phase && p.epi.geglu == 0 && !p.epi.rowadd && n < p.N && (hoist || p.epi.lora_t == nullptr);
+    const bool two = TWO_PHASE && p.two_phase && p.epi.geglu == 0 && !p.epi.rowadd && n < p.N && (hoist || p.epi.lora_t == nullptr) &&
+                     !p.epi.residual_lo && !p.epi.c_lo;         // (the compensated-trunk operands live in the one-chunk form only)
     floatx4 ureg[8];
     float bias8[8];
     int utoff = 0;
@@ -482,7 +494,18 @@ __device__ __forceinline__ void dma_epilogue(const GemmArgs& p, floatx4 (&acc)[B
                     st8(p.C + (size_t)m * p.ldc + F + n, dg);
                     return;
                 }
-                if (p.epi.residual) {                          // the sum is formed in fp32 and rounded ONCE (CLORA_RES_ADD, clora_epilogue.h)
+                if (p.epi.residual_lo || p.epi.c_lo) {         // compensated trunk: the sum continues from (residual + residual_lo) and its
+                    half8 rr = zero8(), rl = zero8(), lo;      // own rounding remainder goes to c_lo (include/clora.h)
+                    if (p.epi.residual) rr = ld8((const half_t*)p.epi.residual + (size_t)m * p.epi.ldr + n);
+                    if (p.epi.residual_lo) rl = ld8((const half_t*)p.epi.residual_lo + (size_t)m * p.epi.ldr + n);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float sum = v[e] + (float)rr[e] + (float)rl[e];
+                        o[e] = (half_t)sum;
+                        lo[e] = (half_t)(sum - (float)o[e]);
+                    }
+                    if (p.epi.c_lo) st8((half_t*)p.epi.c_lo + (size_t)m * p.ldc + n, lo);
+                } else if (p.epi.residual) {                   // the sum is formed in fp32 and rounded ONCE (CLORA_RES_ADD, clora_epilogue.h)
                     const half8 rr = ld8((const half_t*)p.epi.residual + (size_t)m * p.epi.ldr + n);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) o[e] = CLORA_RES_ADD(v[e], o[e], rr[e]);
@@ -1319,7 +1342,13 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(GemmArgs p, int spli
     for (size_t c = (size_t)blockIdx.x * 256 + threadIdx.x; c < chunks; c += (size_t)gridDim.x * 256) {
         const int m = (int)(c / (p.N / 8));
         const int n = (int)(c - (size_t)m * (p.N / 8)) * 8;
-        st8(p.C + (size_t)m * p.ldc + n, finish_chunk8(p.partial, splits, p.M, p.N, p.epi, m, n));     // clora_epilogue.h
+        if (p.epi.c_lo) {                                // compensated trunk: the rounding remainder beside C
+            half8 lo;
+            st8(p.C + (size_t)m * p.ldc + n, finish_chunk8(p.partial, splits, p.M, p.N, p.epi, m, n, &lo));
+            st8((half_t*)p.epi.c_lo + (size_t)m * p.ldc + n, lo);
+        } else {
+            st8(p.C + (size_t)m * p.ldc + n, finish_chunk8(p.partial, splits, p.M, p.N, p.epi, m, n));     // clora_epilogue.h
+        }
     }
 }
 
@@ -2201,6 +2230,9 @@ extern "C" int clora_gemm_f16_ex(const clora_half* A, int lda, const clora_half*
     if (a.epi.lora_t && (a.epi.lora_r <= 0 || a.epi.lora_seg <= 0 || (a.epi.lora_seg & 15))) return CLORA_ERR_ARG;
     if (a.epi.rowadd && a.epi.rows_per_batch <= 0) return CLORA_ERR_ARG;
     if (a.epi.residual && (a.epi.ldr & 7)) return CLORA_ERR_ARG;
+    // compensated trunk: residual_lo rides on residual's pitch, c_lo on C's; not with GEGLU, never deferred
+    if ((a.epi.residual_lo && !a.epi.residual) || ((a.epi.residual_lo || a.epi.c_lo) && (a.epi.geglu || !C || (ldc & 7))) || (a.epi.c_lo && defer))
+        return CLORA_ERR_ARG;
     if (a.epi.geglu) {
         const int F = a.epi.geglu_f;
         if (a.epi.geglu < 0 || a.epi.geglu > 2 || F <= 0 || (F & 63) || a.epi.rowadd || a.epi.residual || a.epi.lora_t) return CLORA_ERR_ARG;
@@ -2214,7 +2246,7 @@ extern "C" int clora_gemm_f16_ex(const clora_half* A, int lda, const clora_half*
     //        channels, kchunk 0, bias-only epilogue, C rows 8-byte aligned); anything it cannot take falls back to the library's own choice
     if (tile_cfg == 61) {
         const int plan = (a.conv.enabled && split_k <= 1 && !defer && !a.epi.rowadd && !a.epi.residual && !a.epi.lora_t && !a.epi.geglu &&
-                          !a.epi.ln_out && C && (ldc & 3) == 0 && K == 9 * a.conv.Cin)
+                          !a.epi.ln_out && !a.epi.c_lo && C && (ldc & 3) == 0 && K == 9 * a.conv.Cin)
                              ? strip_plan(M, N, a.conv) : 0;
         if (plan) {
             StripArgs q;

@@ -179,7 +179,7 @@ def gemm(A: torch.Tensor, Bw: torch.Tensor, M: int, N: int, K: int, *, lda: Opti
          split_k: int = 0, tile_cfg: int = 0, _tuned: bool = True,
          geglu: int = 0, geglu_h: Optional[torch.Tensor] = None, geglu_y: Optional[torch.Tensor] = None,
          geglu_keep_h: bool = True, lora_dpack: Optional[torch.Tensor] = None, lora_t_in: Optional[torch.Tensor] = None,
-         lora_t_in_mask: int = 0, lora_t_in_rows: int = 0, defer: bool = False, ln=None) -> torch.Tensor:
+         lora_t_in_mask: int = 0, lora_t_in_rows: int = 0, defer: bool = False, ln=None, trunk: bool = False) -> torch.Tensor:
     """C[M,N] = A . Bw^T with the fused epilogue of clora_epilogue_t.
     geglu=1 (Bw / bias packed by ops.GegluPack, N = 2F): returns (y [M,F], h [M,2F] or None when not geglu_keep_h);
     geglu=2 (N = F, geglu_h = the saved h): returns dh [M, 2F].
@@ -210,6 +210,21 @@ def gemm(A: torch.Tensor, Bw: torch.Tensor, M: int, N: int, K: int, *, lda: Opti
     if residual is not None:
         assert residual.dtype == f16 and residual.stride(-1) == 1
         e.residual, e.ldr = ptr(residual), (residual.stride(0) if residual.dim() == 2 else N)
+    # compensated residual trunk (clora_epilogue_t.residual_lo / c_lo): inside a TrunkLo window every launch that
+    # adds a residual -- the x + f(x) sums of the UNet -- and every launch flagged `trunk` (proj_in, the shortcut convs: where a trunk
+    # segment starts) also writes the rounding remainder of its output; the launch whose residual is that output picks it up
+    c_lo = None
+    want_lo_out = not _TRUNK_NO_OUT[0]
+    if _TRUNK_LO_ON[0] and not geglu and C_ is not None and C_.dim() == 2 and (residual is not None or (trunk and want_lo_out)):
+        if residual is not None:
+            hit = _TRUNK_LO.pop(residual.data_ptr(), None)
+            if hit is not None and hit[0].numel() == residual.numel() and (residual.stride(0) if residual.dim() == 2 else N) == e.ldr:
+                e.residual_lo = ptr(hit[1], f16)
+                _trunk_keep.append(hit)
+        if want_lo_out:
+            c_lo = torch.empty_strided(C_.shape, C_.stride(), dtype=f16, device=A.device)
+            e.c_lo = ptr(c_lo)
+            defer = False
     if lora_t is not None:
         assert lora_t.dtype == f32 and lora_u.dtype == f32 and lora_t.stride(1) == 1 and lora_u.stride(1) == 1
         e.lora_t, e.ldt, e.lora_u, e.ldu, e.lora_u_tr = ptr(lora_t), lora_t.stride(0), ptr(lora_u), lora_u.stride(0), int(lora_u_tr)
@@ -262,9 +277,64 @@ def gemm(A: torch.Tensor, Bw: torch.Tensor, M: int, N: int, K: int, *, lda: Opti
         if task >= 0 and _pending_task[0] != task:       # inside a backward pass: whatever nobody consumed is finished when the pass ends
             _pending_task[0] = task
             torch.autograd.Variable._execution_engine.queue_callback(flush_pending)
+    if c_lo is not None:
+        _TRUNK_LO[C_.data_ptr()] = (C_, c_lo)                # the strong reference to C_ keeps its address from being re-used
     if geglu == 1:
         return y, C_
     return C_
+
+
+# hi tensor's data_ptr -> (hi, lo): the rounding remainders of the trunk tensors written inside the current TrunkLo window
+_TRUNK_LO = {}
+_trunk_keep = []
+_TRUNK_LO_ON = [False]
+TRUNK_LO_MODE = os.environ.get("CLORA_TRUNK_LO", "infer")      # "infer": forwards without autograd; "always"; "off"
+
+
+class TrunkLo:
+    """`with TrunkLo(enabled):` around ONE UNet forward: residual sums continue from their un-rounded values (see gemm).  The
+    remainders live until the window closes (a captured hipGraph keeps the kernels, not these tensors)."""
+
+    def __init__(self, enabled: bool):
+        self.enabled = bool(enabled)
+
+    def __enter__(self):
+        self.prev = _TRUNK_LO_ON[0]
+        if self.enabled and not self.prev:
+            _TRUNK_LO.clear(); _trunk_keep.clear()
+        _TRUNK_LO_ON[0] = self.enabled or self.prev
+        return self
+
+    def __exit__(self, *exc):
+        _TRUNK_LO_ON[0] = self.prev
+        if not self.prev:
+            _TRUNK_LO.clear(); _trunk_keep.clear()
+        return False
+
+
+_TRUNK_NO_OUT = [False]
+
+
+class TrunkNoOut:
+    """`with TrunkNoOut(cond):` the residual launches inside still continue from the incoming remainder but do not write their own: the
+    caller knows that no residual add reads this sum (a transformer's last FeedForward sum feeds proj_out as an operand; up-path block
+    outputs go into a channel concatenation)."""
+
+    def __init__(self, cond: bool = True):
+        self.cond = bool(cond)
+
+    def __enter__(self):
+        self.prev = _TRUNK_NO_OUT[0]
+        _TRUNK_NO_OUT[0] = self.cond or self.prev
+        return self
+
+    def __exit__(self, *exc):
+        _TRUNK_NO_OUT[0] = self.prev
+        return False
+
+
+def trunk_lo_wanted() -> bool:
+    return TRUNK_LO_MODE == "always" or (TRUNK_LO_MODE == "infer" and not torch.is_grad_enabled())
 
 
 PATCH_TILE_CFGS = (71, 72, 73, 74, 75, 76, 77, 78, 79)     # conv3x3_patch_kernel variants of clora_gemm_f16_ex (77, 78: 392-pixel patch, rows >= 128 wide; 79: 256x160)

@@ -108,10 +108,10 @@ class ConvPack:
 # finish pass to that call.  Never set it where a torch-native op may read the tensor first.
 class _FrozenLinearFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, pack: LinearPack, residual, rowadd, rows_per_batch, defer_out=False, defer_dx=False, ln=None):
+    def forward(ctx, x, pack: LinearPack, residual, rowadd, rows_per_batch, defer_out=False, defer_dx=False, ln=None, trunk=False):
         M = x.shape[0]
         y = K.gemm(x, pack.w, M, pack.N, pack.K, bias=pack.bias, residual=residual, rowadd=rowadd,
-                   rows_per_batch=rows_per_batch, defer=defer_out and ln is None, ln=ln)
+                   rows_per_batch=rows_per_batch, defer=defer_out and ln is None, ln=ln, trunk=trunk)
         ctx.pack, ctx.has_res, ctx.defer_dx = pack, residual is not None, defer_dx
         return y
 
@@ -120,13 +120,14 @@ class _FrozenLinearFn(torch.autograd.Function):
         dy = dy.contiguous()
         p = ctx.pack
         dx = K.gemm(dy, p.wt, dy.shape[0], p.K, p.N, defer=ctx.defer_dx) if ctx.needs_input_grad[0] else None
-        return dx, None, (dy if ctx.has_res and ctx.needs_input_grad[2] else None), None, None, None, None, None
+        return dx, None, (dy if ctx.has_res and ctx.needs_input_grad[2] else None), None, None, None, None, None, None
 
 
-def frozen_linear(x, pack: LinearPack, residual=None, rowadd=None, rows_per_batch=0, defer_out=False, defer_dx=False, ln=None):
+def frozen_linear(x, pack: LinearPack, residual=None, rowadd=None, rows_per_batch=0, defer_out=False, defer_dx=False, ln=None, trunk=False):
     """y = x W^T + b (+ rowadd[batch]) (+ residual); x [M,K] fp16.  ln (kernels.LayerNormSlot): the LayerNorm that follows y, offered to
-    the launch (filled in ln.out where one tile spans the row, see kernels.gemm)."""
-    return _FrozenLinearFn.apply(x, pack, residual, rowadd, rows_per_batch, defer_out, defer_dx, ln)
+    the launch (filled in ln.out where one tile spans the row, see kernels.gemm).  trunk: y starts a stretch of the residual trunk
+    (proj_in, a resnet's shortcut conv): inside a kernels.TrunkLo window its rounding remainder is kept for the next residual add."""
+    return _FrozenLinearFn.apply(x, pack, residual, rowadd, rows_per_batch, defer_out, defer_dx, ln, trunk)
 
 
 class _FrozenConvFn(torch.autograd.Function):

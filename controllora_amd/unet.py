@@ -83,8 +83,8 @@ class Conv1x1(_Packed):
     def _build(self):
         return ops.LinearPack(self.weight, self.bias)
 
-    def forward(self, x, residual=None, defer_out=False, defer_dx=False, ln=None):
-        return ops.frozen_linear(x, self.pack(), residual, defer_out=defer_out, defer_dx=defer_dx, ln=ln)
+    def forward(self, x, residual=None, defer_out=False, defer_dx=False, ln=None, trunk=False):
+        return ops.frozen_linear(x, self.pack(), residual, defer_out=defer_out, defer_dx=defer_dx, ln=ln, trunk=trunk)
 
 
 class Linear(_Packed):
@@ -251,8 +251,9 @@ class BasicTransformerBlock(nn.Module):
         self.attn2 = CrossAttention(dim, cross_attention_dim, heads, dim_head)
         self.norm1, self.norm2, self.norm3 = LayerNorm(dim), LayerNorm(dim), LayerNorm(dim)
 
-    def forward(self, x, ehs, kw, pre_ln1=None):
-        """pre_ln1: norm1(x) as the launch that produced x already wrote it (Transformer2DModel.proj_in), or None"""
+    def forward(self, x, ehs, kw, pre_ln1=None, last=True):
+        """pre_ln1: norm1(x) as the launch that produced x already wrote it (Transformer2DModel.proj_in), or None; last: the block's output
+        feeds proj_out (an operand, not a residual add: no rounding remainder is kept for it, kernels.TrunkNoOut)"""
         B, N, C_ = x.shape
         grad = torch.is_grad_enabled() and x.requires_grad
         # the attention / feed-forward inputs below are LayerNorm outputs with no other consumer: their projections' dgrad GEMMs may
@@ -266,7 +267,8 @@ class BasicTransformerBlock(nn.Module):
         with ops.input_from_norm(), ops.next_layernorm(self.norm3.slot()) as s3:
             x = self.attn2(n, encoder_hidden_states=ehs, residual=xr, **kw)
         n, xr = self.norm3.fork(x, s3.out) if grad else (self.norm3(x, s3.out), x)
-        return self.ff(n.reshape(B * N, C_), xr.reshape(B * N, C_), defer_dx=grad).reshape(B, N, C_)
+        with K.TrunkNoOut(last):
+            return self.ff(n.reshape(B * N, C_), xr.reshape(B * N, C_), defer_dx=grad).reshape(B, N, C_)
 
 
 class Transformer2DModel(nn.Module):
@@ -278,16 +280,18 @@ class Transformer2DModel(nn.Module):
         self.transformer_blocks = nn.ModuleList([BasicTransformerBlock(inner, heads, dim_head, cross_attention_dim)])
         self.proj_out = Conv1x1(inner, in_channels)
 
-    def forward(self, x, ehs, kw, out_to_norm=False):
-        """out_to_norm: the caller feeds the result straight to a GroupNorm (see ops._FrozenLinearFn defer_out)"""
+    def forward(self, x, ehs, kw, out_to_norm=False, trunk_out=True):
+        """out_to_norm: the caller feeds the result straight to a GroupNorm (see ops._FrozenLinearFn defer_out); trunk_out = False: no
+        residual add will read the result (it goes into a channel concatenation / the output norm): kernels.TrunkNoOut"""
         B, N, C_ = x.shape
         grad = torch.is_grad_enabled() and x.requires_grad
         n, xr = self.norm.fork(x, False) if grad else (self.norm(x, False), x)
         s1 = self.transformer_blocks[0].norm1.slot()          # the first block's norm1, offered to proj_in's launch
-        h = self.proj_in(n.reshape(B * N, C_), defer_dx=grad, ln=s1).reshape(B, N, -1)
+        h = self.proj_in(n.reshape(B * N, C_), defer_dx=grad, ln=s1, trunk=True).reshape(B, N, -1)
         for i, blk in enumerate(self.transformer_blocks):
-            h = blk(h, ehs, kw, pre_ln1=s1.out if i == 0 else None)
-        return self.proj_out(h.reshape(B * N, -1), xr.reshape(B * N, C_), defer_out=out_to_norm).reshape(B, N, C_)
+            h = blk(h, ehs, kw, pre_ln1=s1.out if i == 0 else None, last=i == len(self.transformer_blocks) - 1)
+        with K.TrunkNoOut(not trunk_out):
+            return self.proj_out(h.reshape(B * N, -1), xr.reshape(B * N, C_), defer_out=out_to_norm).reshape(B, N, C_)
 
 
 # ------------------------------------------------------------------------------------------------ resnet / samplers
@@ -301,7 +305,7 @@ class ResnetBlock2D(nn.Module):
         self.conv2 = Conv3x3(cout, cout)
         self.conv_shortcut = Conv1x1(cin, cout) if cin != cout else None
 
-    def forward(self, x, temb_act, H, W, temb_proj=None, skip=None, out_to_norm=False):
+    def forward(self, x, temb_act, H, W, temb_proj=None, skip=None, out_to_norm=False, trunk_out=True):
         """skip: the block input is cat([x, skip], channels) (up blocks), read in place by norm1; out_to_norm: the caller feeds the
         result straight to a GroupNorm (a split-K conv2 then leaves its finish pass to that norm, ops._FrozenConvFn defer_out)"""
         B, N, _ = x.shape
@@ -321,8 +325,9 @@ class ResnetBlock2D(nn.Module):
         Cout = h.shape[1]
         h = self.norm2(h.reshape(B, N, Cout), True).reshape(B * N, Cout)
         x2 = xr.reshape(B * N, Cin)
-        sc = self.conv_shortcut(x2) if self.conv_shortcut is not None else x2
-        return self.conv2(h, B, H, W, residual=sc, defer_out=out_to_norm, defer_dx=grad).reshape(B, N, Cout)
+        sc = self.conv_shortcut(x2, trunk=True) if self.conv_shortcut is not None else x2
+        with K.TrunkNoOut(not trunk_out):              # (trunk_out = False: the result goes into a channel concatenation, see Transformer2DModel)
+            return self.conv2(h, B, H, W, residual=sc, defer_out=out_to_norm, defer_dx=grad).reshape(B, N, Cout)
 
 
 class Downsample2D(nn.Module):
@@ -514,7 +519,9 @@ class UNet2DConditionModel(nn.Module):
         tp = self._temb_projections(temb_act)
         ehs = encoder_hidden_states.to(f16).contiguous()
         from . import models as _models                  # (models imports this module: resolved at call time)
-        with _models.grouped_text_kv(self, ehs, kw):     # training: the text K|V projections of all sites, one launch per width
+        # K.TrunkLo: every residual sum of this forward continues from the un-rounded previous sum (compensated trunk, kernels.gemm;
+        # by default for forwards without autograd -- the samplers --, CLORA_TRUNK_LO = always / off for A/B)
+        with _models.grouped_text_kv(self, ehs, kw), K.TrunkLo(K.trunk_lo_wanted()):     # training: the text K|V projections of all sites, one launch per width
             return self._forward_blocks(sample, temb_act, tp, ehs, kw, return_dict)
 
     def _forward_blocks(self, sample, temb_act, tp, ehs, kw, return_dict):
@@ -542,18 +549,20 @@ class UNet2DConditionModel(nn.Module):
                 skips.append((x, H, W))
         x = self.mid_block.resnets[0](x, temb_act, H, W, tproj(self.mid_block.resnets[0]), out_to_norm=True)
         x = self.mid_block.attentions[0](x, ehs, kw, out_to_norm=True)
-        x = self.mid_block.resnets[1](x, temb_act, H, W, tproj(self.mid_block.resnets[1]), out_to_norm=CAT_IN_PLACE)
+        # (trunk_out=False from here on: every block output of the up path is concatenated with a skip tensor, or normed for conv_out --
+        # only a resnet in front of its own transformer is read by a residual add)
+        x = self.mid_block.resnets[1](x, temb_act, H, W, tproj(self.mid_block.resnets[1]), out_to_norm=CAT_IN_PLACE, trunk_out=False)
         for blk in self.up_blocks:
             for j, r in enumerate(blk.resnets):
                 s, _, _ = skips.pop()
                 if CAT_IN_PLACE:
                     nxt_norm = blk.has_attn or j < len(blk.resnets) - 1 or blk.upsamplers is None
-                    x = r(x, temb_act, H, W, tproj(r), skip=s, out_to_norm=nxt_norm)
+                    x = r(x, temb_act, H, W, tproj(r), skip=s, out_to_norm=nxt_norm, trunk_out=blk.has_attn)
                 else:
-                    x = r(ops.concat_channels(x, s), temb_act, H, W, tproj(r), out_to_norm=blk.has_attn)
+                    x = r(ops.concat_channels(x, s), temb_act, H, W, tproj(r), out_to_norm=blk.has_attn, trunk_out=blk.has_attn)
                 if blk.has_attn:
                     last = j == len(blk.resnets) - 1     # then: the upsampler conv, or conv_norm_out after the last block
-                    x = blk.attentions[j](x, ehs, kw, out_to_norm=(CAT_IN_PLACE and not last) or (last and blk.upsamplers is None))
+                    x = blk.attentions[j](x, ehs, kw, out_to_norm=(CAT_IN_PLACE and not last) or (last and blk.upsamplers is None), trunk_out=False)
             if blk.upsamplers is not None:
                 x = blk.upsamplers[0](x, H, W, out_to_norm=CAT_IN_PLACE)
                 H, W = 2 * H, 2 * W

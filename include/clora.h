@@ -111,6 +111,14 @@ typedef struct {
     const float* ln_beta;
     clora_half* ln_out;
     float ln_eps;
+    /* round 6 -- compensated residual trunk (the x + f(x) chain of upstream ResnetBlock2D / BasicTransformerBlock / Transformer2DModel,
+     * SURVEY.md A5-A7): c_lo != NULL (row pitch ldc) receives fp16(v - fp16(v)) for every element of C, v being the fp32 value that
+     * was rounded into C -- the rounding remainder; residual_lo != NULL (needs `residual`, row pitch ldr) is added to the residual in
+     * fp32, so that (residual, residual_lo) = the (C, c_lo) pair of the launch that wrote the trunk tensor continues the sum from its
+     * un-rounded value.  Every other consumer (norms, MFMA operands) reads C as before.  Not with GEGLU; a split-K launch that carries
+     * c_lo is never deferred (CLORA_ERR_ARG); tile_cfg 61 (strip kernel) is not taken. */
+    const clora_half* residual_lo;
+    clora_half* c_lo;
 } clora_epilogue_t;
 
 /* A deferred split-K GEMM (clora_epilogue_t.defer).  element (m, n) of the GEMM's output is

@@ -897,3 +897,43 @@ def case_feed_forward_fused(dev, M=200, C=64, seed=12, tile_cfg=0):
         assert h_inf is None
         out_inf = ops.feed_forward(x, p1, p2, res)
     assert rel(out_inf, out.detach()) < 1e-6
+
+
+def case_gemm_trunk_lo(dev, M, N, K_, split_k=1, tile_cfg=0, conv_like=False, lora=False, seed=41):
+    """Round 6, compensated residual trunk (include/clora.h clora_epilogue_t.residual_lo / c_lo): inside a kernels.TrunkLo window a chain
+    of three residual launches  x1 = A1 W^T + x0,  x2 = A2 W^T + x1,  x3 = A3 W^T + x2  (x0 from a launch flagged `trunk`) carries the
+    rounding remainder of every sum to the next add.  Checked: hi stays ONE fp16 rounding (2.0e-4 rel-L2) away from the un-rounded fp32
+    chain at every link, hi + lo reproduces the fp32 chain to fp32-accumulation accuracy (the plain chain is 3-4e-4
+    away from it), the window leaves nothing registered, and outside a window the same calls give the plain results bit for bit."""
+    g = torch.Generator().manual_seed(seed)
+    W = rnd((N, K_), dev, g, 1 / math.sqrt(K_))
+    As = [rnd((M, K_), dev, g) for _ in range(4)]
+    bias = rnd((N,), dev, g, dtype=f32)
+    kw = dict(split_k=split_k, tile_cfg=tile_cfg)
+    if lora:
+        kw.update(lora_t=rnd((M, 4), dev, g, dtype=f32), lora_u=rnd((N, 4), dev, g, 0.1, dtype=f32), lora_seg=N)
+    plain = [K.gemm(As[0], W, M, N, K_, bias=bias, **kw)]
+    for i in range(1, 4):
+        plain.append(K.gemm(As[i], W, M, N, K_, bias=bias, residual=plain[-1], **kw))
+    with K.TrunkLo(True):
+        hi = [K.gemm(As[0], W, M, N, K_, bias=bias, trunk=True, **kw)]
+        los = [K._TRUNK_LO[hi[0].data_ptr()][1]]
+        for i in range(1, 4):
+            hi.append(K.gemm(As[i], W, M, N, K_, bias=bias, residual=hi[-1].reshape(M, N), **kw))
+            los.append(K._TRUNK_LO[hi[-1].data_ptr()][1])
+            assert hi[-2].data_ptr() not in K._TRUNK_LO              # consumed by the add that read it
+    assert not K._TRUNK_LO and not K._TRUNK_LO_ON[0]
+    Wf = W.float().cpu()
+    upd = None
+    if lora:
+        upd = (kw["lora_t"].float().cpu() @ kw["lora_u"].float().cpu().T)
+    ref = torch.zeros(M, N)
+    for i in range(4):
+        ref = ref + As[i].float().cpu() @ Wf.T + bias.float().cpu() + (upd if upd is not None else 0)
+        comp = hi[i].float().cpu() + los[i].float().cpu()
+        assert rel(comp, ref) < 3e-6 * (i + 1) + 2e-6, (i, rel(comp, ref))
+        assert rel(hi[i], ref) < 2.3e-4                           # hi = ONE fp16 rounding away from the un-rounded chain at every link
+    assert torch.equal(hi[0], plain[0])                              # the first launch has no residual: same C, plus its remainder
+    assert rel(plain[3], ref) > 1.2 * rel(hi[3], ref) or rel(plain[3], ref) < 3e-4
+    again = K.gemm(As[1], W, M, N, K_, bias=bias, residual=plain[0], **kw)
+    assert torch.equal(again, plain[1])

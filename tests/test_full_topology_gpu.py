@@ -37,8 +37,13 @@ pytestmark = pytest.mark.gpu
 # train step pred 1.579 -> 1.490e-3 (v2 bs 8: 1.712 -> 1.609e-3), UNet batch 32 first evaluation 1.629 -> 1.516e-3, latents after step 5
 # 1.761 -> 1.639e-3, 50-step DDIM latents 1.955 -> 1.835e-3, VAE decode 1.515 -> 1.379e-3, worst per-parameter gradient norm 3.77 ->
 # 2.21e-3.  The asserted limits of pred / eps / latents are pulled in accordingly (latents <= 2.2e-3).
+# Round 6, compensated residual trunk (kernels.TrunkLo, clora_epilogue_t.residual_lo / c_lo; on by default for forwards without autograd, i.e.
+# every sampler): each residual sum continues from the un-rounded previous sum.  Same box, CLORA_TRUNK_LO = off / infer (default) / always
+# (profiles/r06_trunk_lo_ab.txt): UNet batch 32 first evaluation 1.514 -> 1.150e-3 (worst sample 1.642 -> 1.242e-3), latents after step 5
+# 1.632 -> 1.228e-3, 50-step DDIM latents 1.828 -> 1.378e-3; with "always" the train step's pred 1.490 -> 1.157e-3 (the default keeps the
+# training forward as it was: +0.25 ms/step otherwise).  eps / latents limits pulled in to 1.3 x the new measurements.
 FIX_EXPECT = dict(pred=1.8e-3, loss=1e-4, grads=5.5e-4, grads_norm=2.4e-4, control=3.7e-3, control_norm=3.5e-5, param_norm=2.9e-3,
-                  eps=1.8e-3, latents=2.1e-3)
+                  eps=1.35e-3, latents=1.6e-3)
 # Round 6: only the three quantities with a cited regime bound (pred / eps: 2.50e-3, latents: 2.85e-3) are asserted against
 # it; gradients, control maps and per-parameter norms keep the round-4 limits (1.3x the bit-stable measurements) UNLESS the fp16-regime
 # figure of that very quantity -- the oracle's own train step run in the reference's fp16 arithmetic in the same test
@@ -46,7 +51,7 @@ FIX_EXPECT = dict(pred=1.8e-3, loss=1e-4, grads=5.5e-4, grads_norm=2.4e-4, contr
 # 1.1 x measured regime value).  (Why it matters: a different-but-valid summation order, e.g. the grouped text K|V projection of round
 # 6, moves the worst of 400 per-parameter norm errors from 1.7e-3 to 3.8e-3 while pred / gradient samples IMPROVE.)
 FIX_TOL = dict(pred=2.0e-3, loss=1e-4, grads=5.5e-4, grads_norm=1.6e-4, control=3.7e-3, control_norm=3.5e-5, param_norm=2.5e-3,
-               eps=2.0e-3, latents=2.2e-3)
+               eps=1.5e-3, latents=1.8e-3)
 
 
 def _regime_limits(floor):
@@ -242,8 +247,9 @@ def test_baseline_inference_ddim50_512_vs_committed_oracle_fixture():
 
     north_star states "denoised latents within 1e-3 rel fp16".  The error budget at this exact configuration
     (tools/error_budget.py, profiles/r03_error_budget.json): the ORACLE ITSELF in the reference's fp16 arithmetic (stock torch
-    ops, fp16 weights / activations) sits 2.85e-3 from its fp32 run, with an fp32 residual trunk 2.62e-3; the product sits
-    1.94e-3 away.  1e-3 is below what fp16 storage of the branch activations allows any implementation at 50 steps, so the test
+    ops, fp16 weights / activations) sits 2.85e-3 from its fp32 run, with an fp32 residual trunk 2.62e-3; the product sat
+    1.94e-3 away through round 5 and sits 1.38e-3 away with round 6's single-rounded, compensated residual trunk (the fp32 oracle
+    carrying exactly the product's fp16 storage roundings reproduces the product to 2 %, profiles/r06_error_budget_trunk.txt).  The test
     pins (a) <= 1.3x the measured product error and (b) product error < the error of the reference's own fp16 arithmetic,
     re-measured here on the same inputs."""
     errs = F.ddim_vs_fixture("cuda", graph=True)

@@ -386,3 +386,9 @@ def test_gemm_eight_phase_random_shapes(zero_latency_dma_param):
         Kd = rng.choice([8, 40, 64, 72, 128, 136, 320, 456, 1032])
         split = rng.choice([1, 1, 2, 3]) if Kd >= 256 else 1
         KC.case_gemm_plain("cpu", M, N, Kd, split, seed=M + N + Kd, tile_cfg=59)
+
+
+@pytest.mark.parametrize("M,N,K_,split,tile,lora", [(150, 320, 128, 1, 0, False), (150, 320, 128, 1, 55, True), (200, 96, 64, 2, 0, False),
+                                                   (130, 64, 320, 1, 43, False), (100, 128, 64, 1, 1, False)])
+def test_gemm_compensated_trunk(M, N, K_, split, tile, lora):
+    KC.case_gemm_trunk_lo("cpu", M, N, K_, split_k=split, tile_cfg=tile, lora=lora)

@@ -462,3 +462,9 @@ def test_groupnorm_team_exchange_under_graph_replay_and_changing_geometry():
         for a, b in zip(captured, first):
             assert torch.equal(a, b)
     assert K.gn_team_errors(DEV) == 0
+
+
+@pytest.mark.parametrize("M,N,K_,split,tile,lora", [(16384, 320, 320, 1, 0, False), (16384, 320, 320, 1, 55, True), (1024, 1280, 1280, 3, 0, False),
+                                                   (4096, 640, 2560, 1, 0, False), (300, 96, 64, 1, 1, False)])
+def test_gemm_compensated_trunk(M, N, K_, split, tile, lora):
+    KC.case_gemm_trunk_lo(DEV, M, N, K_, split_k=split, tile_cfg=tile, lora=lora)
