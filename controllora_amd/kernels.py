@@ -220,7 +220,7 @@ def gemm(A: torch.Tensor, Bw: torch.Tensor, M: int, N: int, K: int, *, lda: Opti
             hit = _TRUNK_LO.pop(residual.data_ptr(), None)
             if hit is not None and hit[0].numel() == residual.numel() and (residual.stride(0) if residual.dim() == 2 else N) == e.ldr:
                 e.residual_lo = ptr(hit[1], f16)
-                _trunk_keep.append(hit)
+                _trunk_keep[:] = [hit]                       # alive across this launch call (afterwards the allocator's stream order protects it)
         if want_lo_out:
             c_lo = torch.empty_strided(C_.shape, C_.stride(), dtype=f16, device=A.device)
             e.c_lo = ptr(c_lo)
