@@ -35,6 +35,7 @@ def rel(a, b):
 
 @torch.no_grad()
 def main():
+    from controllora_amd import kernels as K
     from tests import full_cases as F
     dev = "cuda"
     res = int(sys.argv[2]) if len(sys.argv) > 2 else 512
@@ -77,8 +78,14 @@ def main():
         cum = rel(p_rec[n].reshape(oout_t.shape), oout_t)
         args, kwargs = p_args[n]
         x_p = args[0]
+        if kwargs.get("skip") is not None:                # up-path resnets (round 6): the product reads cat([x, skip]) in place -- split the oracle's input
+            Cx = x_p.shape[-1]
+            kwargs = dict(kwargs, skip=oin_t[..., Cx:].reshape(kwargs["skip"].shape).half().contiguous())
+            oin_t = oin_t[..., :Cx]
         x_o = oin_t.reshape(x_p.shape).half().contiguous()
-        local = rel(p_mods[n](x_o, *args[1:], **kwargs).reshape(oout_t.shape), oout_t)
+        out_p = p_mods[n](x_o, *args[1:], **kwargs)
+        K.flush_pending()                                 # (out_to_norm = True: a split-K producer may have left its finish to the next norm)
+        local = rel(out_p.reshape(oout_t.shape), oout_t)
         floor = rel(oout_t.half(), oout_t)
         rows.append({"module": n, "kind": type(p_mods[n]).__name__, "cumulative": cum, "local": local, "fp16_storage_floor": floor,
                      "tokens": int(oout_t.shape[1]), "channels": int(oout_t.shape[2])})
