@@ -349,6 +349,12 @@ class ControlLoRATrainer:
     # -- checkpoint / resume (train...:713-735 `accelerator.save_state / load_state`: weights, optimizer moments,
     # GradScaler state and the step counters; one flat tensor each because the trainer state IS flat)
     def state_dict(self) -> Dict[str, torch.Tensor]:
+        # a checkpoint is a host sync anyway: the place to notice that a one-launch GroupNorm gave up an in-launch exchange at some point
+        # (sticky flag of the team state, kernels.gn_team_errors) -- the weights would then come from at least one step on invalid norms
+        dev = self.flat.data.device
+        if dev.type == "cuda" and K.gn_team_errors(dev):
+            raise RuntimeError("a GroupNorm team kernel gave up an in-launch exchange during this run (kernels.gn_team_errors != 0): "
+                               "the state is not trustworthy; set CLORA_GN_TEAM=0 and report the device / co-tenant situation")
         return {"params": self.flat.data.detach().cpu().clone(), "exp_avg": self.flat.exp_avg.cpu().clone(),
                 "exp_avg_sq": self.flat.exp_avg_sq.cpu().clone(), "state": self.state.cpu().clone(),
                 "global_step": torch.tensor([self.global_step], dtype=torch.int64),
