@@ -41,7 +41,7 @@ pytestmark = pytest.mark.gpu
 # every sampler): each residual sum continues from the un-rounded previous sum.  Same box, CLORA_TRUNK_LO = off / infer (default) / always
 # (profiles/r06_trunk_lo_ab.txt): UNet batch 32 first evaluation 1.514 -> 1.150e-3 (worst sample 1.642 -> 1.242e-3), latents after step 5
 # 1.632 -> 1.228e-3, 50-step DDIM latents 1.828 -> 1.378e-3; with "always" the train step's pred 1.490 -> 1.157e-3 (the default keeps the
-# training forward as it was: +0.25 ms/step otherwise).  eps / latents limits pulled in to 1.3 x the new measurements.
+# training forward as it was: +0.19 ms/step otherwise).  eps / latents limits pulled in to 1.3 x the new measurements.
 FIX_EXPECT = dict(pred=1.8e-3, loss=1e-4, grads=5.5e-4, grads_norm=2.4e-4, control=3.7e-3, control_norm=3.5e-5, param_norm=2.9e-3,
                   eps=1.35e-3, latents=1.6e-3)
 # Round 6: only the three quantities with a cited regime bound (pred / eps: 2.50e-3, latents: 2.85e-3) are asserted against
